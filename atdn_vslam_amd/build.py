@@ -1,0 +1,68 @@
+"""Builds libatdn_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m atdn_vslam_amd.build [--force]
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container;
+the resulting .so travels to the GPU box with the repository snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libatdn_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "atdn_hip.h"))
+    return hs
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    newest = max([_mtime(os.path.join(CSRC, src))] + [_mtime(h) for h in _headers()])
+    if _mtime(obj) >= newest:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stdout))
+    if r.stdout.strip():
+        sys.stderr.write(r.stdout)
+    return obj, True
+
+
+def build(force=False, jobs=None):
+    """Compile every HIP translation unit for gfx950 and link the shared library. Returns its path."""
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        results = list(ex.map(_compile, _sources()))
+    objs = [o for o, _ in results]
+    if any(changed for _, changed in results) or not os.path.exists(LIB) or _mtime(LIB) < max(_mtime(o) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stdout)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

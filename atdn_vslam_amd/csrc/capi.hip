@@ -1,0 +1,242 @@
+// extern "C" boundary of libatdn_hip (see include/atdn_hip.h).
+#include "../../include/atdn_hip.h"
+
+#include <cmath>
+
+#include "clvo.h"
+#include "gma.h"
+
+namespace atdn {
+extern template TileChoice conv_dispatch<MODE_TAP, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiBias<ACT_RELU>>(const ConvShape&, EpiBias<ACT_RELU>, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_RELU>>(const ConvShape&, EpiBias<ACT_RELU>, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiScale>(const ConvShape&, EpiScale, hipStream_t);
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace atdn
+
+using namespace atdn;
+
+struct atdn_gma { GmaNet net; atdn_gma(int H, int W, int B) : net(H, W, B) {} };
+struct atdn_clvo { ClvoNet net; atdn_clvo(int H, int W, int B) : net(H, W, B) {} };
+
+#define ATDN_API_BEGIN try {
+#define ATDN_API_END                                      \
+  return 0;                                               \
+  } catch (const std::exception& e) {                     \
+    set_last_error(e.what());                             \
+    return 1;                                             \
+  } catch (...) {                                         \
+    set_last_error("unknown error");                      \
+    return 1;                                             \
+  }
+
+// host pose algebra helpers
+template <class T>
+static void euler_yxz(const T* r, T* R) {  // transforms.py:79-81
+  const T c1 = std::cos(r[0]), c2 = std::cos(r[1]), c3 = std::cos(r[2]);
+  const T s1 = std::sin(r[0]), s2 = std::sin(r[1]), s3 = std::sin(r[2]);
+  R[0] = c1 * c3 + s1 * s2 * s3; R[1] = c3 * s1 * s2 - c1 * s3; R[2] = c2 * s1;
+  R[3] = c2 * s3;                R[4] = c2 * c3;                R[5] = -s2;
+  R[6] = c1 * s2 * s3 - c3 * s1; R[7] = c1 * c3 * s2 + s1 * s3; R[8] = c1 * c2;
+}
+template <class T>
+static void make_transform(const T* rot, const T* tr, T* m) {
+  T R[9];
+  euler_yxz(rot, R);
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) m[i * 4 + j] = R[i * 3 + j]; m[i * 4 + 3] = tr[i]; }
+  m[12] = 0; m[13] = 0; m[14] = 0; m[15] = 1;
+}
+template <class T>
+static void matmul4(const T* a, const T* b, T* c) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      T s = 0;
+      for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+      c[i * 4 + j] = s;
+    }
+}
+
+extern "C" {
+
+int atdn_version(void) { return 100; }
+const char* atdn_last_error(void) { return g_last_error.c_str(); }
+
+int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(out, "null out pointer");
+  *out = new atdn_gma(H, W, max_batch);
+  ATDN_API_END
+}
+int atdn_gma_load(atdn_gma* h, const char* key, const float* data, const int64_t* shape, int rank) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && key && data && rank >= 0 && rank <= 4, "bad state-dict entry");
+  h->net.state().put(key, data, shape, rank);
+  ATDN_API_END
+}
+int atdn_gma_finalize(atdn_gma* h) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.finalize();
+  ATDN_API_END
+}
+int atdn_gma_forward(atdn_gma* h, const float* im1, const float* im2, int B, int iters, const float* flow_init,
+                     float* flow_low, float* flow_up, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.forward(im1, im2, B, iters, flow_init, flow_low, flow_up, (hipStream_t)stream);
+  ATDN_API_END
+}
+long atdn_gma_debug_read(atdn_gma* h, const char* name, float* host, long capacity, void* stream) {
+  try {
+    if (!h || !name || !host) throw Error("null argument");
+    const long n = h->net.debug_read(name, host, capacity, (hipStream_t)stream);
+    if (n < 0) throw Error(std::string("unknown tensor name: ") + name);
+    return n;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+int atdn_gma_profile(atdn_gma* h, int B, int iters, int reps, float* ms_out, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && ms_out, "null argument");
+  static_assert(GmaNet::ST_COUNT == ATDN_GMA_STAGES, "stage table out of sync with the header");
+  h->net.profile(B, iters, reps, ms_out, (hipStream_t)stream);
+  ATDN_API_END
+}
+size_t atdn_gma_workspace_bytes(atdn_gma* h) { return h ? h->net.workspace_bytes() : 0; }
+void atdn_gma_destroy(atdn_gma* h) { delete h; }
+
+int atdn_clvo_create(atdn_clvo** out, int H, int W, int max_batch) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(out, "null out pointer");
+  *out = new atdn_clvo(H, W, max_batch);
+  ATDN_API_END
+}
+int atdn_clvo_load(atdn_clvo* h, const char* key, const float* data, const int64_t* shape, int rank) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && key && data && rank >= 0 && rank <= 4, "bad state-dict entry");
+  h->net.state().put(key, data, shape, rank);
+  ATDN_API_END
+}
+int atdn_clvo_finalize(atdn_clvo* h) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.finalize();
+  ATDN_API_END
+}
+int atdn_clvo_encode(atdn_clvo* h, const float* flow, int B, float* feat, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && flow && feat, "null argument");
+  h->net.encode(flow, B, feat, (hipStream_t)stream);
+  ATDN_API_END
+}
+int atdn_clvo_step(atdn_clvo* h, const float* feat, int T, int Bs, float* state, float* rot, float* tr, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && feat && state && rot && tr, "null argument");
+  h->net.step(feat, T, Bs, state, rot, tr, (hipStream_t)stream);
+  ATDN_API_END
+}
+void atdn_clvo_destroy(atdn_clvo* h) { delete h; }
+
+// ------------------------------------------------------------------ pose algebra (host)
+int atdn_pose_transform_f32(const float* rot, const float* tr, float* mat16) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(rot && tr && mat16, "null argument");
+  make_transform(rot, tr, mat16);
+  ATDN_API_END
+}
+int atdn_pose_rel2abs(const float* rot, const float* tr, int T, double* poses) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(rot && tr && poses && T >= 0, "bad argument");
+  for (int i = 0; i < 16; ++i) poses[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int t = 0; t < T; ++t) {
+    const double r[3] = {rot[t * 3], rot[t * 3 + 1], rot[t * 3 + 2]};
+    const double x[3] = {tr[t * 3], tr[t * 3 + 1], tr[t * 3 + 2]};
+    double m[16];
+    make_transform(r, x, m);
+    matmul4(poses + (long)t * 16, m, poses + (long)(t + 1) * 16);
+  }
+  ATDN_API_END
+}
+int atdn_pose_accumulate_f32(float* pose16, const float* rot, const float* tr) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(pose16 && rot && tr, "null argument");
+  float m[16], o[16];
+  make_transform(rot, tr, m);
+  matmul4(pose16, m, o);
+  for (int i = 0; i < 16; ++i) pose16[i] = o[i];
+  ATDN_API_END
+}
+
+// ------------------------------------------------------------------ individual kernels
+int atdn_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, int B, int H8,
+                     int W8, const float* coords, float* out, int ldo, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(pyr0 && pyr1 && pyr2 && pyr3 && coords && out && B >= 1, "null argument");
+  ATDN_CHECK((H8 >> 3) >= 2 && (W8 >> 3) >= 2, "map too small for four pyramid levels");
+  PyramidLevels pl;
+  const float* b[4] = {pyr0, pyr1, pyr2, pyr3};
+  for (int l = 0; l < 4; ++l) { pl.base[l] = b[l]; pl.H[l] = H8 >> l; pl.W[l] = W8 >> l; }
+  launch_lookup(pl, coords, (long)B * H8 * W8, out, ldo, (hipStream_t)stream);
+  ATDN_API_END
+}
+
+int atdn_corr_pyramid(const float* fmap1, const float* fmap2, int B, int H8, int W8, int C, float* pyr0, float* pyr1,
+                      float* pyr2, float* pyr3, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(fmap1 && fmap2 && pyr0 && pyr1 && pyr2 && pyr3 && B >= 1 && C % 32 == 0, "bad argument");
+  const int N = H8 * W8;
+  ConvShape c;
+  c.src0 = fmap1; c.ld0 = C; c.sb0 = (long)N * C; c.C0 = C; c.H = 1; c.W = N;
+  c.w = fmap2; c.wb = (long)N * C; c.ldw = C; c.N = N; c.nimg = B;
+  conv_dispatch<MODE_TAP>(c, EpiScale{1.0f / sqrtf((float)C), pyr0, (long)N * N, N}, (hipStream_t)stream);
+  float* p[4] = {pyr0, pyr1, pyr2, pyr3};
+  for (int l = 1; l < 4; ++l) launch_avgpool(p[l - 1], H8 >> (l - 1), W8 >> (l - 1), p[l], (long)B * N, (hipStream_t)stream);
+  ATDN_API_END
+}
+
+int atdn_conv2d_nhwc(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
+                     const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, int relu,
+                     float* dst, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(src && weight_host && dst && nimg >= 1, "null argument");
+  const bool row = (Cin == 4 || Cin == 16);
+  ATDN_CHECK(row || Cin % 32 == 0, "Cin must be 4, 16 or a multiple of 32");
+  StateDict sd;
+  const int64_t ws[4] = {Cout, Cin, KH, KW};
+  sd.put("c.weight", weight_host, ws, 4);
+  std::vector<float> zb(Cout, 0.f);
+  const int64_t bs[1] = {Cout};
+  sd.put("c.bias", bias_host ? bias_host : zb.data(), bs, 1);
+  WeightArena A;
+  PackedConv L = pack_conv(A, sd, {"c"}, row ? MODE_ROW : MODE_TAP, Cin);
+  A.upload();
+  resolve(A, L);
+  ConvShape s;
+  s.src0 = src; s.ld0 = Cin; s.sb0 = (long)H * W * Cin; s.C0 = L.C; s.H = H; s.W = W;
+  s.KH = KH; s.KW = KW; s.stride = stride; s.padH = padH; s.padW = padW;
+  s.w = L.w; s.ldw = L.ldw; s.N = Cout; s.nimg = nimg;
+  const int Ho = conv_out(H, KH, stride, padH), Wo = conv_out(W, KW, stride, padW);
+  hipStream_t st = (hipStream_t)stream;
+  try {
+    if (row) {
+      if (relu) conv_dispatch<MODE_ROW>(s, EpiBias<ACT_RELU>{L.b, dst, (long)Ho * Wo * Cout, Cout, 1.f}, st);
+      else conv_dispatch<MODE_ROW>(s, EpiBias<ACT_NONE>{L.b, dst, (long)Ho * Wo * Cout, Cout, 1.f}, st);
+    } else {
+      if (relu) conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{L.b, dst, (long)Ho * Wo * Cout, Cout, 1.f}, st);
+      else conv_dispatch<MODE_TAP>(s, EpiBias<ACT_NONE>{L.b, dst, (long)Ho * Wo * Cout, Cout, 1.f}, st);
+    }
+    ATDN_HIP(hipStreamSynchronize(st));
+  } catch (...) {
+    A.release();
+    throw;
+  }
+  A.release();
+  ATDN_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// CLVO pose head `ATDNVO` (atdn_vslam/odometry/network.py:122-146): stateless CNN encoder (shardable over
+// frame pairs) + the sequential LSTM/MLP tail with explicit state.
+#pragma once
+#include "conv_dispatch.h"
+#include "kernels.h"
+#include "weights.h"
+#include "gma.h"  // DeviceBuf
+
+namespace atdn {
+
+class ClvoNet {
+ public:
+  ClvoNet(int H, int W, int max_batch);
+  ~ClvoNet();
+  StateDict& state() { return sd_; }
+  void finalize();
+  // flow NCHW [B,2,H,W] -> feat [B][512]
+  void encode(const float* flow, int B, float* feat, hipStream_t st);
+  // feat [T][Bs][512]; state [4][Bs][512] = h1,c1,h2,c2 (in/out); rot,tr [T][Bs][3]
+  void step(const float* feat, int T, int Bs, float* state, float* rot, float* tr, hipStream_t st);
+
+  int H, W, maxB;
+
+ private:
+  struct ConvBN { PackedConv conv; long sc_off = -1, sh_off = -1; const float* sc = nullptr; const float* sh = nullptr; };
+  struct Res { ConvBN a, b; PackedConv skip; long sc_off = -1, sh_off = -1; const float* sc = nullptr; const float* sh = nullptr; };
+  ConvBN pack_convbn(const std::string& p);
+
+  StateDict sd_;
+  WeightArena arena_;
+  bool ready_ = false;
+  ConvBN stem_, last_;
+  Res res_[4];
+  long dw_w_off_ = -1, dw_b_off_ = -1;
+  struct Lin { long w_off = -1, b_off = -1; const float* w = nullptr; const float* b = nullptr; };
+  Lin fc_, lstm1_ih_, lstm1_hh_, lstm_lin_, lstm2_ih_, lstm2_hh_, rot_[3], tr_[3];
+  Lin pack_linear(const std::string& wkey, const std::string& bkey, const std::vector<int>* perm = nullptr);
+
+  DeviceBuf in4_, bufA_, bufB_, bufS_, flat_, gates_, x2_;
+};
+
+}  // namespace atdn

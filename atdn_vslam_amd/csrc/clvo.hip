@@ -1,0 +1,154 @@
+// CLVO pose head on MI355X. Reference: atdn_vslam/odometry/network.py:63-73,122-146;
+// layers/conv.py:36-37,83-90; layers/linear.py:35-42; utils/normalizations.py:8-10.
+#include "clvo.h"
+
+namespace atdn {
+
+extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_ROW, EpiMishBN>(const ConvShape&, EpiMishBN, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_ROW, EpiMishBNSkipMishBN>(const ConvShape&, EpiMishBNSkipMishBN, hipStream_t);
+
+ClvoNet::ClvoNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) {
+  ATDN_CHECK(max_batch >= 1 && max_batch <= 256, "max_batch out of range");
+  // the head flattens a 16x4x13 map into Linear(832) (odometry/network.py:70-72): only some frame sizes fit
+  int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
+  for (int i = 0; i < 4; ++i) { h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1); }
+  h = conv_out(h, 3, 3, 0); w = conv_out(w, 3, 3, 0);
+  if (h * w * 16 != 832) {
+    char b[160];
+    snprintf(b, sizeof b, "ATDNVO needs a flow size that reduces to 16x4x13 (got 16x%dx%d from %dx%d)", h, w, H, W);
+    throw Error(b);
+  }
+}
+
+ClvoNet::~ClvoNet() {
+  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &gates_, &x2_}) b->release();
+  arena_.release();
+}
+
+ClvoNet::ConvBN ClvoNet::pack_convbn(const std::string& p) {
+  ConvBN c;
+  const int cin = (int)sd_.get(p + ".conv.weight").shape[1];
+  c.conv = pack_conv(arena_, sd_, {p + ".conv"}, MODE_ROW, cin <= 4 ? 4 : 16);
+  ChannelAffine a = bn_affine(sd_, p + ".bn");
+  std::vector<float> sc(a.scale.begin(), a.scale.end()), sh(a.shift.begin(), a.shift.end());
+  c.sc_off = pack_vector(arena_, sc);
+  c.sh_off = pack_vector(arena_, sh);
+  return c;
+}
+
+ClvoNet::Lin ClvoNet::pack_linear(const std::string& wkey, const std::string& bkey, const std::vector<int>* perm) {
+  Lin l;
+  const HostTensor& w = sd_.get(wkey);
+  const int N = (int)w.shape[0], K = (int)w.shape[1];
+  l.w_off = arena_.alloc((long)N * K);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) arena_.at(l.w_off)[(long)n * K + k] = w.data[(long)n * K + (perm ? (*perm)[k] : k)];
+  if (!bkey.empty()) l.b_off = pack_vector(arena_, sd_.get(bkey).data);
+  return l;
+}
+
+void ClvoNet::finalize() {
+  ATDN_CHECK(!ready_, "finalize called twice");
+  dw_w_off_ = pack_vector(arena_, sd_.get("encoder_CNN.0.weight").data);
+  dw_b_off_ = pack_vector(arena_, sd_.get("encoder_CNN.0.bias").data);
+  stem_ = pack_convbn("encoder_CNN.1");
+  for (int i = 0; i < 4; ++i) {
+    const std::string p = "encoder_CNN." + std::to_string(i + 2);
+    res_[i].a = pack_convbn(p + ".conv.0");
+    res_[i].b = pack_convbn(p + ".conv.1");
+    res_[i].skip = pack_conv(arena_, sd_, {p + ".skip_layer"}, MODE_ROW, 16);
+    ChannelAffine a = bn_affine(sd_, p + ".out_block.1");
+    std::vector<float> sc(a.scale.begin(), a.scale.end()), sh(a.shift.begin(), a.shift.end());
+    res_[i].sc_off = pack_vector(arena_, sc);
+    res_[i].sh_off = pack_vector(arena_, sh);
+  }
+  last_ = pack_convbn("encoder_CNN.6");
+  // Flatten is (C,H,W)-ordered in the reference; our activations are (H,W,C): permute the FC columns once
+  std::vector<int> perm(832);
+  for (int p = 0; p < 52; ++p)
+    for (int c = 0; c < 16; ++c) perm[p * 16 + c] = c * 52 + p;
+  fc_ = pack_linear("encoder_CNN.8.linear.weight", "encoder_CNN.8.linear.bias", &perm);
+  lstm1_ih_ = pack_linear("lstm1.weight_ih", "lstm1.bias_ih");
+  lstm1_hh_ = pack_linear("lstm1.weight_hh", "lstm1.bias_hh");
+  lstm_lin_ = pack_linear("lstm_linear.linear.weight", "lstm_linear.linear.bias");
+  lstm2_ih_ = pack_linear("lstm2.weight_ih", "lstm2.bias_ih");
+  lstm2_hh_ = pack_linear("lstm2.weight_hh", "lstm2.bias_hh");
+  const char* heads[2] = {"rotation_regressor", "translation_regressor"};
+  for (int hd = 0; hd < 2; ++hd) {
+    Lin* L = hd ? tr_ : rot_;
+    const std::string p = heads[hd];
+    L[0] = pack_linear(p + ".0.linear.weight", p + ".0.linear.bias");
+    L[1] = pack_linear(p + ".1.linear.weight", p + ".1.linear.bias");
+    L[2] = pack_linear(p + ".2.weight", "");
+  }
+  arena_.upload();
+  auto fix = [&](ConvBN& c) { resolve(arena_, c.conv); c.sc = arena_.dev(c.sc_off); c.sh = arena_.dev(c.sh_off); };
+  fix(stem_); fix(last_);
+  for (auto& r : res_) { fix(r.a); fix(r.b); resolve(arena_, r.skip); r.sc = arena_.dev(r.sc_off); r.sh = arena_.dev(r.sh_off); }
+  for (Lin* l : {&fc_, &lstm1_ih_, &lstm1_hh_, &lstm_lin_, &lstm2_ih_, &lstm2_hh_, &rot_[0], &rot_[1], &rot_[2],
+                 &tr_[0], &tr_[1], &tr_[2]}) {
+    l->w = arena_.dev(l->w_off);
+    l->b = l->b_off >= 0 ? arena_.dev(l->b_off) : nullptr;
+  }
+  const int h1 = conv_out(H, 7, 2, 3), w1 = conv_out(W, 7, 2, 3);
+  in4_.alloc((long)maxB * H * W * 4);
+  bufA_.alloc((long)maxB * h1 * w1 * 16);
+  bufB_.alloc((long)maxB * h1 * w1 * 16);
+  bufS_.alloc((long)maxB * h1 * w1 * 16 / 4 + 64);
+  flat_.alloc((long)maxB * 832);
+  gates_.alloc((long)maxB * 2048);
+  x2_.alloc((long)maxB * 512);
+  ready_ = true;
+}
+
+void ClvoNet::encode(const float* flow, int B, float* feat, hipStream_t st) {
+  ATDN_CHECK(ready_, "weights not finalized");
+  ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
+  launch_prep_flow(flow, B, H, W, arena_.dev(dw_w_off_), arena_.dev(dw_b_off_), in4_.p, st);
+  auto shape = [&](const PackedConv& L, const float* src, int h, int w, int stride, int pad) {
+    ConvShape s;
+    s.src0 = src; s.ld0 = L.C; s.sb0 = (long)h * w * L.C; s.C0 = L.C; s.H = h; s.W = w;
+    s.KH = L.KH; s.KW = L.KW; s.stride = stride; s.padH = pad; s.padW = pad;
+    s.w = L.w; s.ldw = L.ldw; s.N = L.N; s.nimg = B;
+    return s;
+  };
+  int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
+  float* x = bufA_.p; float* t = bufB_.p;
+  conv_dispatch<MODE_ROW>(shape(stem_.conv, in4_.p, H, W, 2, 3),
+                          EpiMishBN{stem_.conv.b, stem_.sc, stem_.sh, x, (long)h * w * 16, 16}, st);
+  for (int i = 0; i < 4; ++i) {
+    const Res& r = res_[i];
+    const int oh = conv_out(h, 3, 2, 1), ow = conv_out(w, 3, 2, 1);
+    conv_dispatch<MODE_ROW>(shape(r.a.conv, x, h, w, 1, 1), EpiMishBN{r.a.conv.b, r.a.sc, r.a.sh, t, (long)h * w * 16, 16}, st);
+    conv_dispatch<MODE_ROW>(shape(r.skip, x, h, w, 2, 0), EpiBias<ACT_NONE>{r.skip.b, bufS_.p, (long)oh * ow * 16, 16, 1.f}, st);
+    // x is dead after the skip conv: the block output overwrites it
+    conv_dispatch<MODE_ROW>(shape(r.b.conv, t, h, w, 2, 1),
+                            EpiMishBNSkipMishBN{r.b.conv.b, r.b.sc, r.b.sh, bufS_.p, (long)oh * ow * 16, 16, r.sc, r.sh, x,
+                                                (long)oh * ow * 16, 16}, st);
+    h = oh; w = ow;
+  }
+  const int fh = conv_out(h, 3, 3, 0), fw = conv_out(w, 3, 3, 0);
+  conv_dispatch<MODE_ROW>(shape(last_.conv, x, h, w, 3, 0),
+                          EpiMishBN{last_.conv.b, last_.sc, last_.sh, flat_.p, (long)fh * fw * 16, 16}, st);
+  launch_linear(fc_.w, flat_.p, 832, 832, nullptr, nullptr, 0, 0, fc_.b, nullptr, 1, feat, 512, 512, B, st);
+}
+
+void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, float* tr, hipStream_t st) {
+  ATDN_CHECK(ready_, "weights not finalized");
+  ATDN_CHECK(Bs >= 1 && Bs <= maxB && T >= 1, "bad sequence shape");
+  float* h1 = state; float* c1 = state + (long)Bs * 512; float* h2 = state + 2L * Bs * 512; float* c2 = state + 3L * Bs * 512;
+  const MlpHead R{rot_[0].w, rot_[0].b, rot_[1].w, rot_[1].b, rot_[2].w};
+  const MlpHead Tt{tr_[0].w, tr_[0].b, tr_[1].w, tr_[1].b, tr_[2].w};
+  for (int t = 0; t < T; ++t) {
+    const float* f = feat + (long)t * Bs * 512;
+    launch_linear(lstm1_ih_.w, f, 512, 512, lstm1_hh_.w, h1, 512, 512, lstm1_ih_.b, lstm1_hh_.b, 0, gates_.p, 2048, 2048, Bs, st);
+    launch_lstm_cell(gates_.p, c1, h1, Bs, 512, st);
+    launch_linear(lstm_lin_.w, h1, 512, 512, nullptr, nullptr, 0, 0, lstm_lin_.b, nullptr, 1, x2_.p, 512, 512, Bs, st);
+    launch_linear(lstm2_ih_.w, x2_.p, 512, 512, lstm2_hh_.w, h2, 512, 512, lstm2_ih_.b, lstm2_hh_.b, 0, gates_.p, 2048, 2048, Bs, st);
+    launch_lstm_cell(gates_.p, c2, h2, Bs, 512, st);
+    launch_mlp_heads(h2, Bs, R, Tt, rot + (long)t * Bs * 3, tr + (long)t * Bs * 3, st);
+  }
+}
+
+}  // namespace atdn

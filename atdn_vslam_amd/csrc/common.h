@@ -1,0 +1,56 @@
+// Shared host/device helpers for libatdn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+
+namespace atdn {
+
+void set_last_error(const std::string& msg);
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define ATDN_HIP(expr)                                                                      \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      char _b[512];                                                                         \
+      snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      throw ::atdn::Error(_b);                                                              \
+    }                                                                                       \
+  } while (0)
+
+#define ATDN_CHECK(cond, msg)                                                               \
+  do {                                                                                      \
+    if (!(cond)) {                                                                          \
+      char _b[512];                                                                         \
+      snprintf(_b, sizeof _b, "%s [%s] (%s:%d)", msg, #cond, __FILE__, __LINE__);           \
+      throw ::atdn::Error(_b);                                                              \
+    }                                                                                       \
+  } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline long cdivl(long a, long b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// Bijective XCD-aware remap of a 1-D block id: blocks that land on the same XCD
+// (observed round-robin: id % 8) receive a contiguous range of logical ids, so
+// neighbouring tiles share that XCD's L2. Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float mishf_(float x) {
+  const float sp = (x > 20.0f) ? x : log1pf(expf(x));
+  return x * tanhf(sp);
+}
+
+}  // namespace atdn

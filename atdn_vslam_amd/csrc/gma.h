@@ -1,0 +1,82 @@
+// GMA optical-flow forward (RAFTGMA.forward, test_mode=True) as one hipGraph of hand-written kernels.
+#pragma once
+#include <map>
+#include <memory>
+
+#include "conv_dispatch.h"
+#include "kernels.h"
+#include "weights.h"
+
+namespace atdn {
+
+struct EncoderWeights {
+  PackedConv stem;
+  struct Block { PackedConv c1, c2, ds; bool has_ds = false; } blk[6];
+  PackedConv head;
+};
+
+class DeviceBuf {
+ public:
+  float* p = nullptr;
+  long n = 0;
+  void alloc(long count) {
+    n = count;
+    ATDN_HIP(hipMalloc(&p, (size_t)count * sizeof(float)));
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; } }
+};
+
+class GmaNet {
+ public:
+  GmaNet(int H, int W, int max_batch);
+  ~GmaNet();
+  StateDict& state() { return sd_; }
+  void finalize();  // pack + upload weights, allocate the workspace
+  // im1/im2 NCHW [B,3,H,W] 0..255; flow_init NCHW [B,2,H/8,W/8] or null; outputs NCHW. All device pointers.
+  void forward(const float* im1, const float* im2, int B, int iters, const float* flow_init, float* flow_low,
+               float* flow_up, hipStream_t st);
+  // copy an internal tensor to host (parity tests); returns element count, or -1 for an unknown name
+  long debug_read(const char* name, float* host, long capacity, hipStream_t st);
+  size_t workspace_bytes() const { return ws_bytes_; }
+  // Eager (un-graphed) run on `st` with hipEvents at stage boundaries; ms[] receives the time of each Stage
+  // summed over `reps` forwards. Inputs are whatever the last forward() left in the workspace.
+  enum Stage { ST_FNET = 0, ST_CORR, ST_POOL, ST_CNET, ST_ATTN, ST_LOOKUP, ST_MOTION, ST_AGG, ST_GRU, ST_FLOWHEAD,
+               ST_MASK, ST_COUNT };
+  void profile(int B, int iters, int reps, float* ms, hipStream_t st);
+
+  int H, W, H8, W8, N, ldN, maxB;
+
+ private:
+  void run_body(int B, int iters, hipStream_t st);  // everything between input prep and upsampling
+  void run_encoder(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int* outH,
+                   int* outW);
+  void iteration(int B, hipStream_t st);
+  void capture(int B, int iters);
+
+  StateDict sd_;
+  WeightArena arena_;
+  bool ready_ = false;
+  bool use_graph_ = true;
+  EncoderWeights fnet_, cnet_;
+  PackedConv convc1_, convc2_, convf1_, convf2_, convm_, to_v_, to_qk_;
+  PackedConv gru_zr_[2], gru_q_[2], fh1_, fh2_, mask0_, mask2_;
+  const float* gamma_ = nullptr;
+  long gamma_off_ = -1;
+
+  // workspace
+  DeviceBuf img4_, enc_[3], fmap_, psum_, pm2_, mean_[2], rstd_[2];
+  DeviceBuf pyr_[4], h_[2], x_, qk_, attn_, vT_, corrfeat_, cor1_, corflo_, flo1_, z_, rh_, fh_, mask_;
+  DeviceBuf coords1_, flow4_;
+  int pyrH_[4], pyrW_[4];
+  int hcur_ = 0;
+  size_t ws_bytes_ = 0;
+
+  struct Timer;
+  Timer* timer_ = nullptr;
+  void mark(int stage, hipStream_t st);
+
+  hipStream_t cap_stream_ = nullptr;
+  std::map<std::pair<int, int>, hipGraphExec_t> graphs_;
+};
+
+}  // namespace atdn

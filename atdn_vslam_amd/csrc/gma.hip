@@ -1,0 +1,401 @@
+// GMA optical-flow forward on MI355X: encoders, all-pairs correlation pyramid, GMA attention, 12x
+// (lookup -> motion encoder -> attention aggregate -> separable ConvGRU -> flow head), mask head and
+// convex upsampling.  Reference: whl:GMA/core/network.py:72-129 and the blocks it calls.
+#include "gma.h"
+
+namespace atdn {
+
+extern template TileChoice conv_dispatch<MODE_TAP, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiBias<ACT_RELU>>(const ConvShape&, EpiBias<ACT_RELU>, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_RELU>>(const ConvShape&, EpiBias<ACT_RELU>, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiBiasStats>(const ConvShape&, EpiBiasStats, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_ROW, EpiBiasStats>(const ConvShape&, EpiBiasStats, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiBiasReluAddRelu>(const ConvShape&, EpiBiasReluAddRelu, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiContextSplit>(const ConvShape&, EpiContextSplit, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiScale>(const ConvShape&, EpiScale, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiQK>(const ConvShape&, EpiQK, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiStoreT>(const ConvShape&, EpiStoreT, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiAggregate>(const ConvShape&, EpiAggregate, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiGruZR>(const ConvShape&, EpiGruZR, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiGruQ>(const ConvShape&, EpiGruQ, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiFlowDelta>(const ConvShape&, EpiFlowDelta, hipStream_t);
+
+namespace {
+
+constexpr int XLD = 384;       // GRU input x = [inp | motion(126) flow(2) | motion_global]  (update.py:130)
+constexpr int CORR_LD = 352;   // 4*81 lookup channels padded to a multiple of 32
+
+ConvShape conv_shape(const PackedConv& L, const float* src, int ld, long sb, int nimg, int H, int W, int stride,
+                     int padH, int padW) {
+  ConvShape s;
+  s.src0 = src; s.ld0 = ld; s.sb0 = sb; s.C0 = L.C;
+  s.H = H; s.W = W; s.KH = L.KH; s.KW = L.KW; s.stride = stride; s.padH = padH; s.padW = padW;
+  s.w = L.w; s.ldw = L.ldw; s.N = L.N; s.nimg = nimg;
+  return s;
+}
+
+EncoderWeights pack_encoder(WeightArena& A, const StateDict& sd, const std::string& p, bool batchnorm) {
+  EncoderWeights E;
+  auto fold = [&](const std::string& norm) { return bn_affine(sd, norm); };
+  if (batchnorm) { auto a = fold(p + "norm1"); E.stem = pack_conv(A, sd, {p + "conv1"}, MODE_ROW, 4, &a); }
+  else E.stem = pack_conv(A, sd, {p + "conv1"}, MODE_ROW, 4);
+  int bi = 0;
+  for (int li = 1; li <= 3; ++li)
+    for (int k = 0; k < 2; ++k, ++bi) {
+      const std::string q = p + "layer" + std::to_string(li) + "." + std::to_string(k) + ".";
+      auto& B = E.blk[bi];
+      B.has_ds = (li > 1 && k == 0);
+      if (batchnorm) {
+        auto a1 = fold(q + "norm1"), a2 = fold(q + "norm2");
+        B.c1 = pack_conv(A, sd, {q + "conv1"}, MODE_TAP, 0, &a1);
+        B.c2 = pack_conv(A, sd, {q + "conv2"}, MODE_TAP, 0, &a2);
+        if (B.has_ds) { auto a3 = fold(q + "norm3"); B.ds = pack_conv(A, sd, {q + "downsample.0"}, MODE_TAP, 0, &a3); }
+      } else {
+        B.c1 = pack_conv(A, sd, {q + "conv1"}, MODE_TAP, 0);
+        B.c2 = pack_conv(A, sd, {q + "conv2"}, MODE_TAP, 0);
+        if (B.has_ds) B.ds = pack_conv(A, sd, {q + "downsample.0"}, MODE_TAP, 0);
+      }
+    }
+  E.head = pack_conv(A, sd, {p + "conv2"}, MODE_TAP, 0);
+  return E;
+}
+
+void resolve_encoder(const WeightArena& A, EncoderWeights& E) {
+  resolve(A, E.stem);
+  for (auto& b : E.blk) { resolve(A, b.c1); resolve(A, b.c2); if (b.has_ds) resolve(A, b.ds); }
+  resolve(A, E.head);
+}
+
+}  // namespace
+
+struct GmaNet::Timer {
+  std::vector<std::pair<int, hipEvent_t>> marks;  // (stage that ENDS at this event)
+  hipEvent_t start = nullptr;
+};
+
+void GmaNet::mark(int stage, hipStream_t st) {
+  if (!timer_) return;
+  hipEvent_t e;
+  ATDN_HIP(hipEventCreate(&e));
+  ATDN_HIP(hipEventRecord(e, st));
+  timer_->marks.emplace_back(stage, e);
+}
+
+void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
+  ATDN_CHECK(ready_ && B >= 1 && B <= maxB && reps >= 1, "bad profile request");
+  for (int i = 0; i < ST_COUNT; ++i) ms[i] = 0.f;
+  for (int r = 0; r < reps; ++r) {
+    Timer t;
+    timer_ = &t;
+    launch_init_coords(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
+    ATDN_HIP(hipEventCreate(&t.start));
+    ATDN_HIP(hipEventRecord(t.start, st));
+    try { run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
+    timer_ = nullptr;
+    ATDN_HIP(hipStreamSynchronize(st));
+    hipEvent_t prev = t.start;
+    for (auto& m : t.marks) {
+      float d = 0.f;
+      ATDN_HIP(hipEventElapsedTime(&d, prev, m.second));
+      ms[m.first] += d;
+      prev = m.second;
+    }
+    for (auto& m : t.marks) (void)hipEventDestroy(m.second);
+    (void)hipEventDestroy(t.start);
+  }
+}
+
+GmaNet::GmaNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) {
+  ATDN_CHECK(H % 8 == 0 && W % 8 == 0 && H >= 64 && W >= 64, "frame size must be a multiple of 8 (use the padder)");
+  ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
+  H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
+  const char* ng = getenv("ATDN_NO_GRAPH");
+  use_graph_ = !(ng && ng[0] == '1');
+}
+
+GmaNet::~GmaNet() {
+  for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+  if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
+                      &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
+                      &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_};
+  for (auto* b : all) b->release();
+  arena_.release();
+}
+
+void GmaNet::finalize() {
+  ATDN_CHECK(!ready_, "finalize called twice");
+  const std::string u = "update_block.";
+  fnet_ = pack_encoder(arena_, sd_, "fnet.", false);
+  cnet_ = pack_encoder(arena_, sd_, "cnet.", true);
+  convc1_ = pack_conv(arena_, sd_, {u + "encoder.convc1"}, MODE_TAP, 0);
+  convc2_ = pack_conv(arena_, sd_, {u + "encoder.convc2"}, MODE_TAP, 0);
+  convf1_ = pack_conv(arena_, sd_, {u + "encoder.convf1"}, MODE_ROW, 4);
+  convf2_ = pack_conv(arena_, sd_, {u + "encoder.convf2"}, MODE_TAP, 0);
+  convm_ = pack_conv(arena_, sd_, {u + "encoder.conv"}, MODE_TAP, 0);
+  to_v_ = pack_conv(arena_, sd_, {u + "aggregator.to_v"}, MODE_TAP, 0, nullptr, false);
+  to_qk_ = pack_conv(arena_, sd_, {"att.to_qk"}, MODE_TAP, 0, nullptr, false);
+  for (int p = 0; p < 2; ++p) {
+    const std::string t = std::to_string(p + 1);
+    gru_zr_[p] = pack_conv(arena_, sd_, {u + "gru.convz" + t, u + "gru.convr" + t}, MODE_TAP, 0);
+    gru_q_[p] = pack_conv(arena_, sd_, {u + "gru.convq" + t}, MODE_TAP, 0);
+  }
+  fh1_ = pack_conv(arena_, sd_, {u + "flow_head.conv1"}, MODE_TAP, 0);
+  fh2_ = pack_conv(arena_, sd_, {u + "flow_head.conv2"}, MODE_TAP, 0);
+  mask0_ = pack_conv(arena_, sd_, {u + "mask.0"}, MODE_TAP, 0);
+  mask2_ = pack_conv(arena_, sd_, {u + "mask.2"}, MODE_TAP, 0);
+  gamma_off_ = pack_vector(arena_, sd_.get(u + "aggregator.gamma").data);
+  arena_.upload();
+  resolve_encoder(arena_, fnet_);
+  resolve_encoder(arena_, cnet_);
+  for (PackedConv* L : {&convc1_, &convc2_, &convf1_, &convf2_, &convm_, &to_v_, &to_qk_, &gru_zr_[0], &gru_zr_[1],
+                        &gru_q_[0], &gru_q_[1], &fh1_, &fh2_, &mask0_, &mask2_})
+    resolve(arena_, *L);
+  gamma_ = arena_.dev(gamma_off_);
+
+  // ---- workspace (sized for maxB pairs; everything stays resident in HBM between calls)
+  const int B = maxB;
+  const int H2 = conv_out(H, 7, 2, 3), W2 = conv_out(W, 7, 2, 3);
+  const long n8 = (long)B * N;
+  img4_.alloc(2L * B * H * W * 4);
+  for (auto& e : enc_) e.alloc(2L * B * H2 * W2 * 64);
+  fmap_.alloc(2L * B * N * 256);
+  const long groups = (long)cdiv(H2 * W2, 64) * 4 + 8;
+  psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128);
+  for (int i = 0; i < 2; ++i) { mean_[i].alloc(2L * B * 128); rstd_[i].alloc(2L * B * 128); }
+  pyrH_[0] = H8; pyrW_[0] = W8;
+  for (int l = 1; l < 4; ++l) { pyrH_[l] = pyrH_[l - 1] / 2; pyrW_[l] = pyrW_[l - 1] / 2; }
+  ATDN_CHECK(pyrH_[3] >= 2 && pyrW_[3] >= 2, "frame too small for a 4-level pyramid");
+  for (int l = 0; l < 4; ++l) pyr_[l].alloc(n8 * pyrH_[l] * pyrW_[l]);
+  h_[0].alloc(n8 * 128); h_[1].alloc(n8 * 128); x_.alloc(n8 * XLD);
+  qk_.alloc(n8 * 256); attn_.alloc(n8 * ldN); vT_.alloc((long)B * 128 * ldN);
+  corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
+  z_.alloc(n8 * 128); rh_.alloc(n8 * 128); fh_.alloc(n8 * 256); mask_.alloc(n8 * 576);
+  coords1_.alloc(n8 * 2); flow4_.alloc(n8 * 4);
+  // pad lanes that kernels read but never write must be finite zeros
+  ATDN_HIP(hipMemset(corrfeat_.p, 0, corrfeat_.n * sizeof(float)));
+  ATDN_HIP(hipMemset(vT_.p, 0, vT_.n * sizeof(float)));
+  ATDN_HIP(hipMemset(attn_.p, 0, attn_.n * sizeof(float)));
+  ATDN_HIP(hipMemset(flow4_.p, 0, flow4_.n * sizeof(float)));
+  ATDN_HIP(hipDeviceSynchronize());
+  ws_bytes_ = 0;
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &fmap_, &psum_, &pm2_, &pyr_[0], &pyr_[1], &pyr_[2],
+                      &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_, &corrfeat_, &cor1_, &corflo_, &flo1_, &z_,
+                      &rh_, &fh_, &mask_, &coords1_, &flow4_};
+  for (auto* b : all) ws_bytes_ += (size_t)b->n * sizeof(float);
+  ATDN_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
+  ready_ = true;
+}
+
+// BasicEncoder.forward (extractor.py:165-189). instance=true: InstanceNorm (fnet); false: BatchNorm folded (cnet).
+void GmaNet::run_encoder(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int* outH,
+                         int* outW) {
+  int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
+  float* P = enc_[0].p; float* Q = enc_[1].p; float* R = enc_[2].p;
+  auto stats_conv = [&](auto mode_tag, const PackedConv& L, const float* src, int ld, int ih, int iw, int stride,
+                        int pad, float* dst, int slot) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    ConvShape s = conv_shape(L, src, ld, (long)ih * iw * ld, nimg, ih, iw, stride, pad, pad);
+    const int oh = conv_out(ih, L.KH, stride, pad), ow = conv_out(iw, L.KW, stride, pad);
+    EpiBiasStats ep{L.b, dst, (long)oh * ow * L.N, L.N, psum_.p, pm2_.p, 0};
+    TileChoice t = conv_dispatch<MODE>(s, ep, st);
+    const int groups = cdiv(oh * ow, t.BM) * (t.BM / 32);
+    ATDN_CHECK((long)nimg * groups * L.N <= psum_.n, "statistics scratch too small");
+    launch_in_finalize(psum_.p, pm2_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p, st);
+  };
+  using TapT = std::integral_constant<int, MODE_TAP>;
+  using RowT = std::integral_constant<int, MODE_ROW>;
+
+  // stem: conv 7x7/2 + norm + relu
+  if (instance) {
+    stats_conv(RowT{}, E.stem, img4_.p, 4, H, W, 2, 3, P, 0);
+    launch_in_apply(P, mean_[0].p, rstd_[0].p, nullptr, nullptr, nullptr, nimg, (long)h * w, 64, st);
+  } else {
+    ConvShape s = conv_shape(E.stem, img4_.p, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
+    conv_dispatch<MODE_ROW>(s, EpiBias<ACT_RELU>{E.stem.b, P, (long)h * w * 64, 64, 1.f}, st);
+  }
+  int c = 64;
+  for (int bi = 0; bi < 6; ++bi) {
+    const auto& Bk = E.blk[bi];
+    const int stride = Bk.has_ds ? 2 : 1;
+    const int co = Bk.c1.N;
+    const int oh = conv_out(h, 3, stride, 1), ow = conv_out(w, 3, stride, 1);
+    const long ohw = (long)oh * ow;
+    if (instance) {
+      stats_conv(TapT{}, Bk.c1, P, c, h, w, stride, 1, Q, 0);
+      launch_in_apply(Q, mean_[0].p, rstd_[0].p, nullptr, nullptr, nullptr, nimg, ohw, co, st);
+      stats_conv(TapT{}, Bk.c2, Q, co, oh, ow, 1, 1, R, 0);
+      if (Bk.has_ds) {
+        stats_conv(TapT{}, Bk.ds, P, c, h, w, 2, 0, Q, 1);
+        launch_in_apply(R, mean_[0].p, rstd_[0].p, Q, mean_[1].p, rstd_[1].p, nimg, ohw, co, st);
+      } else {
+        launch_in_apply(R, mean_[0].p, rstd_[0].p, P, nullptr, nullptr, nimg, ohw, co, st);
+      }
+      std::swap(P, R);  // block output becomes the next input; Q, R are free again
+    } else {
+      ConvShape s1 = conv_shape(Bk.c1, P, c, (long)h * w * c, nimg, h, w, stride, 1, 1);
+      conv_dispatch<MODE_TAP>(s1, EpiBias<ACT_RELU>{Bk.c1.b, Q, ohw * co, co, 1.f}, st);
+      ConvShape s2 = conv_shape(Bk.c2, Q, co, ohw * co, nimg, oh, ow, 1, 1, 1);
+      if (Bk.has_ds) {
+        ConvShape sd = conv_shape(Bk.ds, P, c, (long)h * w * c, nimg, h, w, 2, 0, 0);
+        conv_dispatch<MODE_TAP>(sd, EpiBias<ACT_NONE>{Bk.ds.b, R, ohw * co, co, 1.f}, st);
+        // P (the block input) is dead once the downsample conv has read it: reuse it for the output
+        conv_dispatch<MODE_TAP>(s2, EpiBiasReluAddRelu{Bk.c2.b, R, ohw * co, co, P, ohw * co, co}, st);
+      } else {
+        conv_dispatch<MODE_TAP>(s2, EpiBiasReluAddRelu{Bk.c2.b, P, ohw * co, co, R, ohw * co, co}, st);
+        std::swap(P, R);
+      }
+    }
+    h = oh; w = ow; c = co;
+  }
+  *out_buf = P; *outH = h; *outW = w;
+}
+
+void GmaNet::iteration(int B, hipStream_t st) {
+  const long n8 = (long)B * N;
+  // -- index the correlation pyramid at the current coordinates (corr.py:32-53)
+  PyramidLevels pl;
+  for (int l = 0; l < 4; ++l) { pl.base[l] = pyr_[l].p; pl.H[l] = pyrH_[l]; pl.W[l] = pyrW_[l]; }
+  launch_lookup(pl, coords1_.p, n8, corrfeat_.p, CORR_LD, st);
+  mark(ST_LOOKUP, st);
+
+  // -- motion encoder (update.py:76-84); torch.cat is realised by writing channel slices
+  ConvShape s = conv_shape(convc1_, corrfeat_.p, CORR_LD, (long)N * CORR_LD, B, H8, W8, 1, 0, 0);
+  conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{convc1_.b, cor1_.p, (long)N * 256, 256, 1.f}, st);
+  s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
+  conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256, 1.f}, st);
+  s = conv_shape(convf1_, flow4_.p, 4, (long)N * 4, B, H8, W8, 1, 3, 3);
+  conv_dispatch<MODE_ROW>(s, EpiBias<ACT_RELU>{convf1_.b, flo1_.p, (long)N * 128, 128, 1.f}, st);
+  s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256, 1.f}, st);
+  s = conv_shape(convm_, corflo_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
+  float* mf = x_.p + 128;  // motion_features: 126 conv channels + 2 flow channels (written by the flow update)
+  conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{convm_.b, mf, (long)N * XLD, XLD, 1.f}, st);
+  mark(ST_MOTION, st);
+
+  // -- global motion aggregation (gma.py:102-115): v^T, then attn @ v with the residual fused
+  s = conv_shape(to_v_, mf, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
+  conv_dispatch<MODE_TAP>(s, EpiStoreT{vT_.p, (long)128 * ldN, ldN}, st);
+  ConvShape a;
+  a.src0 = attn_.p; a.ld0 = ldN; a.sb0 = (long)N * ldN; a.C0 = ldN; a.H = 1; a.W = N;
+  a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
+  conv_dispatch<MODE_TAP>(a, EpiAggregate{gamma_, mf, (long)N * XLD, XLD, x_.p + 256, (long)N * XLD, XLD}, st);
+  mark(ST_AGG, st);
+
+  // -- separable ConvGRU (update.py:48-63): horizontal (1x5) then vertical (5x1)
+  for (int p = 0; p < 2; ++p) {
+    const float* hin = h_[p].p;
+    float* hout = h_[p ^ 1].p;
+    const int ph = p ? 2 : 0, pw = p ? 0 : 2;
+    ConvShape g = conv_shape(gru_zr_[p], hin, 128, (long)N * 128, B, H8, W8, 1, ph, pw);
+    g.C0 = 128; g.src1 = x_.p; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = XLD;
+    conv_dispatch<MODE_TAP>(g, EpiGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128}, st);
+    g.src0 = rh_.p; g.w = gru_q_[p].w; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
+    conv_dispatch<MODE_TAP>(g, EpiGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128}, st);
+  }
+  // two passes: the state is back in h_[0]
+  mark(ST_GRU, st);
+
+  // -- flow head (update.py:7-15) and coordinate update (network.py:116)
+  s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{fh1_.b, fh_.p, (long)N * 256, 256, 1.f}, st);
+  s = conv_shape(fh2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
+  conv_dispatch<MODE_TAP>(s, EpiFlowDelta{fh2_.b, coords1_.p, flow4_.p, x_.p + 254, XLD, (long)N * XLD, W8, (long)N}, st);
+  mark(ST_FLOWHEAD, st);
+}
+
+void GmaNet::run_body(int B, int iters, hipStream_t st) {
+  // ---- feature network on [im1 batch ‖ im2 batch] (network.py:86)
+  float* f; int fh, fw;
+  run_encoder(fnet_, true, 2 * B, st, &f, &fh, &fw);
+  ATDN_CHECK(fh == H8 && fw == W8, "encoder geometry mismatch");
+  ConvShape s = conv_shape(fnet_.head, f, 128, (long)N * 128, 2 * B, H8, W8, 1, 0, 0);
+  conv_dispatch<MODE_TAP>(s, EpiBias<ACT_NONE>{fnet_.head.b, fmap_.p, (long)N * 256, 256, 1.f}, st);
+  mark(ST_FNET, st);
+
+  // ---- all-pairs correlation (corr.py:55-63) and its 4-level pyramid (corr.py:28-30)
+  ConvShape c;
+  c.src0 = fmap_.p; c.ld0 = 256; c.sb0 = (long)N * 256; c.C0 = 256; c.H = 1; c.W = N;
+  c.w = fmap_.p + (long)B * N * 256; c.wb = (long)N * 256; c.ldw = 256; c.N = N; c.nimg = B;
+  conv_dispatch<MODE_TAP>(c, EpiScale{1.0f / sqrtf(256.0f), pyr_[0].p, (long)N * N, N}, st);
+  mark(ST_CORR, st);
+  for (int l = 1; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
+  mark(ST_POOL, st);
+
+  // ---- context network on im1 (network.py:94-97): tanh -> hidden state, relu -> x[:, 0:128]
+  run_encoder(cnet_, false, B, st, &f, &fh, &fw);
+  s = conv_shape(cnet_.head, f, 128, (long)N * 128, B, H8, W8, 1, 0, 0);
+  conv_dispatch<MODE_TAP>(s, EpiContextSplit{cnet_.head.b, h_[0].p, (long)N * 128, x_.p, (long)N * XLD, XLD}, st);
+  mark(ST_CNET, st);
+
+  // ---- attention (gma.py:54-76): q,k projection, q·k^T, row softmax
+  s = conv_shape(to_qk_, x_.p, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
+  conv_dispatch<MODE_TAP>(s, EpiQK{1.0f / sqrtf(128.0f), 128, qk_.p, (long)N * 256, 256}, st);
+  ConvShape q;
+  q.src0 = qk_.p; q.ld0 = 256; q.sb0 = (long)N * 256; q.C0 = 128; q.H = 1; q.W = N;
+  q.w = qk_.p + 128; q.wb = (long)N * 256; q.ldw = 256; q.N = N; q.nimg = B;
+  conv_dispatch<MODE_TAP>(q, EpiScale{1.0f, attn_.p, (long)N * ldN, ldN}, st);
+  launch_softmax_rows(attn_.p, (long)B * N, N, ldN, st);
+  mark(ST_ATTN, st);
+
+  for (int it = 0; it < iters; ++it) iteration(B, st);
+
+  // ---- mask head, once (update.py:120-123,138): only the last iteration's mask reaches the output
+  s = conv_shape(mask0_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{mask0_.b, fh_.p, (long)N * 256, 256, 1.f}, st);
+  s = conv_shape(mask2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 0, 0);
+  conv_dispatch<MODE_TAP>(s, EpiBias<ACT_NONE>{mask2_.b, mask_.p, (long)N * 576, 576, 0.25f}, st);
+  mark(ST_MASK, st);
+}
+
+void GmaNet::capture(int B, int iters) {
+  hipGraph_t graph = nullptr;
+  ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
+  try {
+    run_body(B, iters, cap_stream_);
+  } catch (...) {
+    (void)hipStreamEndCapture(cap_stream_, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    throw;
+  }
+  ATDN_HIP(hipStreamEndCapture(cap_stream_, &graph));
+  hipGraphExec_t exec = nullptr;
+  ATDN_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(graph);
+  graphs_[{B, iters}] = exec;
+}
+
+void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const float* flow_init, float* flow_low,
+                     float* flow_up, hipStream_t st) {
+  ATDN_CHECK(ready_, "weights not finalized");
+  ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
+  ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
+  ATDN_CHECK(im1 && im2 && flow_low && flow_up, "null tensor");
+  launch_prep_images(im1, im2, B, H, W, img4_.p, st);
+  launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
+  if (use_graph_) {
+    auto key = std::make_pair(B, iters);
+    if (!graphs_.count(key)) capture(B, iters);
+    ATDN_HIP(hipGraphLaunch(graphs_[key], st));
+  } else {
+    run_body(B, iters, st);
+  }
+  launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
+}
+
+long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_t st) {
+  const std::string k(name);
+  const DeviceBuf* b = nullptr;
+  if (k == "fmap") b = &fmap_; else if (k == "pyr0") b = &pyr_[0]; else if (k == "pyr1") b = &pyr_[1];
+  else if (k == "pyr2") b = &pyr_[2]; else if (k == "pyr3") b = &pyr_[3]; else if (k == "net") b = &h_[0];
+  else if (k == "x") b = &x_; else if (k == "attn") b = &attn_; else if (k == "corrfeat") b = &corrfeat_;
+  else if (k == "mask") b = &mask_; else if (k == "coords1") b = &coords1_; else if (k == "flow4") b = &flow4_;
+  else if (k == "qk") b = &qk_; else if (k == "img4") b = &img4_;
+  if (!b) return -1;
+  const long n = std::min(capacity, b->n);
+  ATDN_HIP(hipStreamSynchronize(st));
+  ATDN_HIP(hipMemcpy(host, b->p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return n;
+}
+
+}  // namespace atdn

@@ -1,0 +1,56 @@
+// Non-GEMM kernels of the odometry path (host launchers; implementations in kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace atdn {
+
+struct PyramidLevels {  // correlation pyramid of ONE batch: level l is [B*N][H_l*W_l] fp32
+  const float* base[4];
+  int H[4], W[4];
+};
+
+// frames NCHW [B,3,H,W] (0..255) x2 -> NHWC4 [2B][H][W][4] = 2*(x/255)-1, 4th channel 0   (network.py:75-76)
+void launch_prep_images(const float* im1, const float* im2, int B, int H, int W, float* img4, hipStream_t st);
+
+// InstanceNorm statistics from the conv epilogue's per-group partials -> mean, rstd  [nimg][C]
+void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, int groups_per_img, int HW, int C,
+                        float eps, float* mean, float* rstd, hipStream_t st);
+// y = relu((x-mean)*rstd); optional residual: y = relu(r + y), r = res or (res-rmean)*rrstd when rmean given
+void launch_in_apply(float* x, const float* mean, const float* rstd, const float* res, const float* rmean,
+                     const float* rrstd, int nimg, long HW, int C, hipStream_t st);
+
+// 2x2/stride-2 average pooling of the last two dims of [rows][H][W] (floor)   (corr.py:28-30)
+void launch_avgpool(const float* src, int H, int W, float* dst, long rows, hipStream_t st);
+
+// radius-4 bilinear pyramid lookup  (corr.py:32-53): out[p][l*81 + i*9 + j], ldo >= 324
+void launch_lookup(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
+                   hipStream_t st);
+
+// in-place row softmax of [rows][ld] over the first n columns; columns [n, ld) are zeroed   (gma.py:74)
+void launch_softmax_rows(float* x, long rows, int n, int ld, hipStream_t st);
+
+// coords1 = grid (+ flow_init NCHW [B,2,H8,W8]); flow4 / x flow channels = coords1 - coords0
+void launch_init_coords(const float* flow_init, int B, int H8, int W8, float* coords1, float* flow4, float* xflow,
+                        int ldx, hipStream_t st);
+
+// convex 8x upsampling (network.py:59-70) straight into caller tensors: flow_up NCHW [B,2,8H8,8W8], flow_low [B,2,H8,W8]
+void launch_upsample(const float* mask, const float* flow4, int B, int H8, int W8, float* flow_low, float* flow_up,
+                     hipStream_t st);
+
+// ---- CLVO head
+// flow NCHW [B,2,H,W] -> NHWC4: (x/std_c)*dw_w[c] + dw_b[c]    (normalizations.py:8-10, odometry/network.py:64)
+void launch_prep_flow(const float* flow, int B, int H, int W, const float* dw_w, const float* dw_b, float* out4,
+                      hipStream_t st);
+// y[b][n] = act( W0[n]·x0[b] (+ W1[n]·x1[b]) + b0[n] (+ b1[n]) ),  act: 0 none, 1 mish
+void launch_linear(const float* W0, const float* x0, int K0, int ldx0, const float* W1, const float* x1, int K1,
+                   int ldx1, const float* b0, const float* b1, int act, float* y, int ldy, int N, int B,
+                   hipStream_t st);
+// LSTMCell pointwise part, gate order i,f,g,o; gates [B][4*Hd]; c in/out, h out
+void launch_lstm_cell(const float* gates, float* c, float* h, int B, int Hd, hipStream_t st);
+// both regressors (512 -> 128 -> 64 -> 3, Mish, last layer no bias): out rot [B][3], tr [B][3]
+struct MlpHead { const float *w0, *b0, *w1, *b1, *w2; };
+void launch_mlp_heads(const float* h2, int B, MlpHead rot, MlpHead tr, float* rot_out, float* tr_out, hipStream_t st);
+
+void launch_fill(float* p, long n, float v, hipStream_t st);
+
+}  // namespace atdn

@@ -1,0 +1,411 @@
+// Non-GEMM kernels of the odometry path, gfx950. Wave = 64 lanes throughout.
+#include "kernels.h"
+
+namespace atdn {
+
+// ------------------------------------------------------------------ block reductions (deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+template <bool MAX>
+__device__ __forceinline__ float block_reduce(float v, float* sm) {  // blockDim 256
+  v = MAX ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float a = sm[0], b = sm[1], c = sm[2], d = sm[3];
+  return MAX ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : ((a + b) + (c + d));
+}
+
+// ------------------------------------------------------------------ frame preparation
+__global__ void prep_images_kernel(const float* __restrict__ im1, const float* __restrict__ im2, int B, long HW,
+                                   float4* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2L * B * HW) return;
+  const long img = i / HW, p = i - img * HW;
+  const float* src = (img < B ? im1 + img * 3 * HW : im2 + (img - B) * 3 * HW) + p;
+  float4 v;
+  v.x = 2.f * (src[0] / 255.0f) - 1.0f;
+  v.y = 2.f * (src[HW] / 255.0f) - 1.0f;
+  v.z = 2.f * (src[2 * HW] / 255.0f) - 1.0f;
+  v.w = 0.f;
+  out[i] = v;
+}
+void launch_prep_images(const float* im1, const float* im2, int B, int H, int W, float* img4, hipStream_t st) {
+  const long n = 2L * B * H * W;
+  hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, im1, im2, B, (long)H * W,
+                     reinterpret_cast<float4*>(img4));
+  ATDN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ instance norm
+__global__ void in_finalize_kernel(const float* __restrict__ ps, const float* __restrict__ pm2, int nimg, int groups,
+                                   int HW, int C, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nimg * C) return;
+  const int img = i / C, c = i - img * C;
+  const int ng = (HW + 31) / 32;  // groups that hold at least one valid row
+  const float* s = ps + (long)img * groups * C + c;
+  const float* m = pm2 + (long)img * groups * C + c;
+  double tot = 0.0;
+  for (int g = 0; g < ng; ++g) tot += (double)s[(long)g * C];
+  const double mu = tot / (double)HW;
+  double m2 = 0.0;
+  for (int g = 0; g < ng; ++g) {
+    const int cnt = min(32, HW - g * 32);
+    const double gm = (double)s[(long)g * C] / cnt - mu;
+    m2 += (double)m[(long)g * C] + cnt * gm * gm;  // Chan et al. merge of (count, mean, M2)
+  }
+  mean[i] = (float)mu;
+  rstd[i] = (float)(1.0 / sqrt(m2 / (double)HW + (double)eps));
+}
+void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, int groups_per_img, int HW, int C,
+                        float eps, float* mean, float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(nimg * C, 64)), dim3(64), 0, st, part_sum, part_m2, nimg,
+                     groups_per_img, HW, C, eps, mean, rstd);
+  ATDN_HIP(hipGetLastError());
+}
+
+__global__ void in_apply_kernel(float4* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float4* __restrict__ res, const float* __restrict__ rmean,
+                                const float* __restrict__ rrstd, long per_img4, int C, long total4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long img = i / per_img4;
+    const int c = (int)((i * 4) % C);
+    const float* mu = mean + img * C + c;
+    const float* rs = rstd + img * C + c;
+    float4 v = x[i];
+    v.x = fmaxf((v.x - mu[0]) * rs[0], 0.f);
+    v.y = fmaxf((v.y - mu[1]) * rs[1], 0.f);
+    v.z = fmaxf((v.z - mu[2]) * rs[2], 0.f);
+    v.w = fmaxf((v.w - mu[3]) * rs[3], 0.f);
+    if (res) {
+      float4 r = res[i];
+      if (rmean) {
+        const float* m2 = rmean + img * C + c;
+        const float* r2 = rrstd + img * C + c;
+        r.x = (r.x - m2[0]) * r2[0]; r.y = (r.y - m2[1]) * r2[1];
+        r.z = (r.z - m2[2]) * r2[2]; r.w = (r.w - m2[3]) * r2[3];
+      }
+      v.x = fmaxf(r.x + v.x, 0.f); v.y = fmaxf(r.y + v.y, 0.f);
+      v.z = fmaxf(r.z + v.z, 0.f); v.w = fmaxf(r.w + v.w, 0.f);
+    }
+    x[i] = v;
+  }
+}
+void launch_in_apply(float* x, const float* mean, const float* rstd, const float* res, const float* rmean,
+                     const float* rrstd, int nimg, long HW, int C, hipStream_t st) {
+  ATDN_CHECK(C % 4 == 0, "in_apply needs C % 4 == 0");
+  const long per_img4 = HW * C / 4, total4 = per_img4 * nimg;
+  const int grid = (int)std::min<long>(cdivl(total4, 256), 256 * 16);
+  hipLaunchKernelGGL(in_apply_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<float4*>(x), mean, rstd,
+                     reinterpret_cast<const float4*>(res), rmean, rrstd, per_img4, C, total4);
+  ATDN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ pyramid pooling
+__global__ void avgpool_kernel(const float* __restrict__ src, int H, int W, int Ho, int Wo, float* __restrict__ dst,
+                               long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / (Ho * Wo);
+    const int rem = (int)(i - row * (Ho * Wo));
+    const int y = rem / Wo, x = rem - y * Wo;
+    const float* p = src + row * ((long)H * W) + (long)(2 * y) * W + 2 * x;
+    dst[i] = (((p[0] + p[1]) + p[W]) + p[W + 1]) * 0.25f;
+  }
+}
+void launch_avgpool(const float* src, int H, int W, float* dst, long rows, hipStream_t st) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = rows * Ho * Wo;
+  const int grid = (int)std::min<long>(cdivl(total, 256), 256 * 32);
+  hipLaunchKernelGGL(avgpool_kernel, dim3(grid), dim3(256), 0, st, src, H, W, Ho, Wo, dst, total);
+  ATDN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ correlation-pyramid lookup
+// One wave per (source pixel, level): the <=10x10 window around the sampling centre is staged in LDS
+// (two cells per lane), then lanes produce the 81 bilinear samples and store them as one contiguous run.
+__global__ __launch_bounds__(256) void lookup_kernel(const PyramidLevels pyr, const float* __restrict__ coords1,
+                                                     long npix, float* __restrict__ out, int ldo) {
+  __shared__ float win[4][10 * 10 + 4];
+  const int lvl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Hl = pyr.H[lvl], Wl = pyr.W[lvl];
+  const float inv = 1.0f / (float)(1 << lvl);
+  float* w = win[lvl];
+  for (long p = blockIdx.x; p < npix; p += gridDim.x) {
+    const float xc = coords1[p * 2 + 0] * inv, yc = coords1[p * 2 + 1] * inv;
+    const bool sane = (fabsf(xc) < 1.0e6f) && (fabsf(yc) < 1.0e6f);  // also rejects NaN
+    const float xf = sane ? floorf(xc) : -1.0e5f, yf = sane ? floorf(yc) : -1.0e5f;
+    const float fx = sane ? xc - xf : 0.f, fy = sane ? yc - yf : 0.f;
+    const int wx0 = (int)xf - 4, wy0 = (int)yf - 4;
+    const float* src = pyr.base[lvl] + p * ((long)Hl * Wl);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int c = lane + 64 * t;
+      if (c < 100) {
+        const int wy = c / 10, wx = c - wy * 10;
+        const int y = wy0 + wy, x = wx0 + wx;
+        const bool ok = ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
+        w[c] = ok ? src[(long)y * Wl + x] : 0.f;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);          // LDS writes of this wave done (one wave owns win[lvl])
+    __builtin_amdgcn_wave_barrier();
+    const float nw = (1.f - fx) * (1.f - fy), ne = fx * (1.f - fy), sw = (1.f - fx) * fy, se = fx * fy;
+    float* o = out + p * ldo + lvl * 81;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = lane + 64 * t;
+      if (k < 81) {
+        const int i = k / 9, j = k - i * 9;  // i steps x, j steps y (RAFT's transposed window)
+        const float* q = w + j * 10 + i;
+        o[k] = ((nw * q[0] + ne * q[1]) + sw * q[10]) + se * q[11];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // all reads done before the next pixel overwrites the window
+  }
+}
+void launch_lookup(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
+                   hipStream_t st) {
+  ATDN_CHECK(ldo >= 324, "lookup output row too short");
+  const int grid = (int)std::min<long>(npix_total, 256 * 16);
+  hipLaunchKernelGGL(lookup_kernel, dim3(grid), dim3(256), 0, st, pyr, coords1, npix_total, out, ldo);
+  ATDN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ row softmax (attention)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int n, int ld) {
+  __shared__ float sm[4];
+  float* row = x + (long)blockIdx.x * ld;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, row[i]);
+  mx = block_reduce<true>(mx, sm);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float e = expf(row[i] - mx);
+    row[i] = e;
+    s += e;
+  }
+  s = block_reduce<false>(s, sm);
+  for (int i = threadIdx.x; i < n; i += 256) row[i] = row[i] / s;
+  for (int i = n + threadIdx.x; i < ld; i += 256) row[i] = 0.f;
+}
+void launch_softmax_rows(float* x, long rows, int n, int ld, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, n, ld);
+  ATDN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ coordinate / flow state
+__global__ void init_coords_kernel(const float* __restrict__ flow_init, int B, int H8, int W8,
+                                   float* __restrict__ coords1, float* __restrict__ flow4, float* __restrict__ xflow,
+                                   int ldx) {
+  const long N = (long)H8 * W8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N) return;
+  const long img = i / N;
+  const int m = (int)(i - img * N);
+  const float x0 = (float)(m % W8), y0 = (float)(m / W8);
+  float fx = 0.f, fy = 0.f;
+  if (flow_init) { fx = flow_init[(img * 2 + 0) * N + m]; fy = flow_init[(img * 2 + 1) * N + m]; }
+  const float cx = x0 + fx, cy = y0 + fy;
+  coords1[i * 2 + 0] = cx;
+  coords1[i * 2 + 1] = cy;
+  const float flx = cx - x0, fly = cy - y0;
+  reinterpret_cast<float4*>(flow4)[i] = make_float4(flx, fly, 0.f, 0.f);
+  xflow[i * ldx + 0] = flx;
+  xflow[i * ldx + 1] = fly;
+}
+void launch_init_coords(const float* flow_init, int B, int H8, int W8, float* coords1, float* flow4, float* xflow,
+                        int ldx, hipStream_t st) {
+  const long n = (long)B * H8 * W8;
+  hipLaunchKernelGGL(init_coords_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, flow_init, B, H8, W8,
+                     coords1, flow4, xflow, ldx);
+  ATDN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ convex upsampling
+// One wave per coarse pixel, lane = (i, j) of its 8x8 output patch; mask row is 9 x 64 contiguous floats.
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ mask, const float* __restrict__ flow4,
+                                                       int B, int H8, int W8, float* __restrict__ flow_low,
+                                                       float* __restrict__ flow_up) {
+  const long N = (long)H8 * W8;
+  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= B * N) return;
+  const int lane = threadIdx.x & 63;
+  const long img = p / N;
+  const int m = (int)(p - img * N);
+  const int h = m / W8, w = m - h * W8;
+  const float* mk = mask + p * 576 + lane;
+  float e[9];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { e[k] = mk[k * 64]; mx = fmaxf(mx, e[k]); }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { e[k] = expf(e[k] - mx); s += e[k]; }
+  float ux = 0.f, uy = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = h + k / 3 - 1, xx = w + k % 3 - 1;
+    float fx = 0.f, fy = 0.f;
+    if ((unsigned)yy < (unsigned)H8 && (unsigned)xx < (unsigned)W8) {
+      const float4 f = reinterpret_cast<const float4*>(flow4)[img * N + (long)yy * W8 + xx];
+      fx = 8.f * f.x; fy = 8.f * f.y;
+    }
+    const float wk = e[k] / s;
+    ux += wk * fx;
+    uy += wk * fy;
+  }
+  const int i = lane >> 3, j = lane & 7;
+  const long Hf = 8L * H8, Wf = 8L * W8;
+  const long o = (img * 2) * Hf * Wf + (long)(8 * h + i) * Wf + 8 * w + j;
+  flow_up[o] = ux;
+  flow_up[o + Hf * Wf] = uy;
+  if (lane == 0) {
+    const float4 f = reinterpret_cast<const float4*>(flow4)[p];
+    flow_low[(img * 2 + 0) * N + m] = f.x;
+    flow_low[(img * 2 + 1) * N + m] = f.y;
+  }
+}
+void launch_upsample(const float* mask, const float* flow4, int B, int H8, int W8, float* flow_low, float* flow_up,
+                     hipStream_t st) {
+  const long n = (long)B * H8 * W8;
+  hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)cdivl(n, 4)), dim3(256), 0, st, mask, flow4, B, H8, W8, flow_low,
+                     flow_up);
+  ATDN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ CLVO head
+__global__ void prep_flow_kernel(const float* __restrict__ flow, int B, long HW, float sx, float sy, const float* dw_w,
+                                 const float* dw_b, float4* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  const long img = i / HW, p = i - img * HW;
+  const float* s = flow + img * 2 * HW + p;
+  float4 v;
+  v.x = (s[0] / sx) * dw_w[0] + dw_b[0];
+  v.y = (s[HW] / sy) * dw_w[1] + dw_b[1];
+  v.z = 0.f; v.w = 0.f;
+  out[i] = v;
+}
+void launch_prep_flow(const float* flow, int B, int H, int W, const float* dw_w, const float* dw_b, float* out4,
+                      hipStream_t st) {
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(prep_flow_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, flow, B, (long)H * W,
+                     58.1837f, 17.7647f, dw_w, dw_b, reinterpret_cast<float4*>(out4));
+  ATDN_HIP(hipGetLastError());
+}
+
+// one wave per output feature n, all batch rows; K multiples of 4, rows 16-byte aligned
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ W0, const float* __restrict__ x0, int K0,
+                                                     int ldx0, const float* __restrict__ W1,
+                                                     const float* __restrict__ x1, int K1, int ldx1,
+                                                     const float* __restrict__ b0, const float* __restrict__ b1,
+                                                     int act, float* __restrict__ y, int ldy, int N, int B) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63;
+  for (int b = 0; b < B; ++b) {
+    float acc = 0.f;
+    const float4* w = reinterpret_cast<const float4*>(W0 + (long)n * K0);
+    const float4* x = reinterpret_cast<const float4*>(x0 + (long)b * ldx0);
+    for (int k = lane; k < K0 / 4; k += 64) {
+      const float4 a = w[k], v = x[k];
+      acc += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+    }
+    if (W1) {
+      const float4* w1 = reinterpret_cast<const float4*>(W1 + (long)n * K1);
+      const float4* x1v = reinterpret_cast<const float4*>(x1 + (long)b * ldx1);
+      for (int k = lane; k < K1 / 4; k += 64) {
+        const float4 a = w1[k], v = x1v[k];
+        acc += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + (b0 ? b0[n] : 0.f) + (b1 ? b1[n] : 0.f);
+      if (act == 1) v = mishf_(v);
+      y[(long)b * ldy + n] = v;
+    }
+  }
+}
+void launch_linear(const float* W0, const float* x0, int K0, int ldx0, const float* W1, const float* x1, int K1,
+                   int ldx1, const float* b0, const float* b1, int act, float* y, int ldy, int N, int B,
+                   hipStream_t st) {
+  ATDN_CHECK(K0 % 4 == 0 && K1 % 4 == 0 && ldx0 % 4 == 0 && ldx1 % 4 == 0, "linear: K and ld must be multiples of 4");
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, W0, x0, K0, ldx0, W1, x1, K1, ldx1, b0, b1, act,
+                     y, ldy, N, B);
+  ATDN_HIP(hipGetLastError());
+}
+
+__global__ void lstm_cell_kernel(const float* __restrict__ gates, float* __restrict__ c, float* __restrict__ h, int B,
+                                 int Hd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Hd) return;
+  const int b = i / Hd, j = i - b * Hd;
+  const float* g = gates + (long)b * 4 * Hd;
+  const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[Hd + j]), gg = tanhf(g[2 * Hd + j]), og = sigmoidf_(g[3 * Hd + j]);
+  const float cn = fg * c[i] + ig * gg;
+  c[i] = cn;
+  h[i] = og * tanhf(cn);
+}
+void launch_lstm_cell(const float* gates, float* c, float* h, int B, int Hd, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, gates, c, h, B, Hd);
+  ATDN_HIP(hipGetLastError());
+}
+
+// block = one batch row; waves 0-1 run the rotation head, waves 2-3 the translation head
+__global__ __launch_bounds__(256) void mlp_heads_kernel(const float* __restrict__ h2, MlpHead rot, MlpHead tr,
+                                                        float* __restrict__ rot_out, float* __restrict__ tr_out) {
+  __shared__ float x[512];
+  __shared__ float a1[2][128];
+  __shared__ float a2[2][64];
+  const int b = blockIdx.x, t = threadIdx.x;
+  x[t] = h2[(long)b * 512 + t];
+  x[t + 256] = h2[(long)b * 512 + 256 + t];
+  __syncthreads();
+  const int hd = t >> 7, u = t & 127;
+  const MlpHead& H = hd ? tr : rot;
+  {
+    const float* w = H.w0 + (long)u * 512;
+    float acc = 0.f;
+    for (int k = 0; k < 512; ++k) acc += w[k] * x[k];
+    a1[hd][u] = mishf_(acc + H.b0[u]);
+  }
+  __syncthreads();
+  if (u < 64) {
+    const float* w = H.w1 + (long)u * 128;
+    float acc = 0.f;
+    for (int k = 0; k < 128; ++k) acc += w[k] * a1[hd][k];
+    a2[hd][u] = mishf_(acc + H.b1[u]);
+  }
+  __syncthreads();
+  if (u < 3) {
+    const float* w = H.w2 + (long)u * 64;
+    float acc = 0.f;
+    for (int k = 0; k < 64; ++k) acc += w[k] * a2[hd][k];
+    (hd ? tr_out : rot_out)[(long)b * 3 + u] = acc;
+  }
+}
+void launch_mlp_heads(const float* h2, int B, MlpHead rot, MlpHead tr, float* rot_out, float* tr_out, hipStream_t st) {
+  hipLaunchKernelGGL(mlp_heads_kernel, dim3(B), dim3(256), 0, st, h2, rot, tr, rot_out, tr_out);
+  ATDN_HIP(hipGetLastError());
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill(float* p, long n, float v, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)std::min<long>(cdivl(n, 256), 4096)), dim3(256), 0, st, p, n, v);
+  ATDN_HIP(hipGetLastError());
+}
+
+}  // namespace atdn

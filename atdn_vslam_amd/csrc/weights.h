@@ -1,0 +1,143 @@
+// Host-side checkpoint staging and weight packing for the implicit-GEMM engine.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv_mfma.h"
+
+namespace atdn {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  long numel() const { long n = 1; for (auto d : shape) n *= d; return n; }
+};
+
+class StateDict {
+ public:
+  void put(const std::string& key, const float* data, const int64_t* shape, int rank) {
+    std::string k = key;
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);  // DataParallel checkpoints (neural_slam.py:51-52)
+    HostTensor t;
+    t.shape.assign(shape, shape + rank);
+    const long n = t.numel();
+    t.data.assign(data, data + n);
+    map_[k] = std::move(t);
+  }
+  const HostTensor& get(const std::string& key) const {
+    auto it = map_.find(key);
+    if (it == map_.end()) throw Error("missing state-dict entry: " + key);
+    return it->second;
+  }
+  bool has(const std::string& key) const { return map_.count(key) != 0; }
+  size_t size() const { return map_.size(); }
+
+ private:
+  std::map<std::string, HostTensor> map_;
+};
+
+// A packed layer inside the device weight arena (offsets in floats until the arena is uploaded).
+struct PackedConv {
+  long w_off = -1, b_off = -1;
+  int N = 0, ldw = 0, KH = 1, KW = 1, C = 0;  // C = (padded) channels per pixel the kernel will see
+  int mode = MODE_TAP;
+  const float* w = nullptr;
+  const float* b = nullptr;
+};
+
+class WeightArena {
+ public:
+  long alloc(long n) {  // 16-byte aligned
+    const long off = (long)host_.size();
+    host_.resize(off + ((n + 3) / 4) * 4, 0.f);
+    return off;
+  }
+  float* at(long off) { return host_.data() + off; }
+  void upload() {
+    ATDN_HIP(hipMalloc(&dev_, host_.size() * sizeof(float)));
+    ATDN_HIP(hipMemcpy(dev_, host_.data(), host_.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  const float* dev(long off) const { return dev_ + off; }
+  void release() { if (dev_) { (void)hipFree(dev_); dev_ = nullptr; } }
+  size_t bytes() const { return host_.size() * sizeof(float); }
+
+ private:
+  std::vector<float> host_;
+  float* dev_ = nullptr;
+};
+
+// Per-output-channel affine folded into a conv: w' = w*scale[n], b' = b*scale[n] + shift[n]
+struct ChannelAffine { std::vector<double> scale, shift; };
+
+inline ChannelAffine bn_affine(const StateDict& sd, const std::string& p, double eps = 1e-5) {
+  const auto& w = sd.get(p + ".weight"); const auto& b = sd.get(p + ".bias");
+  const auto& rm = sd.get(p + ".running_mean"); const auto& rv = sd.get(p + ".running_var");
+  ChannelAffine a;
+  const size_t n = w.data.size();
+  a.scale.resize(n); a.shift.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    a.scale[i] = (double)w.data[i] / std::sqrt((double)rv.data[i] + eps);
+    a.shift[i] = (double)b.data[i] - (double)rm.data[i] * a.scale[i];
+  }
+  return a;
+}
+
+// Pack torch-layout conv weights [Cout][Cin][KH][KW] (several tensors stacked along Cout) into K-contiguous rows.
+//   TAP: row = [ky][kx][Cpad]           (Cpad = Cin rounded up to 32)
+//   ROW: row = [ky][roundup(KW*Cpix,32)] with float index kx*Cpix + c  (Cpix = power of two >= Cin)
+inline PackedConv pack_conv(WeightArena& A, const StateDict& sd, const std::vector<std::string>& names, int mode,
+                            int Cpix, const ChannelAffine* fold = nullptr, bool has_bias = true) {
+  PackedConv L;
+  const HostTensor& w0 = sd.get(names[0] + ".weight");
+  ATDN_CHECK(w0.shape.size() == 4, "conv weight must be 4-d");
+  const int Cin = (int)w0.shape[1], KH = (int)w0.shape[2], KW = (int)w0.shape[3];
+  L.mode = mode; L.KH = KH; L.KW = KW;
+  L.C = (mode == MODE_TAP) ? round_up(Cin, 32) : Cpix;
+  ATDN_CHECK(L.C >= Cin, "channel padding smaller than Cin");
+  L.ldw = packed_k(mode, KH, KW, L.C);
+  int N = 0;
+  for (auto& nm : names) N += (int)sd.get(nm + ".weight").shape[0];
+  L.N = N;
+  L.w_off = A.alloc((long)N * L.ldw);
+  L.b_off = A.alloc(N);
+  int n0 = 0;
+  for (auto& nm : names) {
+    const HostTensor& w = sd.get(nm + ".weight");
+    ATDN_CHECK((int)w.shape[1] == Cin && (int)w.shape[2] == KH && (int)w.shape[3] == KW, "stacked convs must agree");
+    const int Co = (int)w.shape[0];
+    const float* bias = (has_bias && sd.has(nm + ".bias")) ? sd.get(nm + ".bias").data.data() : nullptr;
+    for (int n = 0; n < Co; ++n) {
+      const double sc = fold ? fold->scale[n0 + n] : 1.0;
+      float* row = A.at(L.w_off + (long)(n0 + n) * L.ldw);
+      for (int c = 0; c < Cin; ++c)
+        for (int ky = 0; ky < KH; ++ky)
+          for (int kx = 0; kx < KW; ++kx) {
+            const double v = (double)w.data[(((long)n * Cin + c) * KH + ky) * KW + kx] * sc;
+            const long k = (mode == MODE_TAP) ? ((long)(ky * KW + kx) * L.C + c)
+                                              : ((long)ky * round_up(KW * L.C, 32) + kx * L.C + c);
+            row[k] = (float)v;
+          }
+      double bv = bias ? (double)bias[n] : 0.0;
+      if (fold) bv = bv * sc + fold->shift[n0 + n];
+      A.at(L.b_off)[n0 + n] = (float)bv;
+    }
+    n0 += Co;
+  }
+  return L;
+}
+
+inline long pack_vector(WeightArena& A, const std::vector<float>& v) {
+  const long off = A.alloc((long)v.size());
+  std::memcpy(A.at(off), v.data(), v.size() * sizeof(float));
+  return off;
+}
+
+inline void resolve(const WeightArena& A, PackedConv& L) {
+  L.w = A.dev(L.w_off);
+  L.b = A.dev(L.b_off);
+}
+
+}  // namespace atdn

@@ -1,0 +1,254 @@
+"""Drop-in replacements for the two reference modules on the odometry path.
+
+* `RAFTGMA`  — same constructor / forward / state_dict contract as
+  whl:GMA/core/network.py:26-129 (used at neural_slam.py:51-53,202).
+* `ATDNVO`   — same contract as atdn_vslam/odometry/network.py:11-162
+  (used at evaluate_odometry.py:124,66 and neural_slam.py:57-59,203).
+
+They own parameters with the reference's exact state-dict keys (so the same
+checkpoints load) and run every forward through libatdn_hip's C ABI. PyTorch
+only supplies device memory and the stream.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from .weights_spec import F32, clvo_state_spec, gma_state_spec
+
+_BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked", "rel_ind")
+
+
+class _Node(nn.Module):
+    """Container whose only job is to reproduce the reference's parameter names."""
+
+
+def _build_tree(root, spec):
+    for key, (shape, kind) in spec.items():
+        parts = key.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _Node())
+            mod = mod._modules[p]
+        leaf = parts[-1]
+        if kind == F32:
+            t = torch.zeros(shape, dtype=torch.float32)
+        else:
+            t = torch.zeros(shape, dtype=torch.int64)
+        if leaf in _BUFFER_LEAVES:
+            mod.register_buffer(leaf, t)
+        else:
+            mod.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s: the MI355X path needs tensors on a HIP device (got %s); there is no CPU fallback"
+                           % (what, t.device))
+
+
+class _NativeModule(nn.Module):
+    """Shared plumbing: parameter fingerprinting and per-shape native handles."""
+
+    def __init__(self):
+        super().__init__()
+        self._handles = {}
+
+    def _fingerprint(self):
+        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+
+    def _drop_handles(self):
+        for ent in self._handles.values():  # (handle, fingerprint, destroy_fn, max_batch)
+            ent[2](ent[0])
+        self._handles = {}
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # DataParallel checkpoints carry a "module." prefix (neural_slam.py:51-52)
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self._drop_handles()
+        return out
+
+    def __del__(self):
+        try:
+            self._drop_handles()
+        except Exception:
+            pass
+
+
+class RAFTGMA(_NativeModule):
+    """GMA optical flow; `args` is the reference's GMA_Parameters-like object (only
+    `num_heads`, `position_only`, `position_and_content` are consulted)."""
+
+    def __init__(self, args=None, max_batch=1):
+        super().__init__()
+        self.args = args
+        self.hidden_dim = 128
+        self.context_dim = 128
+        if args is not None:
+            args.corr_levels = 4   # network.py:33-34 writes these back into args
+            args.corr_radius = 4
+            if getattr(args, "num_heads", 1) != 1 or getattr(args, "position_only", False) or \
+                    getattr(args, "position_and_content", False):
+                raise NotImplementedError("only the configuration ATDN vSLAM ships (1 head, content-only attention)")
+        self.max_batch = max_batch
+        _build_tree(self, gma_state_spec())
+        n = 160
+        d = torch.arange(n).view(1, -1) - torch.arange(n).view(-1, 1)
+        self.att.pos_emb.rel_ind.copy_(d + n - 1)
+
+    def _handle(self, H, W, B):
+        key = (H, W)
+        fp = self._fingerprint()
+        ent = self._handles.get(key)
+        if ent is not None and (ent[1] != fp or ent[3] < B):
+            ent[2](ent[0])
+            ent = None
+        if ent is None:
+            L = _lib.lib()
+            h = C.c_void_p()
+            mb = max(B, self.max_batch)
+            _lib.check(L.atdn_gma_create(C.byref(h), H, W, mb))
+            _lib.load_state(L.atdn_gma_load, h, self.state_dict())
+            _lib.check(L.atdn_gma_finalize(h))
+            ent = (h, fp, L.atdn_gma_destroy, mb)
+            self._handles[key] = ent
+        return ent[0]
+
+    @torch.no_grad()
+    def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
+        if not test_mode:
+            raise NotImplementedError("only the inference contract (test_mode=True) is built; the per-iteration "
+                                      "training outputs of network.py:129 are out of scope")
+        _require_gpu(image1, "RAFTGMA.forward")
+        if image1.shape != image2.shape or image1.dim() != 4 or image1.shape[1] != 3:
+            raise RuntimeError("expected two [B,3,H,W] frames, got %s and %s" % (tuple(image1.shape), tuple(image2.shape)))
+        B, _, H, W = image1.shape
+        with torch.cuda.device(image1.device):
+            im1 = image1.float().contiguous()
+            im2 = image2.float().contiguous()
+            fi = None
+            if flow_init is not None:
+                fi = flow_init.to(image1.device).float().contiguous()
+                if tuple(fi.shape) != (B, 2, H // 8, W // 8):
+                    raise RuntimeError("flow_init must be [B,2,H/8,W/8]")
+            flow_low = torch.empty((B, 2, H // 8, W // 8), dtype=torch.float32, device=image1.device)
+            flow_up = torch.empty((B, 2, H, W), dtype=torch.float32, device=image1.device)
+            h = self._handle(H, W, B)
+            _lib.check(_lib.lib().atdn_gma_forward(h, _ptr(im1), _ptr(im2), B, int(iters), _ptr(fi), _ptr(flow_low),
+                                                   _ptr(flow_up), _stream()))
+        return flow_low, flow_up
+
+    def debug_read(self, name, shape, H, W):
+        """Copy an internal activation of the (H, W) handle to a CPU tensor (parity tests)."""
+        out = torch.empty(shape, dtype=torch.float32)
+        h = self._handles[(H, W)][0]
+        n = _lib.lib().atdn_gma_debug_read(h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), _stream())
+        if n < 0:
+            _lib.check(1)
+        return out
+
+    def profile(self, H, W, B, iters=12, reps=1):
+        """Per-stage device milliseconds of one eager forward (HIP events on the current stream)."""
+        ms = (C.c_float * len(_lib.GMA_STAGES))()
+        h = self._handle(H, W, B)
+        _lib.check(_lib.lib().atdn_gma_profile(h, B, int(iters), int(reps), ms, _stream()))
+        return {k: float(v) / reps for k, v in zip(_lib.GMA_STAGES, ms)}
+
+    def freeze_bn(self):  # network.py:45-48; inference-only module: nothing to freeze
+        return None
+
+
+class ATDNVO(_NativeModule):
+    """CLVO pose head. Stateful like the reference: two LSTM cell states persist across calls."""
+
+    def __init__(self, batch_size=1, in_channels=2, compressor=True, use_dropout=False, use_layernorm=False):
+        super().__init__()
+        if in_channels != 2 or not compressor or use_layernorm:
+            raise NotImplementedError("only the shipped configuration ATDNVO() (2 channels, compressor, no layernorm)")
+        self.batch_size = batch_size
+        self.in_channels = in_channels
+        self.device = "cpu"
+        self.lstm_out_size = 512
+        self.suffix = "_c" + ("d" if use_dropout else "")  # network.py:52-60 (dropout is Identity in eval)
+        _build_tree(self, clvo_state_spec())
+        self._state = torch.zeros(4, batch_size, 512)
+
+    # the reference exposes the four state tensors as attributes
+    lstm1_h = property(lambda self: self._state[0])
+    lstm1_c = property(lambda self: self._state[1])
+    lstm2_h = property(lambda self: self._state[2])
+    lstm2_c = property(lambda self: self._state[3])
+
+    def reset_lstm(self):
+        self._state = torch.zeros(4, self.batch_size, 512, device=self.device)
+
+    def to(self, device):
+        super().to(device)
+        self.device = device
+        self.reset_lstm()  # network.py:156-162: moving the module also resets the state
+        return self
+
+    def _handle(self, H, W, B):
+        key = (H, W)
+        fp = self._fingerprint()
+        ent = self._handles.get(key)
+        if ent is not None and (ent[1] != fp or ent[3] < B):
+            ent[2](ent[0])
+            ent = None
+        if ent is None:
+            L = _lib.lib()
+            h = C.c_void_p()
+            _lib.check(L.atdn_clvo_create(C.byref(h), H, W, B))
+            _lib.load_state(L.atdn_clvo_load, h, self.state_dict())
+            _lib.check(L.atdn_clvo_finalize(h))
+            ent = (h, fp, L.atdn_clvo_destroy, B)
+            self._handles[key] = ent
+        return ent[0]
+
+    @torch.no_grad()
+    def encode(self, flows):
+        """Stateless part: flows [B,2,H,W] -> 512-d features (shardable across frame pairs)."""
+        _require_gpu(flows, "ATDNVO.encode")
+        if flows.dim() != 4 or flows.shape[1] != 2:
+            raise RuntimeError("expected flows [B,2,H,W], got %s" % (tuple(flows.shape),))
+        B, _, H, W = flows.shape
+        with torch.cuda.device(flows.device):
+            fl = flows.float().contiguous()
+            feat = torch.empty((B, 512), dtype=torch.float32, device=flows.device)
+            _lib.check(_lib.lib().atdn_clvo_encode(self._handle(H, W, B), _ptr(fl), B, _ptr(feat), _stream()))
+        return feat
+
+    @torch.no_grad()
+    def scan(self, feats, state=None, hw=(376, 1232)):
+        """Ordered recurrence over feats [T,Bs,512]; returns (rot [T,Bs,3], tr [T,Bs,3], state [4,Bs,512])."""
+        _require_gpu(feats, "ATDNVO.scan")
+        T, Bs, _ = feats.shape
+        with torch.cuda.device(feats.device):
+            f = feats.float().contiguous()
+            st = torch.zeros(4, Bs, 512, device=feats.device) if state is None else state.float().contiguous().clone()
+            rot = torch.empty((T, Bs, 3), dtype=torch.float32, device=feats.device)
+            tr = torch.empty((T, Bs, 3), dtype=torch.float32, device=feats.device)
+            h = self._handle(hw[0], hw[1], Bs)
+            _lib.check(_lib.lib().atdn_clvo_step(h, _ptr(f), T, Bs, _ptr(st), _ptr(rot), _ptr(tr), _stream()))
+        return rot, tr, st
+
+    @torch.no_grad()
+    def forward(self, flows):
+        if flows.shape[0] != self.batch_size:
+            raise RuntimeError("ATDNVO was built for batch_size=%d, got %d flows" % (self.batch_size, flows.shape[0]))
+        feat = self.encode(flows)
+        if self._state.device != flows.device:
+            self._state = self._state.to(flows.device)
+        rot, tr, self._state = self.scan(feat[None], self._state, hw=tuple(flows.shape[2:]))
+        return rot[0], tr[0]

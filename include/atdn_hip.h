@@ -1,0 +1,122 @@
+/* libatdn_hip — C ABI of the MI355X-native ATDN vSLAM visual-odometry inference path.
+ *
+ * The reference has no FFI layer: its boundary is two Python nn.Module call contracts. Each entry point
+ * below names the reference interface it stands in for. All tensor arguments are raw DEVICE pointers to
+ * dense fp32 buffers (tensor.data_ptr()) unless marked host; `stream` is a hipStream_t
+ * (torch.cuda.current_stream().cuda_stream), 0/NULL = the default stream.
+ *
+ * Every function returns 0 on success and non-zero on error; atdn_last_error() then holds the message
+ * (thread-local). Handles are not re-entrant: one handle per (device, thread), like the reference modules.
+ */
+#ifndef ATDN_HIP_H
+#define ATDN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct atdn_gma atdn_gma;   /* RAFTGMA flow network handle */
+typedef struct atdn_clvo atdn_clvo; /* ATDNVO pose head handle */
+
+int atdn_version(void);
+const char* atdn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * GMA optical flow  —  replaces torch.nn.DataParallel(RAFTGMA(GMA_Parameters()))
+ *   construction + checkpoint: atdn_vslam/slam_framework/neural_slam.py:51-53
+ *   forward:                   whl:GMA/core/network.py:72-129 (called at neural_slam.py:202,395)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* H, W: frame size after the caller's resize/pad (multiples of 8; 376x1232 in NeuralSLAM,
+ * neural_slam.py:54,198-199). max_batch: largest number of frame pairs per forward. */
+int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch);
+
+/* One state-dict entry (load_state_dict, neural_slam.py:52). `key` as in the checkpoint, with or without the
+ * DataParallel "module." prefix; `data` is a HOST fp32 buffer of the given shape. Non-float buffers
+ * (num_batches_tracked, rel_ind) need not be passed. */
+int atdn_gma_load(atdn_gma* h, const char* key, const float* data, const int64_t* shape, int rank);
+
+/* Packs weights for the MFMA kernels (BatchNorm folded), uploads them, allocates the HBM workspace. */
+int atdn_gma_finalize(atdn_gma* h);
+
+/* flow_low, flow_up = flow_net(image1, image2, iters=iters, flow_init=flow_init, test_mode=True)
+ *   im1, im2   [B,3,H,W]   RGB 0..255
+ *   flow_init  [B,2,H/8,W/8] or NULL          (network.py:103-104)
+ *   flow_low   [B,2,H/8,W/8], flow_up [B,2,H,W]; channel 0 = x flow, 1 = y flow */
+int atdn_gma_forward(atdn_gma* h, const float* im1, const float* im2, int B, int iters, const float* flow_init,
+                     float* flow_low, float* flow_up, void* stream);
+
+/* Copies an internal activation to a HOST buffer for parity tests ("fmap", "pyr0".."pyr3", "attn", "net",
+ * "x", "corrfeat", "mask", "coords1", "flow4", "qk", "img4"). Returns the number of floats copied, -1 on error. */
+long atdn_gma_debug_read(atdn_gma* h, const char* name, float* host, long capacity, void* stream);
+
+/* Per-stage device time (ms, summed over `reps` eager forwards of batch B), measured with HIP events on
+ * `stream`. ms_out has ATDN_GMA_STAGES entries: fnet, corr, pool, cnet, attention, lookup, motion_encoder,
+ * aggregate, gru, flow_head, mask. */
+#define ATDN_GMA_STAGES 11
+int atdn_gma_profile(atdn_gma* h, int B, int iters, int reps, float* ms_out, void* stream);
+
+size_t atdn_gma_workspace_bytes(atdn_gma* h);
+void atdn_gma_destroy(atdn_gma* h);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CLVO pose head  —  replaces ATDNVO()  (atdn_vslam/odometry/network.py:20-162)
+ *   construction: evaluate_odometry.py:124, neural_slam.py:57-59 ; forward: network.py:122-146
+ * The module's hidden LSTM attributes become an explicit state tensor so the stateless CNN encoder can be
+ * sharded over frame pairs while the recurrence runs as one ordered scan.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* H, W: flow size (must reduce to a 16x4x13 map: H in [353,448], W in [1217,1312]); else an error like the
+ * reference's Linear(832) shape error. */
+int atdn_clvo_create(atdn_clvo** out, int H, int W, int max_batch);
+int atdn_clvo_load(atdn_clvo* h, const char* key, const float* data, const int64_t* shape, int rank);
+int atdn_clvo_finalize(atdn_clvo* h);
+
+/* features = encoder_CNN(normalize_flow(flows))   (network.py:131-134): flow [B,2,H,W] -> feat [B,512] */
+int atdn_clvo_encode(atdn_clvo* h, const float* flow, int B, float* feat, void* stream);
+
+/* T ordered recurrent steps (network.py:137-146) for Bs independent sequences:
+ *   feat [T,Bs,512]; state [4,Bs,512] = lstm1_h, lstm1_c, lstm2_h, lstm2_c (in/out; zeros == reset_lstm());
+ *   rot, tr [T,Bs,3] (Euler yxz radians, translation). */
+int atdn_clvo_step(atdn_clvo* h, const float* feat, int T, int Bs, float* state, float* rot, float* tr, void* stream);
+void atdn_clvo_destroy(atdn_clvo* h);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Pose algebra (host, no GPU)  —  replaces atdn_vslam/utils/transforms.py
+ * ------------------------------------------------------------------------------------------------- */
+
+/* transform(rot, tr) (transforms.py:97-119, euler2matrix "yxz" :79-81): HOST rot[3], tr[3] -> row-major 4x4 */
+int atdn_pose_transform_f32(const float* rot, const float* tr, float* mat16);
+/* rel2abs (transforms.py:147-170): HOST rot[T,3], tr[T,3] -> poses [T+1,4,4] float64, identity first */
+int atdn_pose_rel2abs(const float* rot, const float* tr, int T, double* poses);
+/* NeuralSLAM's running pose (neural_slam.py:204-207): pose(4x4 fp32, in/out) = pose @ transform(rot, tr) */
+int atdn_pose_accumulate_f32(float* pose16, const float* rot, const float* tr);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Individual kernels, exported for unit parity tests and roofline micro-benchmarks
+ * ------------------------------------------------------------------------------------------------- */
+
+/* CorrBlock.__call__ (whl:GMA/core/corr.py:32-53): pyramid level l is [B*H8*W8][H_l*W_l] with
+ * H_l = H8 >> l, W_l = W8 >> l; coords [B*H8*W8][2] (x,y); out [B*H8*W8][ldo], channel l*81 + i*9 + j. */
+int atdn_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, int B, int H8,
+                     int W8, const float* coords, float* out, int ldo, void* stream);
+
+/* CorrBlock.__init__ (corr.py:16-30,55-63): fmap1, fmap2 channels-last [B][H8*W8][C] (C % 32 == 0) ->
+ * pyr0..pyr3 as above. */
+int atdn_corr_pyramid(const float* fmap1, const float* fmap2, int B, int H8, int W8, int C, float* pyr0, float* pyr1,
+                      float* pyr2, float* pyr3, void* stream);
+
+/* Generic NHWC convolution through the implicit-GEMM MFMA engine: src [nimg][H][W][Cin] (Cin % 32 == 0 or
+ * Cin in {4,16}), HOST weight in torch layout [Cout][Cin][KH][KW] (+ HOST bias or NULL), dst
+ * [nimg][Ho][Wo][Cout]; relu != 0 applies ReLU. */
+int atdn_conv2d_nhwc(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
+                     const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, int relu,
+                     float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATDN_HIP_H */

@@ -1,0 +1,338 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on identical seeded
+inputs, against the committed golden fixtures (outputs of the imported reference), and through
+size-independent properties at full KITTI size.  Stated tolerances (fp32 MFMA path):
+flow_low <= 2e-4 px... measured per stage below; end-to-end flow_up <= 1e-3 px relative to |flow| scale,
+pose <= 1e-5."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from atdn_vslam_amd import _lib
+from atdn_vslam_amd import synthetic as syn
+from atdn_vslam_amd.modules import ATDNVO, RAFTGMA
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _maxerr(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+# ----------------------------------------------------------------------------- implicit-GEMM engine
+CONV_CASES = [
+    # (Cin, Cout, KH, KW, stride, padH, padW, H, W, nimg, relu)
+    (64, 64, 3, 3, 1, 1, 1, 23, 37, 2, 1),      # tap mode, ragged tiles
+    (64, 96, 3, 3, 2, 1, 1, 40, 52, 1, 0),      # stride 2, 96-wide tile path
+    (96, 128, 1, 1, 2, 0, 0, 31, 45, 2, 0),     # 1x1 downsample
+    (128, 126, 3, 3, 1, 1, 1, 20, 64, 1, 1),    # odd Cout
+    (256, 2, 3, 3, 1, 1, 1, 20, 64, 2, 0),      # flow head: N = 2
+    (128, 256, 1, 5, 1, 0, 2, 20, 64, 1, 0),    # separable GRU conv, horizontal
+    (128, 256, 5, 1, 1, 2, 0, 47, 19, 1, 0),    # vertical
+    (256, 576, 1, 1, 1, 0, 0, 20, 64, 1, 0),    # mask head
+    (4, 64, 7, 7, 2, 3, 3, 53, 77, 2, 1),       # row mode stem
+    (4, 128, 7, 7, 1, 3, 3, 20, 64, 1, 1),      # row mode, stride 1 (convf1)
+    (16, 16, 3, 3, 1, 1, 1, 47, 61, 2, 0),      # CLVO thin convs
+    (16, 16, 3, 3, 2, 1, 1, 47, 61, 1, 0),
+    (16, 16, 3, 3, 3, 0, 0, 12, 39, 3, 0),
+    (16, 16, 1, 1, 2, 0, 0, 47, 61, 1, 0),
+    (64, 64, 3, 3, 1, 1, 1, 188, 616, 2, 1),    # full-size fnet layer1 conv (many tiles, 128x64 tiles)
+    (128, 128, 3, 3, 1, 1, 1, 47, 154, 5, 0),   # 128x128 tile path needs >= 512 tiles: 5 images
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_engine_matches_torch(case):
+    cin, cout, kh, kw, stride, ph, pw, H, W, nimg, relu = case
+    r = np.random.RandomState(hash(case) & 0xFFFF)
+    x = torch.from_numpy(r.uniform(-1, 1, (nimg, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((r.uniform(-1, 1, (cout, cin, kh, kw)) / np.sqrt(cin * kh * kw)).astype(np.float32))
+    b = torch.from_numpy(r.uniform(-0.5, 0.5, (cout,)).astype(np.float32))
+    ref = F.conv2d(x, w, b, stride=stride, padding=(ph, pw))
+    if relu:
+        ref = F.relu(ref)
+    xd = _nhwc(x).to(DEV)
+    ho, wo = ref.shape[2], ref.shape[3]
+    out = torch.full((nimg, ho, wo, cout), float("nan"), dtype=torch.float32, device=DEV)
+    wc, bc = w.contiguous(), b.contiguous()
+    _lib.check(_lib.lib().atdn_conv2d_nhwc(_vp(xd), nimg, H, W, cin, _vp(wc), _vp(bc), cout, kh, kw, stride, ph, pw,
+                                           relu, _vp(out), _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert _maxerr(got, ref) < 2e-5, _maxerr(got, ref)
+
+
+def test_conv_engine_rejects_bad_shapes():
+    x = torch.zeros(1, 8, 8, 24, device=DEV)
+    w = torch.zeros(8, 24, 3, 3)
+    out = torch.zeros(1, 8, 8, 8, device=DEV)
+    rc = _lib.lib().atdn_conv2d_nhwc(_vp(x), 1, 8, 8, 24, _vp(w), None, 8, 3, 3, 1, 1, 1, 0, _vp(out), _stream())
+    assert rc != 0 and b"multiple of 32" in _lib.lib().atdn_last_error()
+
+
+# ----------------------------------------------------------------------------- correlation pyramid + lookup
+def _pyramid_on_gpu(f1, f2):
+    """f1, f2 [B,C,H8,W8] CPU -> list of 4 device tensors [B*N, H_l*W_l]."""
+    B, Cc, H8, W8 = f1.shape
+    N = H8 * W8
+    a = f1.permute(0, 2, 3, 1).reshape(B, N, Cc).contiguous().to(DEV)
+    b = f2.permute(0, 2, 3, 1).reshape(B, N, Cc).contiguous().to(DEV)
+    pyr = [torch.full((B * N, (H8 >> l) * (W8 >> l)), float("nan"), device=DEV) for l in range(4)]
+    _lib.check(_lib.lib().atdn_corr_pyramid(_vp(a), _vp(b), B, H8, W8, Cc, *[_vp(p) for p in pyr], _stream()))
+    return pyr
+
+
+def _lookup_on_gpu(pyr, coords, B, H8, W8, ldo=352):
+    """coords [B,2,H8,W8] CPU -> [B,324,H8,W8] CPU."""
+    N = H8 * W8
+    c = coords.permute(0, 2, 3, 1).reshape(B * N, 2).contiguous().to(DEV)
+    out = torch.full((B * N, ldo), float("nan"), device=DEV)
+    _lib.check(_lib.lib().atdn_corr_lookup(*[_vp(p) for p in pyr], B, H8, W8, _vp(c), _vp(out), ldo, _stream()))
+    torch.cuda.synchronize()
+    return out[:, :324].cpu().reshape(B, H8, W8, 324).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 20, 64), (1, 256, 47, 154)])
+def test_corr_pyramid_and_lookup_match_oracle(shape):
+    from oracle import gma_ref
+    B, Cc, H8, W8 = shape
+    r = np.random.RandomState(11)
+    f1 = torch.from_numpy(r.normal(0, 1, shape).astype(np.float32))
+    f2 = torch.from_numpy(r.normal(0, 1, shape).astype(np.float32))
+    ref_pyr = gma_ref.corr_pyramid(f1, f2)
+    pyr = _pyramid_on_gpu(f1, f2)
+    torch.cuda.synchronize()
+    for l in range(4):
+        ref = ref_pyr[l].reshape(B * H8 * W8, -1)
+        assert pyr[l].shape == ref.shape
+        assert _maxerr(pyr[l].cpu(), ref) < 5e-5 * (Cc / 64) ** 0.5
+    coords = gma_ref.coords_grid(B, H8, W8) + torch.from_numpy(r.uniform(-9, 9, (B, 2, H8, W8)).astype(np.float32))
+    coords[0, :, 0, 0] = torch.tensor([-7.5, 3.25])          # partly outside
+    coords[0, :, 0, 1] = torch.tensor([5000.0, -5000.0])     # far outside: zeros
+    coords[0, :, 0, 2] = torch.tensor([float(W8 - 1), float(H8 - 1)])
+    coords[0, :, 0, 3] = torch.tensor([0.0, 0.0])            # exact integers (iteration 0 situation)
+    ref = gma_ref.corr_lookup(ref_pyr, coords)
+    got = _lookup_on_gpu(pyr, coords, B, H8, W8)
+    assert torch.isfinite(got).all()
+    assert torch.all(got[0, :, 0, 1] == 0)
+    scale = float(ref.abs().max())
+    assert _maxerr(got, ref) < 2e-5 * max(1.0, scale)
+
+
+def test_lookup_matches_reference_golden(golden_dir):
+    """The reference's own CorrBlock output on its own fmaps (C1), reproduced from our pyramid of the same fmaps."""
+    from oracle import gma_ref
+    g = np.load(os.path.join(golden_dir, "gma_c1.npz"))
+    gsd = syn.to_torch(syn.make_gma_state(seed=1))
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=int(g["seed_frames"])))
+    taps = {}
+    gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=1, taps=taps)
+    pyr = _pyramid_on_gpu(taps["fmap1"], taps["fmap2"])
+    got = _lookup_on_gpu(pyr, torch.from_numpy(g["probe"])[None], 1, 20, 64)
+    assert _maxerr(got[0], torch.from_numpy(g["lookup"])) < 3e-5
+
+
+# ----------------------------------------------------------------------------- GMA forward
+@pytest.fixture(scope="module")
+def gsd():
+    return syn.to_torch(syn.make_gma_state(seed=1))
+
+
+@pytest.fixture(scope="module")
+def flow_net(gsd):
+    m = RAFTGMA(max_batch=2)
+    m.load_state_dict({"module." + k: v for k, v in gsd.items()})  # DataParallel-style checkpoint
+    return m.to(DEV).eval()
+
+
+def _nchw_from(buf, B, H8, W8, Cc):
+    return buf.reshape(B, H8, W8, Cc).permute(0, 3, 1, 2)
+
+
+def test_gma_c1_stages_match_oracle_and_golden(golden_dir, gsd, flow_net):
+    from oracle import gma_ref
+    g = np.load(os.path.join(golden_dir, "gma_c1.npz"))
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=int(g["seed_frames"])))
+    taps = {}
+    ref_low1, _ = gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=1, taps=taps)
+    low1, up1 = flow_net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=1, test_mode=True)
+    torch.cuda.synchronize()
+    H8, W8, N = 20, 64, 1280
+    fmap = flow_net.debug_read("fmap", (2, N, 256), 160, 512)
+    f1 = _nchw_from(fmap[0], 1, H8, W8, 256)
+    f2 = _nchw_from(fmap[1], 1, H8, W8, 256)
+    assert _maxerr(f1, taps["fmap1"]) < 5e-5 and _maxerr(f2, taps["fmap2"]) < 5e-5
+    assert _maxerr(f1[0, :, ::3, ::5], torch.from_numpy(g["fmap1"])) < 5e-5
+    for l in range(4):
+        hl, wl = H8 >> l, W8 >> l
+        p = flow_net.debug_read("pyr%d" % l, (N, hl * wl), 160, 512)
+        assert _maxerr(p, taps["pyramid"][l].reshape(N, hl * wl)) < 1e-4
+    x = flow_net.debug_read("x", (N, 384), 160, 512)
+    inp = _nchw_from(x[:, 0:128], 1, H8, W8, 128)
+    assert _maxerr(inp, taps["inp"]) < 5e-5
+    assert _maxerr(inp[0, :, ::3, ::5], torch.from_numpy(g["inp"])) < 5e-5
+    attn = flow_net.debug_read("attn", (N, 1280), 160, 512)
+    ref_attn = taps["attn"].reshape(N, N)
+    assert _maxerr(attn, ref_attn) < 1e-6 + 1e-4 * float(ref_attn.max())
+    assert _maxerr(attn.sum(1), torch.ones(N)) < 1e-5
+    assert _maxerr(attn[[0, 77, 640, 1279]], torch.from_numpy(g["attn_rows"])) < 1e-6 + 1e-4 * float(ref_attn.max())
+    # first update-block pass
+    look = _nchw_from(flow_net.debug_read("corrfeat", (N, 352), 160, 512)[:, :324], 1, H8, W8, 324)
+    assert _maxerr(look, taps["lookup0"]) < 1e-4
+    mf = _nchw_from(x[:, 128:256], 1, H8, W8, 128)
+    mfg = _nchw_from(x[:, 256:384], 1, H8, W8, 128)
+    # after the iteration the flow slots hold the UPDATED flow; compare the 126 conv channels
+    assert _maxerr(mf[:, :126], taps["mf0"][:, :126]) < 1e-4
+    assert _maxerr(mfg[:, :126], taps["mfg0"][:, :126]) < 1e-4
+    net = _nchw_from(flow_net.debug_read("net", (N, 128), 160, 512), 1, H8, W8, 128)
+    assert _maxerr(net, taps["net1"]) < 1e-4
+    assert _maxerr(net[0, :, ::3, ::5], torch.from_numpy(g["net1"])) < 1e-4
+    assert _maxerr(low1.cpu(), ref_low1) < 1e-4
+    assert _maxerr(low1.cpu()[0], torch.from_numpy(g["delta1"])) < 1e-4
+    mask = _nchw_from(flow_net.debug_read("mask", (N, 576), 160, 512), 1, H8, W8, 576)
+    assert _maxerr(mask, taps["mask"]) < 1e-4
+    assert _maxerr(mask[0, :, ::3, ::5], torch.from_numpy(g["mask1"])) < 1e-4
+    assert _maxerr(up1.cpu(), gma_ref.convex_upsample(ref_low1, taps["mask"])) < 1e-3
+
+
+def test_gma_c1_full_flow_matches_golden(golden_dir, gsd, flow_net):
+    from oracle import gma_ref
+    g = np.load(os.path.join(golden_dir, "gma_c1.npz"))
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=int(g["seed_frames"])))
+    low, up = flow_net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=int(g["iters"]), test_mode=True)
+    ref_low, ref_up = gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=int(g["iters"]))
+    low, up = low.cpu(), up.cpu()
+    # stated tolerance of the fp32 path: 2e-3 px on flows of up to 135 px after 8 recurrent iterations
+    assert _maxerr(low[0], torch.from_numpy(g["flow_low"])) < 5e-4
+    assert _maxerr(up[0], torch.from_numpy(g["flow_up"])) < 2e-3
+    assert _maxerr(low, ref_low) < 5e-4 and _maxerr(up, ref_up) < 2e-3
+
+
+def test_gma_c2_kitti_size_matches_golden_and_is_batch_invariant(golden_dir, gsd, flow_net):
+    g = np.load(os.path.join(golden_dir, "gma_c2.npz"))
+    fr = torch.from_numpy(syn.make_frames(2, 376, 1232, seed=int(g["seed_frames"]))).to(DEV)
+    low, up = flow_net(fr[0:1], fr[1:2], iters=int(g["iters"]), test_mode=True)
+    assert tuple(low.shape) == (1, 2, 47, 154) and tuple(up.shape) == (1, 2, 376, 1232)
+    lowc, upc = low.cpu(), up.cpu()
+    assert _maxerr(lowc[0], torch.from_numpy(g["flow_low"])) < 5e-4
+    assert _maxerr(upc[0, :, ::4, ::4], torch.from_numpy(g["flow_up_s4"])) < 2e-3
+    np.testing.assert_allclose(upc.double().sum(dim=(0, 2, 3)).numpy(), g["flow_up_sum"], rtol=1e-5, atol=2.0)
+    # same call again: bit-identical (no atomics anywhere on the path)
+    low2, up2 = flow_net(fr[0:1], fr[1:2], iters=int(g["iters"]), test_mode=True)
+    assert torch.equal(up, up2) and torch.equal(low, low2)
+    # batch of two pairs (second one reversed): each pair equals its single-pair result bit for bit
+    lowb, upb = flow_net(torch.cat([fr[0:1], fr[1:2]]), torch.cat([fr[1:2], fr[0:1]]), iters=int(g["iters"]),
+                         test_mode=True)
+    assert torch.equal(upb[0:1], up)
+    lowr, upr = flow_net(fr[1:2], fr[0:1], iters=int(g["iters"]), test_mode=True)
+    assert torch.equal(upb[1:2], upr)
+    # flow_init = 0 is the same as no flow_init; a non-zero one changes the result
+    low0, up0 = flow_net(fr[0:1], fr[1:2], iters=2, flow_init=torch.zeros(1, 2, 47, 154, device=DEV), test_mode=True)
+    lown, upn = flow_net(fr[0:1], fr[1:2], iters=2, test_mode=True)
+    assert torch.equal(up0, upn)
+    low1, _ = flow_net(fr[0:1], fr[1:2], iters=2, flow_init=torch.ones(1, 2, 47, 154, device=DEV), test_mode=True)
+    assert not torch.equal(low1, lown)
+
+
+def test_gma_flow_init_matches_oracle(gsd, flow_net):
+    from oracle import gma_ref
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=21))
+    r = np.random.RandomState(3)
+    fi = torch.from_numpy(r.uniform(-2, 2, (1, 2, 20, 64)).astype(np.float32))
+    ref_low, ref_up = gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=3, flow_init=fi)
+    low, up = flow_net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=3, flow_init=fi.to(DEV), test_mode=True)
+    assert _maxerr(low.cpu(), ref_low) < 3e-4 and _maxerr(up.cpu(), ref_up) < 2e-3
+
+
+def test_gma_module_contract(flow_net):
+    with pytest.raises(NotImplementedError):
+        flow_net(torch.zeros(1, 3, 160, 512, device=DEV), torch.zeros(1, 3, 160, 512, device=DEV))
+    with pytest.raises(RuntimeError):
+        flow_net(torch.zeros(1, 3, 160, 512), torch.zeros(1, 3, 160, 512), test_mode=True)  # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        flow_net(torch.zeros(1, 3, 161, 512, device=DEV), torch.zeros(1, 3, 161, 512, device=DEV), test_mode=True)
+
+
+# ----------------------------------------------------------------------------- CLVO head
+@pytest.fixture(scope="module")
+def hsd():
+    return syn.to_torch(syn.make_clvo_state(seed=1))
+
+
+def test_clvo_head_matches_golden_and_oracle(golden_dir, hsd):
+    from oracle import clvo_ref
+    g = np.load(os.path.join(golden_dir, "clvo.npz"))
+    head = ATDNVO()
+    head.load_state_dict(hsd)
+    head = head.to(DEV).eval()
+    fl = torch.from_numpy(syn.make_flow(3, 376, 1232, seed=6))
+    feat = head.encode(fl.to(DEV)).cpu()
+    assert _maxerr(feat, torch.from_numpy(g["feat"])) < 2e-5
+    assert _maxerr(feat, clvo_ref.clvo_encode(hsd, fl)) < 2e-5
+    for t in range(3):  # state carried across calls
+        rot, tr = head(fl[t:t + 1].to(DEV))
+        assert tuple(rot.shape) == (1, 3) and tuple(tr.shape) == (1, 3)
+        assert _maxerr(rot.cpu(), torch.from_numpy(g["rot%d" % t])) < 1e-5
+        assert _maxerr(tr.cpu(), torch.from_numpy(g["tr%d" % t])) < 1e-5
+    head.reset_lstm()
+    rot, tr = head(fl[1:2].to(DEV))
+    assert _maxerr(rot.cpu(), torch.from_numpy(g["rot_after_reset"])) < 1e-5
+    assert _maxerr(tr.cpu(), torch.from_numpy(g["tr_after_reset"])) < 1e-5
+    # .to() resets the state as the reference does
+    head.to(DEV)
+    assert float(head.lstm1_h.abs().max()) == 0.0
+    # batch of 4 independent sequences
+    head4 = ATDNVO(batch_size=4)
+    head4.load_state_dict(hsd)
+    head4 = head4.to(DEV)
+    fl4 = torch.from_numpy(syn.make_flow(4, 376, 1232, seed=8)).to(DEV)
+    r4, t4 = head4(fl4)
+    assert _maxerr(r4.cpu(), torch.from_numpy(g["rot_b4"])) < 1e-5
+    r4b, t4b = head4(fl4.flip(0))
+    assert _maxerr(r4b.cpu(), torch.from_numpy(g["rot_b4_step2"])) < 1e-5
+    assert _maxerr(t4b.cpu(), torch.from_numpy(g["tr_b4_step2"])) < 1e-5
+    with pytest.raises(RuntimeError):
+        head4(fl4[:2])
+    # scan over a sequence == repeated single steps
+    feats = head.encode(fl.to(DEV))
+    rot_seq, tr_seq, _ = head.scan(feats[:, None, :])
+    for t in range(3):
+        assert _maxerr(rot_seq[t].cpu(), torch.from_numpy(g["rot%d" % t])) < 1e-5
+
+
+def test_clvo_head_rejects_unsupported_size(hsd):
+    head = ATDNVO()
+    head.load_state_dict(hsd)
+    head = head.to(DEV)
+    with pytest.raises(RuntimeError, match="16x4x13"):
+        head(torch.zeros(1, 2, 160, 512, device=DEV))
+
+
+def test_flow_plus_head_end_to_end_matches_golden(golden_dir, flow_net, hsd):
+    g = np.load(os.path.join(golden_dir, "gma_c2.npz"))
+    fr = torch.from_numpy(syn.make_frames(2, 376, 1232, seed=int(g["seed_frames"]))).to(DEV)
+    _, up = flow_net(fr[0:1], fr[1:2], iters=12, test_mode=True)
+    head = ATDNVO()
+    head.load_state_dict(hsd)
+    head = head.to(DEV)
+    rot, tr = head(up)
+    assert _maxerr(rot.cpu(), torch.from_numpy(g["rot"])) < 1e-5
+    assert _maxerr(tr.cpu(), torch.from_numpy(g["tr"])) < 1e-5
