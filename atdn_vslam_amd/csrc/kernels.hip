@@ -130,43 +130,57 @@ void launch_avgpool(const float* src, int H, int W, float* dst, long rows, hipSt
 }
 
 // ------------------------------------------------------------------ correlation-pyramid lookup
-// One wave per (source pixel, level): the <=10x10 window around the sampling centre is staged in LDS
-// (two cells per lane), then lanes produce the 81 bilinear samples and store them as one contiguous run.
+// One wave per (source pixel, level): a 12x12 window around the sampling centre is staged in LDS (cells
+// outside the map are the zero padding), then lanes produce the 81 bilinear samples and store them as one
+// contiguous run. Sample coordinates follow the reference's arithmetic step by step — centroid/2^l + delta
+// (corr.py:44-46), 2x/(W-1)-1 (utils.py:63-64), then grid_sample's align_corners un-normalisation
+// (x+1)*((W-1)/2) — so floor() and the four weights see the same fp32 values as the oracle; the 12-wide
+// window (one cell more than the nominal 10 on each side) covers a floor() that lands one off at integers.
+constexpr int LK_WIN = 12;
 __global__ __launch_bounds__(256) void lookup_kernel(const PyramidLevels pyr, const float* __restrict__ coords1,
                                                      long npix, float* __restrict__ out, int ldo) {
-  __shared__ float win[4][10 * 10 + 4];
+  __shared__ float win[4][LK_WIN * LK_WIN + 16];
   const int lvl = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int Hl = pyr.H[lvl], Wl = pyr.W[lvl];
   const float inv = 1.0f / (float)(1 << lvl);
+  const float wm1 = (float)(Wl - 1), hm1 = (float)(Hl - 1);
+  const float sfx = wm1 / 2.f, sfy = hm1 / 2.f;
   float* w = win[lvl];
   for (long p = blockIdx.x; p < npix; p += gridDim.x) {
     const float xc = coords1[p * 2 + 0] * inv, yc = coords1[p * 2 + 1] * inv;
     const bool sane = (fabsf(xc) < 1.0e6f) && (fabsf(yc) < 1.0e6f);  // also rejects NaN
-    const float xf = sane ? floorf(xc) : -1.0e5f, yf = sane ? floorf(yc) : -1.0e5f;
-    const float fx = sane ? xc - xf : 0.f, fy = sane ? yc - yf : 0.f;
-    const int wx0 = (int)xf - 4, wy0 = (int)yf - 4;
+    const int wx0 = sane ? (int)floorf(xc) - 5 : -(1 << 24), wy0 = sane ? (int)floorf(yc) - 5 : -(1 << 24);
     const float* src = pyr.base[lvl] + p * ((long)Hl * Wl);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 3; ++t) {
       const int c = lane + 64 * t;
-      if (c < 100) {
-        const int wy = c / 10, wx = c - wy * 10;
+      if (c < LK_WIN * LK_WIN) {
+        const int wy = c / LK_WIN, wx = c - wy * LK_WIN;
         const int y = wy0 + wy, x = wx0 + wx;
         const bool ok = ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
         w[c] = ok ? src[(long)y * Wl + x] : 0.f;
       }
     }
-    __builtin_amdgcn_s_waitcnt(0);          // LDS writes of this wave done (one wave owns win[lvl])
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's window is complete (one wave owns win[lvl])
     __builtin_amdgcn_wave_barrier();
-    const float nw = (1.f - fx) * (1.f - fy), ne = fx * (1.f - fy), sw = (1.f - fx) * fy, se = fx * fy;
     float* o = out + p * ldo + lvl * 81;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int k = lane + 64 * t;
       if (k < 81) {
         const int i = k / 9, j = k - i * 9;  // i steps x, j steps y (RAFT's transposed window)
-        const float* q = w + j * 10 + i;
-        o[k] = ((nw * q[0] + ne * q[1]) + sw * q[10]) + se * q[11];
+        float v = 0.f;
+        if (sane) {
+          const float px = xc + (float)(i - 4), py = yc + (float)(j - 4);
+          const float xg = 2.f * px / wm1 - 1.f, yg = 2.f * py / hm1 - 1.f;
+          const float ix = (xg + 1.f) * sfx, iy = (yg + 1.f) * sfy;
+          const float xw = floorf(ix), yn = floorf(iy);
+          const float ww = ix - xw, ee = 1.f - ww, nn = iy - yn, ss = 1.f - nn;
+          const int lx = min(max((int)xw - wx0, 0), LK_WIN - 2), ly = min(max((int)yn - wy0, 0), LK_WIN - 2);
+          const float* q = w + ly * LK_WIN + lx;
+          v = ((q[0] * (ee * ss) + q[1] * (ww * ss)) + q[LK_WIN] * (ee * nn)) + q[LK_WIN + 1] * (ww * nn);
+        }
+        o[k] = v;
       }
     }
     __builtin_amdgcn_wave_barrier();  // all reads done before the next pixel overwrites the window

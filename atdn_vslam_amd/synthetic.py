@@ -54,11 +54,24 @@ def make_gma_state(seed=0, prefix=""):
     for key in list(out):
         if ".downsample.1." in key:
             out[key] = out[key.replace(".downsample.1.", ".norm3.")].copy()
-    # keep the GRU/flow head contraction mild so 12 iterations stay O(10 px)
-    for key in out:
-        if "flow_head.conv2.weight" in key:
-            out[key] = (out[key] * 0.5).astype(np.float32)
+    # Trained checkpoints keep activations O(1)-O(10); plain fan-in scaling does not (features reach the
+    # hundreds and every sigmoid/softmax saturates, which amplifies rounding noise ~1000x). These per-layer
+    # factors bring the synthetic network to trained-like statistics: |fmap| ~ 4, |corr| ~ 25, |inp| ~ 6,
+    # motion features O(1), ~0.5 px flow update per iteration.
+    for frag, fac in _GMA_RESCALE:
+        for key in out:
+            if frag in key and (key.endswith(".weight") or key.endswith(".bias")) and "norm" not in key:
+                out[key] = (out[key] * fac).astype(np.float32)
     return out
+
+
+_GMA_RESCALE = (
+    ("fnet.conv2.", 0.25),
+    ("cnet.conv2.", 0.1),
+    ("update_block.encoder.convc1.", 0.1),
+    ("update_block.encoder.convf1.", 0.2),
+    ("update_block.flow_head.conv2.", 0.5),
+)
 
 
 def make_clvo_state(seed=0):

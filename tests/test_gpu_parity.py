@@ -1,8 +1,11 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on identical seeded
 inputs, against the committed golden fixtures (outputs of the imported reference), and through
-size-independent properties at full KITTI size.  Stated tolerances (fp32 MFMA path):
-flow_low <= 2e-4 px... measured per stage below; end-to-end flow_up <= 1e-3 px relative to |flow| scale,
-pose <= 1e-5."""
+size-independent properties at full KITTI size.
+
+Stated tolerances of the fp32-MFMA path: flow_low <= 2e-4 px, flow_up <= 1e-3 px
+(flows of up to ~75 px), pose <= 1e-5; intermediate activations <= 1e-4 absolute (values of O(1)-O(25)).
+Measured (tools/parity_report.py, MI355X): flow_up 1.6e-4 px max / 1.2e-5 mean at 376x1232 after 12
+iterations, against 8.8e-5 px between 1- and 8-thread runs of the CPU path itself."""
 import ctypes as C
 import os
 
@@ -147,7 +150,7 @@ def test_lookup_matches_reference_golden(golden_dir):
     gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=1, taps=taps)
     pyr = _pyramid_on_gpu(taps["fmap1"], taps["fmap2"])
     got = _lookup_on_gpu(pyr, torch.from_numpy(g["probe"])[None], 1, 20, 64)
-    assert _maxerr(got[0], torch.from_numpy(g["lookup"])) < 3e-5
+    assert _maxerr(got[0], torch.from_numpy(g["lookup"])) < 5e-5
 
 
 # ----------------------------------------------------------------------------- GMA forward
@@ -220,10 +223,9 @@ def test_gma_c1_full_flow_matches_golden(golden_dir, gsd, flow_net):
     low, up = flow_net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=int(g["iters"]), test_mode=True)
     ref_low, ref_up = gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=int(g["iters"]))
     low, up = low.cpu(), up.cpu()
-    # stated tolerance of the fp32 path: 2e-3 px on flows of up to 135 px after 8 recurrent iterations
-    assert _maxerr(low[0], torch.from_numpy(g["flow_low"])) < 5e-4
-    assert _maxerr(up[0], torch.from_numpy(g["flow_up"])) < 2e-3
-    assert _maxerr(low, ref_low) < 5e-4 and _maxerr(up, ref_up) < 2e-3
+    assert _maxerr(low[0], torch.from_numpy(g["flow_low"])) < 2e-4
+    assert _maxerr(up[0], torch.from_numpy(g["flow_up"])) < 1e-3
+    assert _maxerr(low, ref_low) < 2e-4 and _maxerr(up, ref_up) < 1e-3
 
 
 def test_gma_c2_kitti_size_matches_golden_and_is_batch_invariant(golden_dir, gsd, flow_net):
@@ -232,8 +234,8 @@ def test_gma_c2_kitti_size_matches_golden_and_is_batch_invariant(golden_dir, gsd
     low, up = flow_net(fr[0:1], fr[1:2], iters=int(g["iters"]), test_mode=True)
     assert tuple(low.shape) == (1, 2, 47, 154) and tuple(up.shape) == (1, 2, 376, 1232)
     lowc, upc = low.cpu(), up.cpu()
-    assert _maxerr(lowc[0], torch.from_numpy(g["flow_low"])) < 5e-4
-    assert _maxerr(upc[0, :, ::4, ::4], torch.from_numpy(g["flow_up_s4"])) < 2e-3
+    assert _maxerr(lowc[0], torch.from_numpy(g["flow_low"])) < 2e-4
+    assert _maxerr(upc[0, :, ::4, ::4], torch.from_numpy(g["flow_up_s4"])) < 1e-3
     np.testing.assert_allclose(upc.double().sum(dim=(0, 2, 3)).numpy(), g["flow_up_sum"], rtol=1e-5, atol=2.0)
     # same call again: bit-identical (no atomics anywhere on the path)
     low2, up2 = flow_net(fr[0:1], fr[1:2], iters=int(g["iters"]), test_mode=True)
@@ -259,7 +261,7 @@ def test_gma_flow_init_matches_oracle(gsd, flow_net):
     fi = torch.from_numpy(r.uniform(-2, 2, (1, 2, 20, 64)).astype(np.float32))
     ref_low, ref_up = gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=3, flow_init=fi)
     low, up = flow_net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=3, flow_init=fi.to(DEV), test_mode=True)
-    assert _maxerr(low.cpu(), ref_low) < 3e-4 and _maxerr(up.cpu(), ref_up) < 2e-3
+    assert _maxerr(low.cpu(), ref_low) < 2e-4 and _maxerr(up.cpu(), ref_up) < 1e-3
 
 
 def test_gma_module_contract(flow_net):
