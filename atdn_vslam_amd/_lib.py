@@ -37,7 +37,7 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
 }
 
-GMA_STAGES = ("fnet", "corr", "pool", "cnet", "attention", "lookup", "motion_encoder", "aggregate", "gru",
+GMA_STAGES = ("fnet", "corr", "pool", "cnet", "attention", "lookup", "motion_encoder", "aggregate", "gru_zr", "gru_q",
               "flow_head", "mask")
 
 _lib = None

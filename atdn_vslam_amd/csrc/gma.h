@@ -40,7 +40,7 @@ class GmaNet {
   size_t workspace_bytes() const { return ws_bytes_; }
   // Eager (un-graphed) run on `st` with hipEvents at stage boundaries; ms[] receives the time of each Stage
   // summed over `reps` forwards. Inputs are whatever the last forward() left in the workspace.
-  enum Stage { ST_FNET = 0, ST_CORR, ST_POOL, ST_CNET, ST_ATTN, ST_LOOKUP, ST_MOTION, ST_AGG, ST_GRU, ST_FLOWHEAD,
+  enum Stage { ST_FNET = 0, ST_CORR, ST_POOL, ST_CNET, ST_ATTN, ST_LOOKUP, ST_MOTION, ST_AGG, ST_GRU_ZR, ST_GRU_Q, ST_FLOWHEAD,
                ST_MASK, ST_COUNT };
   void profile(int B, int iters, int reps, float* ms, hipStream_t st);
 
@@ -68,7 +68,6 @@ class GmaNet {
   DeviceBuf pyr_[4], h_[2], x_, qk_, attn_, vT_, corrfeat_, cor1_, corflo_, flo1_, z_, rh_, fh_, mask_;
   DeviceBuf coords1_, flow4_;
   int pyrH_[4], pyrW_[4];
-  int hcur_ = 0;
   size_t ws_bytes_ = 0;
 
   struct Timer;

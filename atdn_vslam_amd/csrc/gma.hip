@@ -290,11 +290,12 @@ void GmaNet::iteration(int B, hipStream_t st) {
     ConvShape g = conv_shape(gru_zr_[p], hin, 128, (long)N * 128, B, H8, W8, 1, ph, pw);
     g.C0 = 128; g.src1 = x_.p; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = XLD;
     conv_dispatch<MODE_TAP>(g, EpiGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128}, st);
+    mark(ST_GRU_ZR, st);
     g.src0 = rh_.p; g.w = gru_q_[p].w; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_dispatch<MODE_TAP>(g, EpiGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128}, st);
+    mark(ST_GRU_Q, st);
   }
   // two passes: the state is back in h_[0]
-  mark(ST_GRU, st);
 
   // -- flow head (update.py:7-15) and coordinate update (network.py:116)
   s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);

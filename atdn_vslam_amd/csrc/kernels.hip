@@ -46,29 +46,51 @@ void launch_prep_images(const float* im1, const float* im2, int B, int H, int W,
 }
 
 // ------------------------------------------------------------------ instance norm
-__global__ void in_finalize_kernel(const float* __restrict__ ps, const float* __restrict__ pm2, int nimg, int groups,
-                                   int HW, int C, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nimg * C) return;
-  const int img = i / C, c = i - img * C;
+// One block per (image, 64-channel slab): lane = channel (coalesced partial reads), 16 waves stride over the
+// 32-row groups; every thread folds its groups with Chan's (count, mean, M2) merge in fp64, then the 16 partial
+// triples of a channel are merged in a fixed order through LDS (deterministic).
+__global__ __launch_bounds__(1024) void in_finalize_kernel(const float* __restrict__ ps, const float* __restrict__ pm2,
+                                                           int groups, int HW, int C, float eps,
+                                                           float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ double s_n[16][64], s_mu[16][64], s_m2[16][64];
+  const int img = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   const int ng = (HW + 31) / 32;  // groups that hold at least one valid row
-  const float* s = ps + (long)img * groups * C + c;
-  const float* m = pm2 + (long)img * groups * C + c;
-  double tot = 0.0;
-  for (int g = 0; g < ng; ++g) tot += (double)s[(long)g * C];
-  const double mu = tot / (double)HW;
-  double m2 = 0.0;
-  for (int g = 0; g < ng; ++g) {
-    const int cnt = min(32, HW - g * 32);
-    const double gm = (double)s[(long)g * C] / cnt - mu;
-    m2 += (double)m[(long)g * C] + cnt * gm * gm;  // Chan et al. merge of (count, mean, M2)
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  if (c < C) {
+    const float* s = ps + (long)img * groups * C + c;
+    const float* m = pm2 + (long)img * groups * C + c;
+#pragma unroll 4
+    for (int g = wv; g < ng; g += 16) {
+      const double cnt = (double)min(32, HW - g * 32);
+      const double gmu = (double)s[(long)g * C] / cnt;
+      const double gm2 = (double)m[(long)g * C];
+      const double tot = n + cnt, d = gmu - mu;
+      mu += d * (cnt / tot);
+      m2 += gm2 + d * d * (n * cnt / tot);
+      n = tot;
+    }
   }
-  mean[i] = (float)mu;
-  rstd[i] = (float)(1.0 / sqrt(m2 / (double)HW + (double)eps));
+  s_n[wv][lane] = n; s_mu[wv][lane] = mu; s_m2[wv][lane] = m2;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    n = 0.0; mu = 0.0; m2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      const double cnt = s_n[k][lane];
+      if (cnt > 0.0) {
+        const double tot = n + cnt, d = s_mu[k][lane] - mu;
+        mu += d * (cnt / tot);
+        m2 += s_m2[k][lane] + d * d * (n * cnt / tot);
+        n = tot;
+      }
+    }
+    mean[img * C + c] = (float)mu;
+    rstd[img * C + c] = (float)(1.0 / sqrt(m2 / (double)HW + (double)eps));
+  }
 }
 void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, int groups_per_img, int HW, int C,
                         float eps, float* mean, float* rstd, hipStream_t st) {
-  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(nimg * C, 64)), dim3(64), 0, st, part_sum, part_m2, nimg,
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(C, 64), nimg), dim3(1024), 0, st, part_sum, part_m2,
                      groups_per_img, HW, C, eps, mean, rstd);
   ATDN_HIP(hipGetLastError());
 }

@@ -1,0 +1,182 @@
+"""Headline benchmark: frame-pairs/s of KITTI-shaped odometry inference on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic frame pairs per GPU: GMA flow
+(12 GRU iterations, 376x1232 after the reference's resize of 376x1241 KITTI frames) -> CLVO CNN
+encoder -> 512-d feature. After the K steps the timed region also holds the sequence tail: ONE RCCL
+all-gather of the features and the ordered LSTM/MLP scan + rel2abs that turns them into the 6-DoF
+trajectory (every rank ends up with all N*K*B poses). Frames are resident in HBM before timing starts.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from atdn_vslam_amd import synthetic as syn  # noqa: E402
+from atdn_vslam_amd import transforms  # noqa: E402
+from atdn_vslam_amd.pipeline import OdometryPipeline, resize_frames  # noqa: E402
+from atdn_vslam_amd.sharding import gather_features  # noqa: E402
+
+H_KITTI, W_KITTI = 376, 1241
+H, W = 376, 1232
+N8 = (H // 8) * (W // 8)
+ITERS = 12
+# Algorithmic work per frame pair (SURVEY §8d / BASELINE.md §3): mask head + upsampling counted once.
+FLOP_PER_PAIR = 0.951e12
+# Dominant kernel: the fused z|r convolution of the separable ConvGRU (1x5 / 5x1, 512 -> 256 channels):
+# 2 * N8 * 256 * (5*512) FLOP per pair and launch, 24 launches per forward.
+GRU_ZR_FLOP = 2.0 * N8 * 256 * 2560
+LOOKUP_BYTES = N8 * (400 + 324) * 4.0  # <=400 cells read + 324 samples written per source pixel (fp32)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask and cgroup quota, capped at 64 (more threads only
+    slow the oneDNN convolutions of this path down)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(gsd, hsd, frames, budget_s=25.0):
+    """The CPU oracle (a port of the reference's PyTorch-CPU op sequence) on this host's cores, bounded sample."""
+    from oracle import clvo_ref, gma_ref
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    fr = frames.cpu()
+    state = clvo_ref.zero_state(1)
+    times = []
+    t_all = time.time()
+    for i in range(min(4, fr.shape[0] - 1)):
+        t0 = time.time()
+        _, up = gma_ref.gma_forward(gsd, fr[i:i + 1], fr[i + 1:i + 2], iters=ITERS)
+        _, _, state = clvo_ref.clvo_forward(hsd, up, state)
+        times.append(time.time() - t0)
+        if time.time() - t_all > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times  # first pair is warm-up
+    sec = float(np.median(timed))
+    return {"value": 1.0 / sec, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d pair(s) after 1 warm-up, 376x1232, %d iters, fp32, torch CPU ops, median %.3f s/pair"
+                      % (len(timed), ITERS, sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="frame pairs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B, K, Wm = args.batch, args.steps, args.warmup
+
+    gsd = syn.to_torch(syn.make_gma_state(seed=1))
+    hsd = syn.to_torch(syn.make_clvo_state(seed=1))
+    pipe = OdometryPipeline(gsd, hsd, device=dev, max_batch=B, iters=ITERS)
+    # synthetic clip, different per rank (each rank owns its own stretch of the sequence); resized once, resident
+    clip = 2 * B + 1
+    frames = resize_frames(torch.from_numpy(syn.make_frames(clip, H_KITTI, W_KITTI, seed=100 + rank)).to(dev))
+    torch.cuda.synchronize()
+
+    def step(i, feats):
+        s = (i * B) % (clip - B)
+        f, _ = pipe.features(frames[s:s + B], frames[s + 1:s + B + 1])
+        feats[i * B:(i + 1) * B] = f
+
+    feats = torch.empty((max(K, Wm) * B, 512), device=dev)
+    for i in range(Wm):
+        step(i, feats)
+    if Wm:
+        pipe.scan(feats[:B])  # warm the tail kernels too
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(K):
+        step(i, feats)
+        ev[i + 1].record()
+    allf = gather_features(feats[:K * B], world * K * B) if world > 1 else feats[:K * B]
+    rot, tr = pipe.scan(allf)
+    poses = transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert tuple(poses.shape) == (world * K * B + 1, 4, 4) and bool(torch.isfinite(poses).all())
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(K)]
+
+    if rank == 0:
+        total_pairs = world * K * B
+        # per-stage device time of the same forward, eager with HIP events on the launch stream
+        reps = 3
+        st = pipe.flow_net.profile(H, W, B, iters=ITERS, reps=reps)
+        zr_launch_ms = st["gru_zr"] / (2 * ITERS)
+        zr_tflops = GRU_ZR_FLOP * B / (zr_launch_ms * 1e-3) / 1e12
+        lookup_ms = st["lookup"] / ITERS
+        fwd_ms = float(np.median(step_ms))
+        out = {
+            "metric": "frame-pairs/sec, KITTI 1241x376 odometry inference at 1/2/4/8 MI355X",
+            "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "KITTI seq-03-shaped 376x1241 frames resized to 376x1232, GMA flow 12 GRU iters + "
+                                   "CLVO head -> 6-DoF trajectory (BASELINE configs[1])",
+                       "pairs_per_step_per_gpu": B, "gru_iters": ITERS, "parallelism": "pairs sharded x%d, one "
+                       "all-gather of 512-d features, replicated LSTM scan" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<TAP, EpiGruZR> (fused z|r ConvGRU convolution)",
+                         "achieved": zr_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": zr_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launch_ms": zr_launch_ms, "flop_per_launch": GRU_ZR_FLOP * B},
+            "forward": {"ms_per_batch_median": fwd_ms, "tflops": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12,
+                        "frac_of_f32_mfma_peak": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "lookup": {"ms_per_launch": lookup_ms, "achieved_GBps": LOOKUP_BYTES * B / (lookup_ms * 1e-3) / 1e9,
+                       "peak_GBps": PEAK_HBM_GBS},
+            "stages_ms_per_forward": {k: round(v, 4) for k, v in st.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(gsd, hsd, frames[:6])
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,8 +55,8 @@ long atdn_gma_debug_read(atdn_gma* h, const char* name, float* host, long capaci
 
 /* Per-stage device time (ms, summed over `reps` eager forwards of batch B), measured with HIP events on
  * `stream`. ms_out has ATDN_GMA_STAGES entries: fnet, corr, pool, cnet, attention, lookup, motion_encoder,
- * aggregate, gru, flow_head, mask. */
-#define ATDN_GMA_STAGES 11
+ * aggregate, gru_zr (fused z|r convolution), gru_q, flow_head, mask. */
+#define ATDN_GMA_STAGES 12
 int atdn_gma_profile(atdn_gma* h, int B, int iters, int reps, float* ms_out, void* stream);
 
 size_t atdn_gma_workspace_bytes(atdn_gma* h);
