@@ -1,0 +1,57 @@
+"""Worker for tests/test_sharding.py: runs the sharded odometry driver on `gloo` CPU tensors. The per-pair
+feature function and the scan are the CPU oracle (tests may use it); what is under test is the driver:
+shard ranges, ragged/empty shards, gather order and rank-identical results."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from atdn_vslam_amd import synthetic as syn  # noqa: E402
+from atdn_vslam_amd.sharding import gather_features, shard_range, sharded_odometry  # noqa: E402
+from oracle import clvo_ref  # noqa: E402
+
+
+def main():
+    out_dir = sys.argv[1]
+    n_pairs = int(sys.argv[2])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.set_num_threads(2)
+    hsd = syn.to_torch(syn.make_clvo_state(seed=1))
+    flows = torch.from_numpy(syn.make_flow(n_pairs, 376, 1232, seed=31))  # stands in for the per-pair flow
+
+    calls = []
+
+    def encode(lo, hi):
+        calls.append((lo, hi))
+        if hi == lo:
+            return torch.zeros((0, 512))
+        return clvo_ref.clvo_encode(hsd, flows[lo:hi])
+
+    def scan(feats):
+        state = clvo_ref.zero_state(1)
+        rots, trs = [], []
+        for t in range(feats.shape[0]):
+            r, x, state = clvo_ref.clvo_step(hsd, feats[t:t + 1], state)
+            rots.append(r)
+            trs.append(x)
+        return torch.cat(rots), torch.cat(trs)
+
+    rot, tr = sharded_odometry(n_pairs, encode, scan)
+    assert calls == [shard_range(n_pairs, rank, world)]
+    # gather_features alone, with a recognisable payload
+    lo, hi = shard_range(n_pairs, rank, world)
+    tag = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
+    full = gather_features(tag, n_pairs)
+    assert torch.equal(full[:, 0], torch.arange(n_pairs, dtype=torch.float32))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rot=rot.numpy(), tr=tr.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
