@@ -44,6 +44,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, den
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel_fragment, batch):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, collected in separate --pmc runs at B = 4)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files or batch != 4:
+        return None
+    data = json.load(open(files[-1]))
+    for name, v in data.items():
+        if kernel_fragment in name:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask and cgroup quota, capped at 64 (more threads only
     slow the oneDNN convolutions of this path down)."""
@@ -162,7 +176,7 @@ def main():
                        "all-gather of 512-d features, replicated LSTM scan" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<TAP, EpiGruZR> (fused z|r ConvGRU convolution)",
                          "achieved": zr_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": zr_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": zr_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("EpiGruZR", B),
                          "launch_ms": zr_launch_ms, "flop_per_launch": GRU_ZR_FLOP * B},
             "forward": {"ms_per_batch_median": fwd_ms, "tflops": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12,
                         "frac_of_f32_mfma_peak": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
