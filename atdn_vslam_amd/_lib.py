@@ -14,7 +14,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "atdn_version": (C.c_int, []),
     "atdn_last_error": (C.c_char_p, []),
-    "atdn_gma_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),
+    "atdn_gma_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
     "atdn_gma_load": (C.c_int, [_vp, C.c_char_p, _vp, _i64p, C.c_int]),
     "atdn_gma_finalize": (C.c_int, [_vp]),
     "atdn_gma_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
@@ -35,6 +35,8 @@ SIGNATURES = {
     "atdn_corr_pyramid": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "atdn_conv2d_nhwc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "atdn_conv2d_nhwc_sf": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, _vp, _vp]),
 }
 
 GMA_STAGES = ("fnet", "corr", "pool", "cnet", "attention", "lookup", "motion_encoder", "aggregate", "gru_zr", "gru_q",

@@ -5,6 +5,8 @@
 
 #include "clvo.h"
 #include "gma.h"
+#include "conv_sf.h"
+#include "epilogues_sf.h"
 
 namespace atdn {
 extern template TileChoice conv_dispatch<MODE_TAP, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
@@ -13,13 +15,15 @@ extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_NONE>>(const Conv
 extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_RELU>>(const ConvShape&, EpiBias<ACT_RELU>, hipStream_t);
 extern template TileChoice conv_dispatch<MODE_TAP, EpiScale>(const ConvShape&, EpiScale, hipStream_t);
 
+extern template TileChoice conv_sf_dispatch<EpiBias<ACT_NONE>>(const ConvShape&, float, EpiBias<ACT_NONE>, hipStream_t);
+
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 }  // namespace atdn
 
 using namespace atdn;
 
-struct atdn_gma { GmaNet net; atdn_gma(int H, int W, int B) : net(H, W, B) {} };
+struct atdn_gma { GmaNet net; atdn_gma(int H, int W, int B, int prec) : net(H, W, B, prec) {} };
 struct atdn_clvo { ClvoNet net; atdn_clvo(int H, int W, int B) : net(H, W, B) {} };
 
 #define ATDN_API_BEGIN try {
@@ -64,10 +68,10 @@ extern "C" {
 int atdn_version(void) { return 100; }
 const char* atdn_last_error(void) { return g_last_error.c_str(); }
 
-int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch) {
+int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch, int precision) {
   ATDN_API_BEGIN
   ATDN_CHECK(out, "null out pointer");
-  *out = new atdn_gma(H, W, max_batch);
+  *out = new atdn_gma(H, W, max_batch, precision);
   ATDN_API_END
 }
 int atdn_gma_load(atdn_gma* h, const char* key, const float* data, const int64_t* shape, int rank) {
@@ -235,6 +239,44 @@ int atdn_conv2d_nhwc(const float* src, int nimg, int H, int W, int Cin, const fl
     A.release();
     throw;
   }
+  A.release();
+  ATDN_API_END
+}
+
+int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
+                        const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, float* dst,
+                        void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(src && weight_host && dst && nimg >= 1 && Cin % 32 == 0, "bad argument (Cin must be a multiple of 32)");
+  StateDict sd;
+  const int64_t ws[4] = {Cout, Cin, KH, KW};
+  sd.put("c.weight", weight_host, ws, 4);
+  std::vector<float> zb(Cout, 0.f);
+  const int64_t bs[1] = {Cout};
+  sd.put("c.bias", bias_host ? bias_host : zb.data(), bs, 1);
+  WeightArena A;
+  PackedConv L = pack_conv_sf(A, sd, {"c"});
+  A.upload();
+  resolve(A, L);
+  hipStream_t st = (hipStream_t)stream;
+  float* tmp = nullptr;
+  const long rows = (long)nimg * H * W;
+  ATDN_HIP(hipMalloc(&tmp, (size_t)rows * Cin * sizeof(float)));
+  try {
+    launch_to_sf(src, tmp, rows, Cin, st);
+    ConvShape s;
+    s.src0 = tmp; s.ld0 = Cin; s.sb0 = (long)H * W * Cin; s.C0 = L.C; s.H = H; s.W = W;
+    s.KH = KH; s.KW = KW; s.stride = stride; s.padH = padH; s.padW = padW;
+    s.w = L.w; s.ldw = L.ldw; s.N = Cout; s.nimg = nimg;
+    const int Ho = conv_out(H, KH, stride, padH), Wo = conv_out(W, KW, stride, padW);
+    conv_sf_dispatch(s, L.wscale, EpiBias<ACT_NONE>{L.b, dst, (long)Ho * Wo * Cout, Cout, 1.f}, st);
+    ATDN_HIP(hipStreamSynchronize(st));
+  } catch (...) {
+    (void)hipFree(tmp);
+    A.release();
+    throw;
+  }
+  (void)hipFree(tmp);
   A.release();
   ATDN_API_END
 }

@@ -1,0 +1,190 @@
+// Implicit-GEMM convolution / batched NT-GEMM on the f16 matrix core with split-f16 ("sf", sf.h) operands:
+//   A·B ≈ A_hi·B_hi + A_hi·B_lo + A_lo·B_hi        (three v_mfma_f32_32x32x16_f16, fp32 accumulate)
+// f16 x f16 products are exact in fp32 and the dropped lo·lo term is 2^-22 relative, so the result is fp32-grade
+// while the matrix pipe runs at 16/3 = 5.3x the rate of v_mfma_f32_32x32x2_f32.
+//
+// Same tiling, gather (TAP mode only: channel counts are multiples of 32), virtual concat, per-image M tiling,
+// XCD remap and epilogue interface as conv_mfma.h. Differences:
+// * operands are sf tensors: a 128-byte K-chunk of a pixel is [32 hi | 32 lo] halves, copied verbatim to LDS
+//   ([row][144 B]); lane (r, h) reads its 8 hi and 8 lo halves of a 16-deep k-step with two ds_read_b128;
+// * packed weights carry a per-layer power-of-two scale (max|w'| in [1,2)) so that the lo halves of small
+//   weights stay normal f16 numbers; the accumulator is multiplied by `wscale` = 2^-p before the epilogue.
+#pragma once
+#include "conv_dispatch.h"
+#include "sf.h"
+
+namespace atdn {
+
+template <int TM, int TN, int WGM, int WGN, class Epi>
+__global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const float wscale, const Epi ep) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
+  float* As = lds;
+  float* Bs = lds + BM * LDS_LD;
+
+  const int tid = threadIdx.x;
+  const int nblk = g.nimg * g.tiles_per_img * g.ntile_n;
+  const int id = xcd_remap(blockIdx.x, nblk);
+  const int tile_n = id % g.ntile_n;
+  const int tmg = id / g.ntile_n;
+  const int img = tmg / g.tiles_per_img;
+  const int pix0 = (tmg % g.tiles_per_img) * BM;
+  const int n0 = tile_n * BN;
+  const int HoWo = g.Ho * g.Wo;
+
+  const int s = tid & 7;
+  const int r0 = tid >> 3;
+  int iy0[RA], ix0[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = pix0 + r0 + 32 * i;
+    if (m < HoWo) {
+      const int oy = m / g.Wo, ox = m - oy * g.Wo;
+      iy0[i] = oy * g.stride - g.padH;
+      ix0[i] = ox * g.stride - g.padW;
+    } else {
+      iy0[i] = -(1 << 20);
+      ix0[i] = -(1 << 20);
+    }
+  }
+  const float* wrow[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int n = n0 + r0 + 32 * j;
+    wrow[j] = (n < g.N) ? (g.w + (long)img * g.wb + (long)n * g.ldw + 4 * s) : nullptr;
+  }
+  const float* s0 = g.src0 + (long)img * g.sb0;
+  const float* s1 = g.src1 ? g.src1 + (long)img * g.sb1 : nullptr;
+
+  float4 ra[RA], rb[RB];
+  int ky = 0, kx = 0, cc = 0;
+  const int ctot = g.C0 + g.C1;
+
+  auto fetch = [&](int q) {
+    const float* sp;
+    int ld, co;
+    if (cc < g.C0) { sp = s0; ld = g.ld0; co = cc; } else { sp = s1; ld = g.ld1; co = cc - g.C0; }
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      const bool ok = ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+      ra[i] = ok ? *reinterpret_cast<const float4*>(sp + (long)(iy * g.W + ix) * ld + co + 4 * s)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    cc += 32;
+    if (cc == ctot) { cc = 0; if (++kx == g.KW) { kx = 0; ++ky; } }
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      rb[j] = wrow[j] ? *reinterpret_cast<const float4*>(wrow[j] + q * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // byte view of the LDS image: row stride 144 B; hi halves at [0,64), lo halves at [64,128)
+  const char* a_rd = reinterpret_cast<const char*>(As + (wm * TM * 32 + r) * LDS_LD) + 16 * h;
+  const char* b_rd = reinterpret_cast<const char*>(Bs + (wn * TN * 32 + r) * LDS_LD) + 16 * h;
+  constexpr int ROWB = LDS_LD * 4;
+
+  fetch(0);
+  for (int q = 0; q < g.nchunks; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDS_LD + 4 * s) = ra[i];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = rb[j];
+    __syncthreads();
+    if (q + 1 < g.nchunks) fetch(q + 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(a_rd + i * 32 * ROWB + 32 * t);
+        al[i] = *reinterpret_cast<const f16x8*>(a_rd + i * 32 * ROWB + 32 * t + 64);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(b_rd + j * 32 * ROWB + 32 * t);
+        bl[j] = *reinterpret_cast<const f16x8*>(b_rd + j * 32 * ROWB + 32 * t + 64);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mbase = pix0 + (wm * TM + i) * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + r;
+      const bool nok = n < g.N;
+      if constexpr (Epi::kStats) {
+        const float bias = nok ? ep.bias[n] : 0.f;
+        float v[16];
+        float sum = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+          v[e] = acc[i][j][e] * wscale + bias;
+          if (m < HoWo) { sum += v[e]; ++cnt; }
+        }
+        sum += __shfl_xor(sum, 32);
+        cnt += __shfl_xor(cnt, 32);
+        const float mean = sum / (float)(cnt > 0 ? cnt : 1);
+        float m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m < HoWo) { const float d = v[e] - mean; m2 += d * d; }
+        }
+        m2 += __shfl_xor(m2, 32);
+        if (h == 0 && nok) {
+          const int grp = mbase >> 5;
+          const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
+          ep.part_sum[o] = sum;
+          ep.part_m2[o] = m2;
+        }
+      }
+      if (nok) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m < HoWo) ep(img, m, n, acc[i][j][e] * wscale);
+        }
+      }
+    }
+  }
+}
+
+template <int TM, int TN, int WGM, int WGN, class Epi>
+inline void launch_conv_sf(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  ConvGeom g = make_geom<MODE_TAP>(s, BM, BN);
+  const int nblk = g.nimg * g.tiles_per_img * g.ntile_n;
+  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
+  ATDN_HIP(hipGetLastError());
+}
+
+// Definitions are explicitly instantiated in conv_sf_inst_*.hip
+template <class Epi>
+TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_t st);
+
+}  // namespace atdn

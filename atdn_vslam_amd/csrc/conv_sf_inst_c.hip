@@ -1,0 +1,6 @@
+#include "conv_sf_dispatch_impl.h"
+namespace atdn {
+ATDN_INSTANTIATE_CONV_SF(EpiScale)
+ATDN_INSTANTIATE_CONV_SF(SfQK)
+ATDN_INSTANTIATE_CONV_SF(SfStoreT)
+}

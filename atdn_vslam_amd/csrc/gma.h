@@ -28,7 +28,8 @@ class DeviceBuf {
 
 class GmaNet {
  public:
-  GmaNet(int H, int W, int max_batch);
+  // precision: 0 = exact-fp32 MFMA everywhere; 1 = split-f16 (3 x f16 MFMA, fp32-grade) for every TAP-mode GEMM
+  GmaNet(int H, int W, int max_batch, int precision);
   ~GmaNet();
   StateDict& state() { return sd_; }
   void finalize();  // pack + upload weights, allocate the workspace
@@ -44,13 +45,16 @@ class GmaNet {
                ST_MASK, ST_COUNT };
   void profile(int B, int iters, int reps, float* ms, hipStream_t st);
 
-  int H, W, H8, W8, N, ldN, maxB;
+  int H, W, H8, W8, N, ldN, maxB, precision;
 
  private:
   void run_body(int B, int iters, hipStream_t st);  // everything between input prep and upsampling
   void run_encoder(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int* outH,
                    int* outW);
   void iteration(int B, hipStream_t st);
+  void run_body_sf(int B, int iters, hipStream_t st);
+  void run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf);
+  void iteration_sf(int B, hipStream_t st);
   void capture(int B, int iters);
 
   StateDict sd_;
@@ -64,7 +68,7 @@ class GmaNet {
   long gamma_off_ = -1;
 
   // workspace
-  DeviceBuf img4_, enc_[3], fmap_, psum_, pm2_, mean_[2], rstd_[2];
+  DeviceBuf img4_, enc_[4], sim_, scratch_, fmap_, psum_, pm2_, mean_[2], rstd_[2];
   DeviceBuf pyr_[4], h_[2], x_, qk_, attn_, vT_, corrfeat_, cor1_, corflo_, flo1_, z_, rh_, fh_, mask_;
   DeviceBuf coords1_, flow4_;
   int pyrH_[4], pyrW_[4];

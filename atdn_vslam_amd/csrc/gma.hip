@@ -2,6 +2,8 @@
 // (lookup -> motion encoder -> attention aggregate -> separable ConvGRU -> flow head), mask head and
 // convex upsampling.  Reference: whl:GMA/core/network.py:72-129 and the blocks it calls.
 #include "gma.h"
+#include "conv_sf.h"
+#include "epilogues_sf.h"
 
 namespace atdn {
 
@@ -20,6 +22,13 @@ extern template TileChoice conv_dispatch<MODE_TAP, EpiGruZR>(const ConvShape&, E
 extern template TileChoice conv_dispatch<MODE_TAP, EpiGruQ>(const ConvShape&, EpiGruQ, hipStream_t);
 extern template TileChoice conv_dispatch<MODE_TAP, EpiFlowDelta>(const ConvShape&, EpiFlowDelta, hipStream_t);
 
+extern template TileChoice conv_dispatch<MODE_ROW, SfBias<ACT_RELU>>(const ConvShape&, SfBias<ACT_RELU>, hipStream_t);
+#define ATDN_EXTERN_SF(EPI) extern template TileChoice conv_sf_dispatch<EPI>(const ConvShape&, float, EPI, hipStream_t);
+ATDN_EXTERN_SF(SfBias<ACT_NONE>) ATDN_EXTERN_SF(SfBias<ACT_RELU>) ATDN_EXTERN_SF(EpiBias<ACT_NONE>)
+ATDN_EXTERN_SF(EpiBiasStats) ATDN_EXTERN_SF(SfBiasReluAddRelu) ATDN_EXTERN_SF(SfContextSplit)
+ATDN_EXTERN_SF(EpiScale) ATDN_EXTERN_SF(SfQK) ATDN_EXTERN_SF(SfStoreT)
+ATDN_EXTERN_SF(SfAggregate) ATDN_EXTERN_SF(SfGruZR) ATDN_EXTERN_SF(SfGruQ) ATDN_EXTERN_SF(SfFlowDelta)
+
 namespace {
 
 constexpr int XLD = 384;       // GRU input x = [inp | motion(126) flow(2) | motion_global]  (update.py:130)
@@ -34,9 +43,13 @@ ConvShape conv_shape(const PackedConv& L, const float* src, int ld, long sb, int
   return s;
 }
 
-EncoderWeights pack_encoder(WeightArena& A, const StateDict& sd, const std::string& p, bool batchnorm) {
+EncoderWeights pack_encoder(WeightArena& A, const StateDict& sd, const std::string& p, bool batchnorm, bool sf) {
   EncoderWeights E;
   auto fold = [&](const std::string& norm) { return bn_affine(sd, norm); };
+  auto pack_conv = [&](WeightArena& A_, const StateDict& sd_, const std::vector<std::string>& names, int mode, int cpix,
+                       const ChannelAffine* f = nullptr) {
+    return (sf && mode == MODE_TAP) ? pack_conv_sf(A_, sd_, names, f) : atdn::pack_conv(A_, sd_, names, mode, cpix, f);
+  };
   if (batchnorm) { auto a = fold(p + "norm1"); E.stem = pack_conv(A, sd, {p + "conv1"}, MODE_ROW, 4, &a); }
   else E.stem = pack_conv(A, sd, {p + "conv1"}, MODE_ROW, 4);
   int bi = 0;
@@ -87,10 +100,11 @@ void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
   for (int r = 0; r < reps; ++r) {
     Timer t;
     timer_ = &t;
-    launch_init_coords(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
+    if (precision == 1) launch_init_coords_sf(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
+    else launch_init_coords(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
     ATDN_HIP(hipEventCreate(&t.start));
     ATDN_HIP(hipEventRecord(t.start, st));
-    try { run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
+    try { if (precision == 1) run_body_sf(B, iters, st); else run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
     timer_ = nullptr;
     ATDN_HIP(hipStreamSynchronize(st));
     hipEvent_t prev = t.start;
@@ -105,7 +119,8 @@ void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
   }
 }
 
-GmaNet::GmaNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) {
+GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), maxB(max_batch), precision(precision_) {
+  ATDN_CHECK(precision == 0 || precision == 1, "precision must be 0 (fp32 MFMA) or 1 (split-f16 MFMA)");
   ATDN_CHECK(H % 8 == 0 && W % 8 == 0 && H >= 64 && W >= 64, "frame size must be a multiple of 8 (use the padder)");
   ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
@@ -116,7 +131,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) {
 GmaNet::~GmaNet() {
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_};
   for (auto* b : all) b->release();
@@ -126,24 +141,29 @@ GmaNet::~GmaNet() {
 void GmaNet::finalize() {
   ATDN_CHECK(!ready_, "finalize called twice");
   const std::string u = "update_block.";
-  fnet_ = pack_encoder(arena_, sd_, "fnet.", false);
-  cnet_ = pack_encoder(arena_, sd_, "cnet.", true);
-  convc1_ = pack_conv(arena_, sd_, {u + "encoder.convc1"}, MODE_TAP, 0);
-  convc2_ = pack_conv(arena_, sd_, {u + "encoder.convc2"}, MODE_TAP, 0);
+  const bool sf = precision == 1;
+  auto tap = [&](const std::vector<std::string>& names, bool has_bias = true) {
+    return sf ? pack_conv_sf(arena_, sd_, names, nullptr, has_bias)
+              : pack_conv(arena_, sd_, names, MODE_TAP, 0, nullptr, has_bias);
+  };
+  fnet_ = pack_encoder(arena_, sd_, "fnet.", false, sf);
+  cnet_ = pack_encoder(arena_, sd_, "cnet.", true, sf);
+  convc1_ = tap({u + "encoder.convc1"});
+  convc2_ = tap({u + "encoder.convc2"});
   convf1_ = pack_conv(arena_, sd_, {u + "encoder.convf1"}, MODE_ROW, 4);
-  convf2_ = pack_conv(arena_, sd_, {u + "encoder.convf2"}, MODE_TAP, 0);
-  convm_ = pack_conv(arena_, sd_, {u + "encoder.conv"}, MODE_TAP, 0);
-  to_v_ = pack_conv(arena_, sd_, {u + "aggregator.to_v"}, MODE_TAP, 0, nullptr, false);
-  to_qk_ = pack_conv(arena_, sd_, {"att.to_qk"}, MODE_TAP, 0, nullptr, false);
+  convf2_ = tap({u + "encoder.convf2"});
+  convm_ = tap({u + "encoder.conv"});
+  to_v_ = tap({u + "aggregator.to_v"}, false);
+  to_qk_ = tap({"att.to_qk"}, false);
   for (int p = 0; p < 2; ++p) {
     const std::string t = std::to_string(p + 1);
-    gru_zr_[p] = pack_conv(arena_, sd_, {u + "gru.convz" + t, u + "gru.convr" + t}, MODE_TAP, 0);
-    gru_q_[p] = pack_conv(arena_, sd_, {u + "gru.convq" + t}, MODE_TAP, 0);
+    gru_zr_[p] = tap({u + "gru.convz" + t, u + "gru.convr" + t});
+    gru_q_[p] = tap({u + "gru.convq" + t});
   }
-  fh1_ = pack_conv(arena_, sd_, {u + "flow_head.conv1"}, MODE_TAP, 0);
-  fh2_ = pack_conv(arena_, sd_, {u + "flow_head.conv2"}, MODE_TAP, 0);
-  mask0_ = pack_conv(arena_, sd_, {u + "mask.0"}, MODE_TAP, 0);
-  mask2_ = pack_conv(arena_, sd_, {u + "mask.2"}, MODE_TAP, 0);
+  fh1_ = tap({u + "flow_head.conv1"});
+  fh2_ = tap({u + "flow_head.conv2"});
+  mask0_ = tap({u + "mask.0"});
+  mask2_ = tap({u + "mask.2"});
   gamma_off_ = pack_vector(arena_, sd_.get(u + "aggregator.gamma").data);
   arena_.upload();
   resolve_encoder(arena_, fnet_);
@@ -158,7 +178,8 @@ void GmaNet::finalize() {
   const int H2 = conv_out(H, 7, 2, 3), W2 = conv_out(W, 7, 2, 3);
   const long n8 = (long)B * N;
   img4_.alloc(2L * B * H * W * 4);
-  for (auto& e : enc_) e.alloc(2L * B * H2 * W2 * 64);
+  for (int i = 0; i < (sf ? 4 : 3); ++i) enc_[i].alloc(2L * B * H2 * W2 * 64);
+  if (sf) sim_.alloc((long)B * N * ldN);
   fmap_.alloc(2L * B * N * 256);
   const long groups = (long)cdiv(H2 * W2, 64) * 4 + 8;
   psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128);
@@ -179,7 +200,7 @@ void GmaNet::finalize() {
   ATDN_HIP(hipMemset(flow4_.p, 0, flow4_.n * sizeof(float)));
   ATDN_HIP(hipDeviceSynchronize());
   ws_bytes_ = 0;
-  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &fmap_, &psum_, &pm2_, &pyr_[0], &pyr_[1], &pyr_[2],
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &fmap_, &psum_, &pm2_, &pyr_[0], &pyr_[1], &pyr_[2],
                       &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_, &corrfeat_, &cor1_, &corflo_, &flo1_, &z_,
                       &rh_, &fh_, &mask_, &coords1_, &flow4_};
   for (auto* b : all) ws_bytes_ += (size_t)b->n * sizeof(float);
@@ -349,11 +370,162 @@ void GmaNet::run_body(int B, int iters, hipStream_t st) {
   mark(ST_MASK, st);
 }
 
+// =============================================================== split-f16 pipeline (precision == 1)
+// Same op sequence; every TAP-mode GEMM runs on conv_sf_kernel and every tensor that feeds one is stored in the
+// sf format (sf.h). ROW-mode layers (7x7 stems, convf1) stay on the exact-fp32 engine and write sf directly.
+void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf) {
+  int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
+  float* X = enc_[0].p; float* R = enc_[1].p; float* Y = enc_[2].p; float* O = enc_[3].p;
+  auto stats_sf = [&](const PackedConv& L, const float* src, int ld, int ih, int iw, int stride, int pad, float* dst,
+                      int slot) {
+    ConvShape s = conv_shape(L, src, ld, (long)ih * iw * ld, nimg, ih, iw, stride, pad, pad);
+    const int oh = conv_out(ih, L.KH, stride, pad), ow = conv_out(iw, L.KW, stride, pad);
+    EpiBiasStats ep{L.b, dst, (long)oh * ow * L.N, L.N, psum_.p, pm2_.p, 0};
+    TileChoice t = conv_sf_dispatch(s, L.wscale, ep, st);
+    const int groups = cdiv(oh * ow, t.BM) * (t.BM / 32);
+    ATDN_CHECK((long)nimg * groups * L.N <= psum_.n, "statistics scratch too small");
+    launch_in_finalize(psum_.p, pm2_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p, st);
+  };
+  if (instance) {
+    ConvShape s = conv_shape(E.stem, img4_.p, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
+    EpiBiasStats ep{E.stem.b, R, (long)h * w * 64, 64, psum_.p, pm2_.p, 0};
+    TileChoice t = conv_dispatch<MODE_ROW>(s, ep, st);
+    const int groups = cdiv(h * w, t.BM) * (t.BM / 32);
+    launch_in_finalize(psum_.p, pm2_.p, nimg, groups, h * w, 64, 1e-5f, mean_[0].p, rstd_[0].p, st);
+    launch_in_apply_sf(R, X, mean_[0].p, rstd_[0].p, nullptr, nullptr, nullptr, nullptr, nimg, (long)h * w, 64, st);
+  } else {
+    ConvShape s = conv_shape(E.stem, img4_.p, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
+    conv_dispatch<MODE_ROW>(s, SfBias<ACT_RELU>{E.stem.b, X, (long)h * w * 64, 64}, st);
+  }
+  int c = 64;
+  for (int bi = 0; bi < 6; ++bi) {
+    const auto& Bk = E.blk[bi];
+    const int stride = Bk.has_ds ? 2 : 1;
+    const int co = Bk.c1.N;
+    const int oh = conv_out(h, 3, stride, 1), ow = conv_out(w, 3, stride, 1);
+    const long ohw = (long)oh * ow;
+    if (instance) {
+      stats_sf(Bk.c1, X, c, h, w, stride, 1, R, 0);
+      launch_in_apply_sf(R, Y, mean_[0].p, rstd_[0].p, nullptr, nullptr, nullptr, nullptr, nimg, ohw, co, st);
+      stats_sf(Bk.c2, Y, co, oh, ow, 1, 1, R, 0);
+      if (Bk.has_ds) {
+        stats_sf(Bk.ds, X, c, h, w, 2, 0, Y, 1);  // Y is dead once conv2 has consumed it: holds the raw shortcut
+        launch_in_apply_sf(R, O, mean_[0].p, rstd_[0].p, nullptr, Y, mean_[1].p, rstd_[1].p, nimg, ohw, co, st);
+      } else {
+        launch_in_apply_sf(R, O, mean_[0].p, rstd_[0].p, X, nullptr, nullptr, nullptr, nimg, ohw, co, st);
+      }
+    } else {
+      const float* res = X;
+      if (Bk.has_ds) {
+        ConvShape sd = conv_shape(Bk.ds, X, c, (long)h * w * c, nimg, h, w, 2, 0, 0);
+        conv_sf_dispatch(sd, Bk.ds.wscale, SfBias<ACT_NONE>{Bk.ds.b, R, ohw * co, co}, st);
+        res = R;
+      }
+      ConvShape s1 = conv_shape(Bk.c1, X, c, (long)h * w * c, nimg, h, w, stride, 1, 1);
+      conv_sf_dispatch(s1, Bk.c1.wscale, SfBias<ACT_RELU>{Bk.c1.b, Y, ohw * co, co}, st);
+      ConvShape s2 = conv_shape(Bk.c2, Y, co, ohw * co, nimg, oh, ow, 1, 1, 1);
+      conv_sf_dispatch(s2, Bk.c2.wscale, SfBiasReluAddRelu{Bk.c2.b, res, ohw * co, co, O, ohw * co, co}, st);
+    }
+    std::swap(X, O);
+    h = oh; w = ow; c = co;
+  }
+  ATDN_CHECK(h == H8 && w == W8, "encoder geometry mismatch");
+  *out_buf = X;
+}
+
+void GmaNet::iteration_sf(int B, hipStream_t st) {
+  const long n8 = (long)B * N;
+  PyramidLevels pl;
+  for (int l = 0; l < 4; ++l) { pl.base[l] = pyr_[l].p; pl.H[l] = pyrH_[l]; pl.W[l] = pyrW_[l]; }
+  launch_lookup_sf(pl, coords1_.p, n8, corrfeat_.p, CORR_LD, st);
+  mark(ST_LOOKUP, st);
+
+  ConvShape s = conv_shape(convc1_, corrfeat_.p, CORR_LD, (long)N * CORR_LD, B, H8, W8, 1, 0, 0);
+  conv_sf_dispatch(s, convc1_.wscale, SfBias<ACT_RELU>{convc1_.b, cor1_.p, (long)N * 256, 256}, st);
+  s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
+  conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
+  s = conv_shape(convf1_, flow4_.p, 4, (long)N * 4, B, H8, W8, 1, 3, 3);
+  conv_dispatch<MODE_ROW>(s, SfBias<ACT_RELU>{convf1_.b, flo1_.p, (long)N * 128, 128}, st);
+  s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  conv_sf_dispatch(s, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
+  s = conv_shape(convm_, corflo_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
+  float* mf = x_.p + 128;
+  conv_sf_dispatch(s, convm_.wscale, SfBias<ACT_RELU>{convm_.b, mf, (long)N * XLD, XLD}, st);
+  mark(ST_MOTION, st);
+
+  s = conv_shape(to_v_, mf, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
+  conv_sf_dispatch(s, to_v_.wscale, SfStoreT{vT_.p, (long)128 * ldN, ldN}, st);
+  ConvShape a;
+  a.src0 = attn_.p; a.ld0 = ldN; a.sb0 = (long)N * ldN; a.C0 = ldN; a.H = 1; a.W = N;
+  a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
+  conv_sf_dispatch(a, 1.f, SfAggregate{gamma_, mf, (long)N * XLD, XLD, x_.p + 256, (long)N * XLD, XLD}, st);
+  mark(ST_AGG, st);
+
+  for (int p = 0; p < 2; ++p) {
+    const float* hin = h_[p].p;
+    float* hout = h_[p ^ 1].p;
+    const int ph = p ? 2 : 0, pw = p ? 0 : 2;
+    ConvShape g = conv_shape(gru_zr_[p], hin, 128, (long)N * 128, B, H8, W8, 1, ph, pw);
+    g.C0 = 128; g.src1 = x_.p; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = XLD;
+    conv_sf_dispatch(g, gru_zr_[p].wscale, SfGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128}, st);
+    mark(ST_GRU_ZR, st);
+    g.src0 = rh_.p; g.w = gru_q_[p].w; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
+    conv_sf_dispatch(g, gru_q_[p].wscale, SfGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128}, st);
+    mark(ST_GRU_Q, st);
+  }
+
+  s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  conv_sf_dispatch(s, fh1_.wscale, SfBias<ACT_RELU>{fh1_.b, fh_.p, (long)N * 256, 256}, st);
+  s = conv_shape(fh2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
+  conv_sf_dispatch(s, fh2_.wscale,
+                   SfFlowDelta{fh2_.b, coords1_.p, flow4_.p, x_.p, XLD, (long)N * XLD, 254, W8, (long)N}, st);
+  mark(ST_FLOWHEAD, st);
+}
+
+void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
+  float* f;
+  run_encoder_sf(fnet_, true, 2 * B, st, &f);
+  ConvShape s = conv_shape(fnet_.head, f, 128, (long)N * 128, 2 * B, H8, W8, 1, 0, 0);
+  conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fmap_.p, (long)N * 256, 256}, st);
+  mark(ST_FNET, st);
+
+  ConvShape c;
+  c.src0 = fmap_.p; c.ld0 = 256; c.sb0 = (long)N * 256; c.C0 = 256; c.H = 1; c.W = N;
+  c.w = fmap_.p + (long)B * N * 256; c.wb = (long)N * 256; c.ldw = 256; c.N = N; c.nimg = B;
+  conv_sf_dispatch(c, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[0].p, (long)N * N, N}, st);
+  mark(ST_CORR, st);
+  for (int l = 1; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
+  mark(ST_POOL, st);
+
+  run_encoder_sf(cnet_, false, B, st, &f);
+  s = conv_shape(cnet_.head, f, 128, (long)N * 128, B, H8, W8, 1, 0, 0);
+  conv_sf_dispatch(s, cnet_.head.wscale,
+                   SfContextSplit{cnet_.head.b, h_[0].p, (long)N * 128, x_.p, (long)N * XLD, XLD}, st);
+  mark(ST_CNET, st);
+
+  s = conv_shape(to_qk_, x_.p, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
+  conv_sf_dispatch(s, to_qk_.wscale, SfQK{1.0f / sqrtf(128.0f), 128, qk_.p, (long)N * 256, 256}, st);
+  ConvShape q;
+  q.src0 = qk_.p; q.ld0 = 256; q.sb0 = (long)N * 256; q.C0 = 128; q.H = 1; q.W = N;
+  q.w = qk_.p + 128; q.wb = (long)N * 256; q.ldw = 256; q.N = N; q.nimg = B;
+  conv_sf_dispatch(q, 1.f, EpiScale{1.0f, sim_.p, (long)N * ldN, ldN}, st);
+  launch_softmax_rows_sf(sim_.p, attn_.p, (long)B * N, N, ldN, st);
+  mark(ST_ATTN, st);
+
+  for (int it = 0; it < iters; ++it) iteration_sf(B, st);
+
+  s = conv_shape(mask0_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  conv_sf_dispatch(s, mask0_.wscale, SfBias<ACT_RELU>{mask0_.b, fh_.p, (long)N * 256, 256}, st);
+  s = conv_shape(mask2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 0, 0);
+  conv_sf_dispatch(s, mask2_.wscale, EpiBias<ACT_NONE>{mask2_.b, mask_.p, (long)N * 576, 576, 0.25f}, st);
+  mark(ST_MASK, st);
+}
+
 void GmaNet::capture(int B, int iters) {
   hipGraph_t graph = nullptr;
   ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
   try {
-    run_body(B, iters, cap_stream_);
+    if (precision == 1) run_body_sf(B, iters, cap_stream_); else run_body(B, iters, cap_stream_);
   } catch (...) {
     (void)hipStreamEndCapture(cap_stream_, &graph);
     if (graph) (void)hipGraphDestroy(graph);
@@ -373,13 +545,14 @@ void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const
   ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
   ATDN_CHECK(im1 && im2 && flow_low && flow_up, "null tensor");
   launch_prep_images(im1, im2, B, H, W, img4_.p, st);
-  launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
+  if (precision == 1) launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
+  else launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
   if (use_graph_) {
     auto key = std::make_pair(B, iters);
     if (!graphs_.count(key)) capture(B, iters);
     ATDN_HIP(hipGraphLaunch(graphs_[key], st));
   } else {
-    run_body(B, iters, st);
+    if (precision == 1) run_body_sf(B, iters, st); else run_body(B, iters, st);
   }
   launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
 }
@@ -394,8 +567,15 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
   else if (k == "qk") b = &qk_; else if (k == "img4") b = &img4_;
   if (!b) return -1;
   const long n = std::min(capacity, b->n);
+  const bool is_sf = precision == 1 && (k == "fmap" || k == "net" || k == "x" || k == "attn" || k == "corrfeat" || k == "qk");
+  const float* src = b->p;
+  if (is_sf) {  // decode the split-f16 tensor into a scratch fp32 copy first
+    if (scratch_.n < b->n) { scratch_.release(); scratch_.alloc(b->n); }
+    launch_from_sf(b->p, scratch_.p, b->n / 32, 32, st);
+    src = scratch_.p;
+  }
   ATDN_HIP(hipStreamSynchronize(st));
-  ATDN_HIP(hipMemcpy(host, b->p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  ATDN_HIP(hipMemcpy(host, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   return n;
 }
 

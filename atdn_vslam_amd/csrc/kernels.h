@@ -51,6 +51,25 @@ void launch_lstm_cell(const float* gates, float* c, float* h, int B, int Hd, hip
 struct MlpHead { const float *w0, *b0, *w1, *b1, *w2; };
 void launch_mlp_heads(const float* h2, int B, MlpHead rot, MlpHead tr, float* rot_out, float* tr_out, hipStream_t st);
 
+// ---- split-f16 ("sf", sf.h) variants used by the 3xf16 MFMA pipeline
+// fp32 NHWC [rows][C] (C % 32 == 0) -> sf
+void launch_to_sf(const float* src, float* dst, long rows, int C, hipStream_t st);
+// sf -> fp32 NHWC
+void launch_from_sf(const float* src, float* dst, long rows, int C, hipStream_t st);
+// InstanceNorm apply, out of place: raw fp32 x -> sf y = relu((x-mean)*rstd); optional residual (sf `res`, or raw fp32
+// `res_raw` normalised with rmean/rrstd): y = relu(r + y)
+void launch_in_apply_sf(const float* x, float* y, const float* mean, const float* rstd, const float* res,
+                        const float* res_raw, const float* rmean, const float* rrstd, int nimg, long HW, int C,
+                        hipStream_t st);
+// lookup with sf output rows (ldo = 352: 324 samples + zero pad, 11 channel groups)
+void launch_lookup_sf(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
+                      hipStream_t st);
+// row softmax, fp32 logits [rows][ld] -> sf probabilities [rows][ld] (pad columns zero); ld % 32 == 0
+void launch_softmax_rows_sf(const float* x, float* y, long rows, int n, int ld, hipStream_t st);
+// as launch_init_coords, x flow channels written in sf at channels cflow, cflow+1 of the sf GRU input
+void launch_init_coords_sf(const float* flow_init, int B, int H8, int W8, float* coords1, float* flow4, float* x,
+                           int ldx, int cflow, hipStream_t st);
+
 void launch_fill(float* p, long n, float v, hipStream_t st);
 
 }  // namespace atdn

@@ -445,3 +445,227 @@ void launch_fill(float* p, long n, float v, hipStream_t st) {
 }
 
 }  // namespace atdn
+
+// ================================================================== split-f16 ("sf") variants
+#include "sf.h"
+namespace atdn {
+
+// one thread = 4 consecutive channels of one pixel: 16-B fp32 read, two 8-B half stores (hi plane, lo plane)
+__device__ __forceinline__ void sf_store4(float* dst, long i4, float4 v) {
+  // i4 = index of the float4 inside the fp32 tensor; group = i4 / 8, slot = i4 % 8 (4 channels each)
+  const long grp = i4 >> 3;
+  const int sl = (int)(i4 & 7);
+  _Float16* g = reinterpret_cast<_Float16*>(dst + grp * 32) + sl * 4;
+  const SfPair a = sf_split(v.x), b = sf_split(v.y), c = sf_split(v.z), d = sf_split(v.w);
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  h4 hi = {a.hi, b.hi, c.hi, d.hi};
+  h4 lo = {a.lo, b.lo, c.lo, d.lo};
+  *reinterpret_cast<h4*>(g) = hi;
+  *reinterpret_cast<h4*>(g + 32) = lo;
+}
+__device__ __forceinline__ float4 sf_load4(const float* src, long i4) {
+  const long grp = i4 >> 3;
+  const int sl = (int)(i4 & 7);
+  const _Float16* g = reinterpret_cast<const _Float16*>(src + grp * 32) + sl * 4;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 hi = *reinterpret_cast<const h4*>(g);
+  const h4 lo = *reinterpret_cast<const h4*>(g + 32);
+  return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2],
+                     (float)hi[3] + (float)lo[3]);
+}
+
+__global__ void to_sf_kernel(const float4* __restrict__ src, float* __restrict__ dst, long total4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x)
+    sf_store4(dst, i, src[i]);
+}
+void launch_to_sf(const float* src, float* dst, long rows, int C, hipStream_t st) {
+  ATDN_CHECK(C % 32 == 0, "sf tensors need C % 32 == 0");
+  const long total4 = rows * C / 4;
+  hipLaunchKernelGGL(to_sf_kernel, dim3((unsigned)std::min<long>(cdivl(total4, 256), 4096)), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(src), dst, total4);
+  ATDN_HIP(hipGetLastError());
+}
+__global__ void from_sf_kernel(const float* __restrict__ src, float4* __restrict__ dst, long total4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x)
+    dst[i] = sf_load4(src, i);
+}
+void launch_from_sf(const float* src, float* dst, long rows, int C, hipStream_t st) {
+  ATDN_CHECK(C % 32 == 0, "sf tensors need C % 32 == 0");
+  const long total4 = rows * C / 4;
+  hipLaunchKernelGGL(from_sf_kernel, dim3((unsigned)std::min<long>(cdivl(total4, 256), 4096)), dim3(256), 0, st, src,
+                     reinterpret_cast<float4*>(dst), total4);
+  ATDN_HIP(hipGetLastError());
+}
+
+__global__ void in_apply_sf_kernel(const float4* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
+                                   const float* __restrict__ rstd, const float* __restrict__ res,
+                                   const float4* __restrict__ res_raw, const float* __restrict__ rmean,
+                                   const float* __restrict__ rrstd, long per_img4, int C, long total4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long img = i / per_img4;
+    const int c = (int)((i * 4) % C);
+    const float* mu = mean + img * C + c;
+    const float* rs = rstd + img * C + c;
+    float4 v = x[i];
+    v.x = fmaxf((v.x - mu[0]) * rs[0], 0.f);
+    v.y = fmaxf((v.y - mu[1]) * rs[1], 0.f);
+    v.z = fmaxf((v.z - mu[2]) * rs[2], 0.f);
+    v.w = fmaxf((v.w - mu[3]) * rs[3], 0.f);
+    if (res || res_raw) {
+      float4 r;
+      if (res) {
+        r = sf_load4(res, i);
+      } else {
+        r = res_raw[i];
+        const float* m2 = rmean + img * C + c;
+        const float* r2 = rrstd + img * C + c;
+        r.x = (r.x - m2[0]) * r2[0]; r.y = (r.y - m2[1]) * r2[1];
+        r.z = (r.z - m2[2]) * r2[2]; r.w = (r.w - m2[3]) * r2[3];
+      }
+      v.x = fmaxf(r.x + v.x, 0.f); v.y = fmaxf(r.y + v.y, 0.f);
+      v.z = fmaxf(r.z + v.z, 0.f); v.w = fmaxf(r.w + v.w, 0.f);
+    }
+    sf_store4(y, i, v);
+  }
+}
+void launch_in_apply_sf(const float* x, float* y, const float* mean, const float* rstd, const float* res,
+                        const float* res_raw, const float* rmean, const float* rrstd, int nimg, long HW, int C,
+                        hipStream_t st) {
+  ATDN_CHECK(C % 32 == 0, "sf tensors need C % 32 == 0");
+  const long per_img4 = HW * C / 4, total4 = per_img4 * nimg;
+  const int grid = (int)std::min<long>(cdivl(total4, 256), 256 * 16);
+  hipLaunchKernelGGL(in_apply_sf_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(x), y, mean,
+                     rstd, res, reinterpret_cast<const float4*>(res_raw), rmean, rrstd, per_img4, C, total4);
+  ATDN_HIP(hipGetLastError());
+}
+
+// Lookup with the sample arithmetic of lookup_kernel; the 4 waves (levels) of a block stage the pixel's 324
+// samples in LDS and the block stores the 352-channel sf row (11 groups of [32 hi | 32 lo]) as dwords.
+__global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr, const float* __restrict__ coords1,
+                                                        long npix, float* __restrict__ out, int ldo) {
+  __shared__ float win[4][LK_WIN * LK_WIN + 16];
+  __shared__ float vals[352];
+  const int lvl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Hl = pyr.H[lvl], Wl = pyr.W[lvl];
+  const float inv = 1.0f / (float)(1 << lvl);
+  const float wm1 = (float)(Wl - 1), hm1 = (float)(Hl - 1);
+  const float sfx = wm1 / 2.f, sfy = hm1 / 2.f;
+  float* w = win[lvl];
+  if (threadIdx.x >= 324 - 256 && threadIdx.x < 352 - 256) vals[256 + threadIdx.x] = 0.f;  // pad channels 324..351
+  for (long p = blockIdx.x; p < npix; p += gridDim.x) {
+    const float xc = coords1[p * 2 + 0] * inv, yc = coords1[p * 2 + 1] * inv;
+    const bool sane = (fabsf(xc) < 1.0e6f) && (fabsf(yc) < 1.0e6f);
+    const int wx0 = sane ? (int)floorf(xc) - 5 : -(1 << 24), wy0 = sane ? (int)floorf(yc) - 5 : -(1 << 24);
+    const float* src = pyr.base[lvl] + p * ((long)Hl * Wl);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int c = lane + 64 * t;
+      if (c < LK_WIN * LK_WIN) {
+        const int wy = c / LK_WIN, wx = c - wy * LK_WIN;
+        const int y = wy0 + wy, x = wx0 + wx;
+        const bool ok = ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
+        w[c] = ok ? src[(long)y * Wl + x] : 0.f;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = lane + 64 * t;
+      if (k < 81) {
+        const int i = k / 9, j = k - i * 9;
+        float v = 0.f;
+        if (sane) {
+          const float px = xc + (float)(i - 4), py = yc + (float)(j - 4);
+          const float xg = 2.f * px / wm1 - 1.f, yg = 2.f * py / hm1 - 1.f;
+          const float ix = (xg + 1.f) * sfx, iy = (yg + 1.f) * sfy;
+          const float xw = floorf(ix), yn = floorf(iy);
+          const float ww = ix - xw, ee = 1.f - ww, nn = iy - yn, ss = 1.f - nn;
+          const int lx = min(max((int)xw - wx0, 0), LK_WIN - 2), ly = min(max((int)yn - wy0, 0), LK_WIN - 2);
+          const float* q = w + ly * LK_WIN + lx;
+          v = ((q[0] * (ee * ss) + q[1] * (ww * ss)) + q[LK_WIN] * (ee * nn)) + q[LK_WIN + 1] * (ww * nn);
+        }
+        vals[lvl * 81 + k] = v;
+      }
+    }
+    __syncthreads();
+    // 352 dwords per row: dword d -> group d/32, word w = d%32: w<16 -> hi halves of channels 2w,2w+1; else lo halves
+    unsigned* orow = reinterpret_cast<unsigned*>(out + p * ldo);
+    for (int d = threadIdx.x; d < 352; d += 256) {
+      const int g = d >> 5, ww = d & 31;
+      const int c = g * 32 + 2 * (ww & 15);
+      const SfPair a = sf_split(vals[c]), b = sf_split(vals[c + 1]);
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      h2 o;
+      if (ww < 16) { o[0] = a.hi; o[1] = b.hi; } else { o[0] = a.lo; o[1] = b.lo; }
+      orow[d] = *reinterpret_cast<unsigned*>(&o);
+    }
+    __syncthreads();
+  }
+}
+void launch_lookup_sf(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
+                      hipStream_t st) {
+  ATDN_CHECK(ldo == 352, "sf lookup rows are 352 channels (11 groups)");
+  const int grid = (int)std::min<long>(npix_total, 256 * 16);
+  hipLaunchKernelGGL(lookup_sf_kernel, dim3(grid), dim3(256), 0, st, pyr, coords1, npix_total, out, ldo);
+  ATDN_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_sf_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+                                                              int ld) {
+  __shared__ float sm[4];
+  const float* row = x + (long)blockIdx.x * ld;
+  float* orow = y + (long)blockIdx.x * ld;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, row[i]);
+  mx = block_reduce<true>(mx, sm);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += expf(row[i] - mx);
+  s = block_reduce<false>(s, sm);
+  // pairs of adjacent columns -> one dword in the hi plane and one in the lo plane
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  for (int i2 = threadIdx.x; i2 < ld / 2; i2 += 256) {
+    const int c = 2 * i2;
+    const float a = (c < n) ? expf(row[c] - mx) / s : 0.f;
+    const float b = (c + 1 < n) ? expf(row[c + 1] - mx) / s : 0.f;
+    const SfPair pa = sf_split(a), pb = sf_split(b);
+    _Float16* q = sf_ptr(orow, 0, c);
+    h2 hi = {pa.hi, pb.hi}, lo = {pa.lo, pb.lo};
+    *reinterpret_cast<h2*>(q) = hi;
+    *reinterpret_cast<h2*>(q + 32) = lo;
+  }
+}
+void launch_softmax_rows_sf(const float* x, float* y, long rows, int n, int ld, hipStream_t st) {
+  ATDN_CHECK(ld % 32 == 0, "sf rows need ld % 32 == 0");
+  hipLaunchKernelGGL(softmax_rows_sf_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, y, n, ld);
+  ATDN_HIP(hipGetLastError());
+}
+
+__global__ void init_coords_sf_kernel(const float* __restrict__ flow_init, int B, int H8, int W8,
+                                      float* __restrict__ coords1, float* __restrict__ flow4, float* __restrict__ x,
+                                      int ldx, int cflow) {
+  const long N = (long)H8 * W8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N) return;
+  const long img = i / N;
+  const int m = (int)(i - img * N);
+  const float x0 = (float)(m % W8), y0 = (float)(m / W8);
+  float fx = 0.f, fy = 0.f;
+  if (flow_init) { fx = flow_init[(img * 2 + 0) * N + m]; fy = flow_init[(img * 2 + 1) * N + m]; }
+  const float cx = x0 + fx, cy = y0 + fy;
+  coords1[i * 2 + 0] = cx;
+  coords1[i * 2 + 1] = cy;
+  const float flx = cx - x0, fly = cy - y0;
+  reinterpret_cast<float4*>(flow4)[i] = make_float4(flx, fly, 0.f, 0.f);
+  sf_store(x, i * ldx, cflow, flx);
+  sf_store(x, i * ldx, cflow + 1, fly);
+}
+void launch_init_coords_sf(const float* flow_init, int B, int H8, int W8, float* coords1, float* flow4, float* x,
+                           int ldx, int cflow, hipStream_t st) {
+  const long n = (long)B * H8 * W8;
+  hipLaunchKernelGGL(init_coords_sf_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, flow_init, B, H8, W8,
+                     coords1, flow4, x, ldx, cflow);
+  ATDN_HIP(hipGetLastError());
+}
+
+}  // namespace atdn

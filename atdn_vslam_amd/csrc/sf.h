@@ -1,0 +1,44 @@
+// "sf" — split-f16 storage of fp32 activations/weights for the 3xf16 MFMA engine.
+//
+// x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 significant bits, the same 4 bytes per element as fp32.
+// Channels are stored in groups of 32: one group = 128 bytes = [32 x hi | 32 x lo], so a K-chunk of the
+// implicit GEMM is still one contiguous 128-byte run per pixel and `ld`/channel offsets keep their fp32
+// meaning (units of 4 bytes, channel offsets multiples of 32).
+// Range: |x| <= 65504 (clamped). Below |x| ~ 0.06 the residual is an f16 subnormal and the absolute
+// representation error floors at 3e-8 — fp32-epsilon of O(1) data, which is what flows through this network.
+#pragma once
+#include "common.h"
+
+namespace atdn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct SfPair { _Float16 hi, lo; };
+
+__device__ __forceinline__ SfPair sf_split(float v) {
+  v = fminf(fmaxf(v, -65504.f), 65504.f);
+  SfPair p;
+  p.hi = (_Float16)v;
+  p.lo = (_Float16)(v - (float)p.hi);
+  return p;
+}
+
+// element (pixel offset `off` in 4-byte units, channel c) of an sf tensor
+__device__ __forceinline__ _Float16* sf_ptr(float* base, long off, int c) {
+  return reinterpret_cast<_Float16*>(base + off + (c & ~31)) + (c & 31);
+}
+__device__ __forceinline__ const _Float16* sf_ptr(const float* base, long off, int c) {
+  return reinterpret_cast<const _Float16*>(base + off + (c & ~31)) + (c & 31);
+}
+__device__ __forceinline__ void sf_store(float* base, long off, int c, float v) {
+  const SfPair p = sf_split(v);
+  _Float16* q = sf_ptr(base, off, c);
+  q[0] = p.hi;
+  q[32] = p.lo;
+}
+__device__ __forceinline__ float sf_load(const float* base, long off, int c) {
+  const _Float16* q = sf_ptr(base, off, c);
+  return (float)q[0] + (float)q[32];
+}
+
+}  // namespace atdn

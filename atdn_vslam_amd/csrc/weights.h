@@ -44,6 +44,7 @@ struct PackedConv {
   long w_off = -1, b_off = -1;
   int N = 0, ldw = 0, KH = 1, KW = 1, C = 0;  // C = (padded) channels per pixel the kernel will see
   int mode = MODE_TAP;
+  float wscale = 1.f;  // sf packing: accumulator multiplier (power of two)
   const float* w = nullptr;
   const float* b = nullptr;
 };
@@ -125,6 +126,36 @@ inline PackedConv pack_conv(WeightArena& A, const StateDict& sd, const std::vect
       A.at(L.b_off)[n0 + n] = (float)bv;
     }
     n0 += Co;
+  }
+  return L;
+}
+
+// Same as pack_conv(TAP) but in split-f16 form (sf.h): every 32-float K-chunk of a row becomes [32 hi | 32 lo]
+// halves; all weights of the layer are pre-multiplied by 2^p so that max|w| lands in [1,2) and L.wscale = 2^-p.
+inline PackedConv pack_conv_sf(WeightArena& A, const StateDict& sd, const std::vector<std::string>& names,
+                               const ChannelAffine* fold = nullptr, bool has_bias = true) {
+  PackedConv L = pack_conv(A, sd, names, MODE_TAP, 0, fold, has_bias);  // fp32 rows first (BN already folded)
+  float* w = A.at(L.w_off);
+  const long total = (long)L.N * L.ldw;
+  float mx = 0.f;
+  for (long i = 0; i < total; ++i) mx = std::max(mx, std::fabs(w[i]));
+  int e = 0;
+  if (mx > 0.f) (void)std::frexp(mx, &e);  // mx = f * 2^e, f in [0.5,1)
+  const int p = 1 - e;                      // w * 2^p has its maximum in [1,2)
+  L.wscale = std::ldexp(1.0f, -p);
+  std::vector<float> row(L.ldw);
+  for (int n = 0; n < L.N; ++n) {
+    float* r = w + (long)n * L.ldw;
+    std::memcpy(row.data(), r, L.ldw * sizeof(float));
+    _Float16* hrow = reinterpret_cast<_Float16*>(r);
+    for (int q = 0; q < L.ldw / 32; ++q)
+      for (int j = 0; j < 32; ++j) {
+        const float v = std::ldexp(row[q * 32 + j], p);
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        hrow[q * 64 + j] = hi;
+        hrow[q * 64 + 32 + j] = lo;
+      }
   }
   return L;
 }

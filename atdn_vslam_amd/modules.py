@@ -10,6 +10,7 @@ checkpoints load) and run every forward through libatdn_hip's C ABI. PyTorch
 only supplies device memory and the stream.
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -90,9 +91,14 @@ class RAFTGMA(_NativeModule):
     """GMA optical flow; `args` is the reference's GMA_Parameters-like object (only
     `num_heads`, `position_only`, `position_and_content` are consulted)."""
 
-    def __init__(self, args=None, max_batch=1):
+    PRECISIONS = {"f32": 0, "split_f16": 1}
+
+    def __init__(self, args=None, max_batch=1, precision=None):
         super().__init__()
         self.args = args
+        self.precision = precision or os.environ.get("ATDN_PRECISION", "split_f16")
+        if self.precision not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
         self.hidden_dim = 128
         self.context_dim = 128
         if args is not None:
@@ -118,7 +124,7 @@ class RAFTGMA(_NativeModule):
             L = _lib.lib()
             h = C.c_void_p()
             mb = max(B, self.max_batch)
-            _lib.check(L.atdn_gma_create(C.byref(h), H, W, mb))
+            _lib.check(L.atdn_gma_create(C.byref(h), H, W, mb, self.PRECISIONS[self.precision]))
             _lib.load_state(L.atdn_gma_load, h, self.state_dict())
             _lib.check(L.atdn_gma_finalize(h))
             ent = (h, fp, L.atdn_gma_destroy, mb)

@@ -31,8 +31,13 @@ const char* atdn_last_error(void);
  * ------------------------------------------------------------------------------------------------- */
 
 /* H, W: frame size after the caller's resize/pad (multiples of 8; 376x1232 in NeuralSLAM,
- * neural_slam.py:54,198-199). max_batch: largest number of frame pairs per forward. */
-int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch);
+ * neural_slam.py:54,198-199). max_batch: largest number of frame pairs per forward.
+ * precision: ATDN_PRECISION_F32 = every GEMM on the exact-fp32 matrix core (v_mfma_f32_32x32x2_f32);
+ *            ATDN_PRECISION_SPLIT_F16 = every channel-wide GEMM as three f16 MFMAs on split operands
+ *            (x = hi + lo, fp32 accumulate): fp32-grade results at 5.3x the matrix rate. */
+#define ATDN_PRECISION_F32 0
+#define ATDN_PRECISION_SPLIT_F16 1
+int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch, int precision);
 
 /* One state-dict entry (load_state_dict, neural_slam.py:52). `key` as in the checkpoint, with or without the
  * DataParallel "module." prefix; `data` is a HOST fp32 buffer of the given shape. Non-float buffers
@@ -115,6 +120,12 @@ int atdn_corr_pyramid(const float* fmap1, const float* fmap2, int B, int H8, int
 int atdn_conv2d_nhwc(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
                      const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, int relu,
                      float* dst, void* stream);
+
+/* The same convolution through the split-f16 engine (three f16 MFMAs per product, fp32-grade result):
+ * src fp32 NHWC (converted internally to the sf format), Cin % 32 == 0, fp32 NHWC output. */
+int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
+                        const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, float* dst,
+                        void* stream);
 
 #ifdef __cplusplus
 }

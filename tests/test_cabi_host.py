@@ -65,7 +65,7 @@ def test_padder_matches_reference(golden_dir):
 def test_argument_errors_are_reported():
     L = _lib.lib()
     h = C.c_void_p()
-    assert L.atdn_gma_create(C.byref(h), 375, 1232, 1) != 0  # not a multiple of 8
+    assert L.atdn_gma_create(C.byref(h), 375, 1232, 1, 0) != 0  # not a multiple of 8
     assert b"multiple of 8" in L.atdn_last_error()
     assert L.atdn_clvo_create(C.byref(h), 160, 512, 1) != 0  # cannot reduce to 16x4x13
     assert b"16x4x13" in L.atdn_last_error()

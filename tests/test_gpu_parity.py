@@ -83,6 +83,25 @@ def test_conv_engine_matches_torch(case):
     assert _maxerr(got, ref) < 2e-5, _maxerr(got, ref)
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] % 32 == 0])
+def test_split_f16_engine_matches_fp64(case):
+    """3 x f16 MFMA on split operands must be fp32-grade: compared with an fp64 convolution."""
+    cin, cout, kh, kw, stride, ph, pw, H, W, nimg, _ = case
+    r = np.random.RandomState(hash(case) & 0xFFFF)
+    x = torch.from_numpy(r.normal(0, 1, (nimg, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((r.uniform(-1, 1, (cout, cin, kh, kw)) * np.sqrt(3.0 / (cin * kh * kw))).astype(np.float32))
+    b = torch.from_numpy(r.uniform(-0.5, 0.5, (cout,)).astype(np.float32))
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=(ph, pw))
+    xd = _nhwc(x).to(DEV)
+    out = torch.full((nimg, ref.shape[2], ref.shape[3], cout), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.check(_lib.lib().atdn_conv2d_nhwc_sf(_vp(xd), nimg, H, W, cin, _vp(w), _vp(b), cout, kh, kw, stride, ph, pw,
+                                              _vp(out), _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert _maxerr(got, ref) < 2e-5, _maxerr(got, ref)
+
+
 def test_conv_engine_rejects_bad_shapes():
     x = torch.zeros(1, 8, 8, 24, device=DEV)
     w = torch.zeros(8, 24, 3, 3)
@@ -159,9 +178,10 @@ def gsd():
     return syn.to_torch(syn.make_gma_state(seed=1))
 
 
-@pytest.fixture(scope="module")
-def flow_net(gsd):
-    m = RAFTGMA(max_batch=2)
+@pytest.fixture(scope="module", params=["split_f16", "f32"])
+def flow_net(gsd, request):
+    """Both arithmetic modes of the engine: three f16 MFMAs on split operands (default) and exact-fp32 MFMA."""
+    m = RAFTGMA(max_batch=2, precision=request.param)
     m.load_state_dict({"module." + k: v for k, v in gsd.items()})  # DataParallel-style checkpoint
     return m.to(DEV).eval()
 
