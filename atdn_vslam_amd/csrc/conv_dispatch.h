@@ -6,7 +6,11 @@
 
 namespace atdn {
 
-struct TileChoice { int BM, BN; };
+struct TileChoice {
+  int BM, BN;
+  int groups_per_img = 0;  // InstanceNorm statistics groups per image written by a kStats epilogue
+  bool counted = false;    // true: groups are 2-D tile quarters and part_cnt holds their sizes
+};
 
 // Deterministic: depends only on the problem shape (graph capture + InstanceNorm group bookkeeping rely on it).
 inline TileChoice choose_tile(int nimg, int HoWo, int N) {

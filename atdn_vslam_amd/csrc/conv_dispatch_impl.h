@@ -11,8 +11,9 @@ inline void set_groups(EpiBiasStats& ep, int groups) { ep.groups_per_img = group
 template <int MODE, class Epi>
 TileChoice conv_dispatch(const ConvShape& s, Epi ep, hipStream_t st) {
   const int Ho = conv_out(s.H, s.KH, s.stride, s.padH), Wo = conv_out(s.W, s.KW, s.stride, s.padW);
-  const TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);
-  set_groups(ep, cdiv(Ho * Wo, t.BM) * (t.BM / 32));
+  TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);
+  t.groups_per_img = cdiv(Ho * Wo, t.BM) * (t.BM / 32);
+  set_groups(ep, t.groups_per_img);
   if (t.BM == 128 && t.BN == 128) launch_conv<MODE, 2, 2, 2, 2>(s, ep, st);
   else if (t.BM == 128 && t.BN == 64) launch_conv<MODE, 2, 1, 2, 2>(s, ep, st);
   else if (t.BM == 128 && t.BN == 96) launch_conv<MODE, 1, 3, 4, 1>(s, ep, st);

@@ -1,0 +1,252 @@
+// Split-f16 implicit-GEMM convolution, generation 2: spatially blocked with an LDS-resident halo patch.
+//
+// conv_sf.h re-reads every A row once per filter tap (9x for a 3x3), which makes the f16 matrix pipe wait on
+// L2. Here an M tile is a TH x TW block of OUTPUT pixels of one image (TH*TW = 128); per 32-channel chunk the
+// (TH+KH-1) x (TW+KW-1) input patch (true zero padding included) is staged in LDS ONCE and all KH*KW taps are
+// served from it by offsetting the fragment address — A traffic drops by ~KH*KW/1.4. Weight tiles [BN][32-chunk]
+// stream per (chunk, tap) through a double-buffered LDS image with a register prefetch: one barrier per tap,
+// two at a chunk boundary. Stride-1 TAP-mode convolutions only (everything at 1/8 resolution and the stride-1
+// encoder convs); 1x1 / strided / GEMM shapes stay on conv_sf_kernel.
+#pragma once
+#include "conv_sf.h"
+
+namespace atdn {
+
+struct Conv2Geom {
+  const float* src0; const float* src1;
+  long sb0, sb1;
+  int ld0, ld1, C0, C1;
+  int H, W, Ho, Wo;
+  int KH, KW, padH, padW;
+  int PH, PW;            // patch size in pixels
+  int tiles_x, tiles_y;  // per image
+  int nimg, ntile_n;
+  const float* w; int ldw; int N;
+  float wscale;
+};
+
+constexpr int C2_PATCH_MAX = 192;  // pixels: 8x16 tile with 3x3 (180), 1x5 (160), 5x1 (192)
+
+template <int TH, int TW, int TN, class Epi>
+__global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const Epi ep) {
+  static_assert(TH * TW == 128, "M tile is 128 output pixels");
+  constexpr int BN = 64 * TN;
+  constexpr int RB = BN / 32;                    // weight float4 per thread per step
+  constexpr int NP = (C2_PATCH_MAX * 8 + 255) / 256;  // patch float4 per thread per chunk
+  constexpr int ROWB = LDS_LD * 4;
+  __shared__ __attribute__((aligned(16))) float lds[(C2_PATCH_MAX + 2 * BN) * LDS_LD];
+  float* Ps = lds;
+  float* Ws = lds + C2_PATCH_MAX * LDS_LD;
+
+  const int tid = threadIdx.x;
+  const int tiles_img = g.tiles_x * g.tiles_y;
+  const int nblk = g.nimg * tiles_img * g.ntile_n;
+  const int id = xcd_remap(blockIdx.x, nblk);
+  const int tile_n = id % g.ntile_n;
+  const int tmg = id / g.ntile_n;
+  const int img = tmg / tiles_img;
+  const int tloc = tmg - img * tiles_img;
+  const int ty0 = (tloc / g.tiles_x) * TH, tx0 = (tloc % g.tiles_x) * TW;
+  const int n0 = tile_n * BN;
+  const int npatch = g.PH * g.PW;
+
+  // ---- loader roles
+  const int s = tid & 7, r0 = tid >> 3;
+  int poff[NP];  // input pixel index of this thread's patch rows, -1 = zero padding / unused
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int prow = r0 + 32 * k;
+    int off = -1;
+    if (prow < npatch) {
+      const int py = prow / g.PW, px = prow - py * g.PW;
+      const int iy = ty0 - g.padH + py, ix = tx0 - g.padW + px;
+      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) off = iy * g.W + ix;
+    }
+    poff[k] = off;
+  }
+  const float* wrow[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int n = n0 + r0 + 32 * j;
+    wrow[j] = (n < g.N) ? (g.w + (long)n * g.ldw + 4 * s) : nullptr;
+  }
+  const float* s0 = g.src0 + (long)img * g.sb0;
+  const float* s1 = g.src1 ? g.src1 + (long)img * g.sb1 : nullptr;
+  const int nck = (g.C0 + g.C1) >> 5, ntap = g.KH * g.KW;
+  const int nstep = nck * ntap;
+
+  float4 pr[NP], wr[RB];
+  auto fetch_patch = [&](int c) {
+    const int cc = c << 5;
+    const float* sp; int ld, co;
+    if (cc < g.C0) { sp = s0; ld = g.ld0; co = cc; } else { sp = s1; ld = g.ld1; co = cc - g.C0; }
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      pr[k] = (poff[k] >= 0) ? *reinterpret_cast<const float4*>(sp + (long)poff[k] * ld + co + 4 * s)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto fetch_w = [&](int c, int tap) {
+    const int q = tap * nck + c;  // packed K order is [tap][channel chunk]
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      wr[j] = wrow[j] ? *reinterpret_cast<const float4*>(wrow[j] + q * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      if (r0 + 32 * k < C2_PATCH_MAX) *reinterpret_cast<float4*>(Ps + (r0 + 32 * k) * LDS_LD + 4 * s) = pr[k];
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(Ws + (buf * BN + r0 + 32 * j) * LDS_LD + 4 * s) = wr[j];
+  };
+
+  // ---- MFMA roles: wave grid 2 x 2, each wave 2 x TN tiles of 32x32
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  int a_off[2];  // byte offset of this lane's A row inside the patch for tap (0,0)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = (wm * 2 + i) * 32 + r;
+    a_off[i] = ((p / TW) * g.PW + (p % TW)) * ROWB + 16 * h;
+  }
+  const char* Pb = reinterpret_cast<const char*>(Ps);
+  const char* Wb = reinterpret_cast<const char*>(Ws) + (wn * TN * 32 + r) * ROWB + 16 * h;
+
+  fetch_patch(0);
+  fetch_w(0, 0);
+  store_patch();
+  store_w(0);
+  __syncthreads();
+  int c = 0, tap = 0, ky = 0, kx = 0;
+  for (int st = 0; st < nstep; ++st) {
+    // next step's coordinates
+    int c2 = c, tap2 = tap + 1;
+    if (tap2 == ntap) { tap2 = 0; c2 = c + 1; }
+    const bool more = st + 1 < nstep;
+    if (more) fetch_w(c2, tap2);
+    if (tap == 0 && c + 1 < nck) fetch_patch(c + 1);  // lands during this chunk's taps
+
+    const char* arow = Pb + (ky * g.PW + kx) * ROWB;
+    const char* brow = Wb + (st & 1) * BN * ROWB;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f16x8 ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t);
+        al[i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t + 64);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(brow + j * 32 * ROWB + 32 * t);
+        bl[j] = *reinterpret_cast<const f16x8*>(brow + j * 32 * ROWB + 32 * t + 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) {
+      if (tap2 == 0) {           // chunk boundary: the patch is replaced, every wave must be done reading it
+        __syncthreads();
+        store_patch();
+      }
+      store_w((st + 1) & 1);     // the other weight buffer was last read one step ago (barrier since then)
+      __syncthreads();
+    }
+    c = c2; tap = tap2;
+    if (++kx == g.KW) { kx = 0; if (++ky == g.KH) ky = 0; }
+  }
+
+  // ---- epilogue
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pbase = (wm * 2 + i) * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + r;
+      const bool nok = n < g.N;
+      int mm[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = pbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+        mm[e] = (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
+      }
+      if constexpr (Epi::kStats) {
+        const float bias = nok ? ep.bias[n] : 0.f;
+        float v[16];
+        float sum = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          v[e] = acc[i][j][e] * g.wscale + bias;
+          if (mm[e] >= 0) { sum += v[e]; ++cnt; }
+        }
+        sum += __shfl_xor(sum, 32);
+        cnt += __shfl_xor(cnt, 32);
+        const float mean = sum / (float)(cnt > 0 ? cnt : 1);
+        float m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (mm[e] >= 0) { const float d = v[e] - mean; m2 += d * d; }
+        m2 += __shfl_xor(m2, 32);
+        const int grp = tloc * 4 + wm * 2 + i;
+        if (h == 0 && nok) {
+          const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
+          ep.part_sum[o] = sum;
+          ep.part_m2[o] = m2;
+        }
+        if (lane == 0 && n == 0) ep.part_cnt[(long)img * ep.groups_per_img + grp] = (float)cnt;
+      }
+      if (nok) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (mm[e] >= 0) ep(img, mm[e], n, acc[i][j][e] * g.wscale);
+      }
+    }
+  }
+}
+
+// true if the shape can run on conv_sf2_kernel
+inline bool conv_sf2_eligible(const ConvShape& s) {
+  if (s.stride != 1 || s.KH * s.KW == 1 || s.wb != 0) return false;
+  const int PH = 8 + s.KH - 1, PW = 16 + s.KW - 1;
+  return PH * PW <= C2_PATCH_MAX;
+}
+
+template <int TN, class Epi>
+inline void launch_conv_sf2(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
+  constexpr int TH = 8, TW = 16;
+  Conv2Geom g{};
+  g.src0 = s.src0; g.src1 = s.src1; g.sb0 = s.sb0; g.sb1 = s.sb1; g.ld0 = s.ld0; g.ld1 = s.ld1;
+  g.C0 = s.C0; g.C1 = s.C1; g.H = s.H; g.W = s.W;
+  g.KH = s.KH; g.KW = s.KW; g.padH = s.padH; g.padW = s.padW;
+  g.Ho = conv_out(s.H, s.KH, 1, s.padH); g.Wo = conv_out(s.W, s.KW, 1, s.padW);
+  g.PH = TH + s.KH - 1; g.PW = TW + s.KW - 1;
+  ATDN_CHECK(conv_sf2_eligible(s), "shape not eligible for the halo-patch kernel");
+  ATDN_CHECK(s.C0 % 32 == 0 && s.C1 % 32 == 0 && s.C0 > 0 && s.ld0 % 4 == 0, "TAP-mode channel constraints");
+  ATDN_CHECK(s.ldw % 4 == 0 && s.ldw >= s.KH * s.KW * (s.C0 + s.C1), "weight rows too short");
+  g.tiles_x = cdiv(g.Wo, TW); g.tiles_y = cdiv(g.Ho, TH);
+  g.nimg = s.nimg; g.ntile_n = cdiv(s.N, 64 * TN);
+  g.w = s.w; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;
+  set_groups(ep, g.tiles_x * g.tiles_y * 4);
+  const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
+  hipLaunchKernelGGL((conv_sf2_kernel<TH, TW, TN, Epi>), dim3(nblk), dim3(256), 0, st, g, ep);
+  ATDN_HIP(hipGetLastError());
+}
+
+}  // namespace atdn

@@ -2,6 +2,7 @@
 #pragma once
 #include "conv_dispatch_impl.h"
 #include "conv_sf.h"
+#include "conv_sf2.h"
 #include "epilogues_sf.h"
 
 namespace atdn {
@@ -9,8 +10,18 @@ namespace atdn {
 template <class Epi>
 TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
   const int Ho = conv_out(s.H, s.KH, s.stride, s.padH), Wo = conv_out(s.W, s.KW, s.stride, s.padW);
-  const TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);
-  set_groups(ep, cdiv(Ho * Wo, t.BM) * (t.BM / 32));
+  static const bool use_v2 = !(getenv("ATDN_NO_HALO") && getenv("ATDN_NO_HALO")[0] == '1');
+  if (use_v2 && conv_sf2_eligible(s)) {
+    // halo-patch kernel: 8x16 output tiles; 128-wide N tiles once they still fill the chip
+    const int tiles = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
+    TileChoice t2{128, 64, cdiv(Wo, 16) * cdiv(Ho, 8) * 4, true};
+    if (s.N > 64 && (long)tiles * cdiv(s.N, 128) >= 400) { t2.BN = 128; launch_conv_sf2<2>(s, wscale, ep, st); }
+    else launch_conv_sf2<1>(s, wscale, ep, st);
+    return t2;
+  }
+  TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);
+  t.groups_per_img = cdiv(Ho * Wo, t.BM) * (t.BM / 32);
+  set_groups(ep, t.groups_per_img);
   if (t.BM == 128 && t.BN == 128) launch_conv_sf<2, 2, 2, 2>(s, wscale, ep, st);
   else if (t.BM == 128 && t.BN == 64) launch_conv_sf<2, 1, 2, 2>(s, wscale, ep, st);
   else if (t.BM == 128 && t.BN == 96) launch_conv_sf<1, 3, 4, 1>(s, wscale, ep, st);

@@ -27,6 +27,7 @@ struct EpiBiasStats {
   const float* bias;
   float* dst; long ob; int ld;
   float* part_sum; float* part_m2; int groups_per_img;
+  float* part_cnt = nullptr;  // valid rows per group (only the 2-D tiled kernel writes it)
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
     dst[(long)img * ob + (long)m * ld + n] = a + bias[n];
   }

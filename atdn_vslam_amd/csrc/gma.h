@@ -68,7 +68,7 @@ class GmaNet {
   long gamma_off_ = -1;
 
   // workspace
-  DeviceBuf img4_, enc_[4], sim_, scratch_, fmap_, psum_, pm2_, mean_[2], rstd_[2];
+  DeviceBuf img4_, enc_[4], sim_, scratch_, pcnt_, fmap_, psum_, pm2_, mean_[2], rstd_[2];
   DeviceBuf pyr_[4], h_[2], x_, qk_, attn_, vT_, corrfeat_, cor1_, corflo_, flo1_, z_, rh_, fh_, mask_;
   DeviceBuf coords1_, flow4_;
   int pyrH_[4], pyrW_[4];

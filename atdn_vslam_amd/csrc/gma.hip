@@ -131,7 +131,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
 GmaNet::~GmaNet() {
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_};
   for (auto* b : all) b->release();
@@ -182,7 +182,7 @@ void GmaNet::finalize() {
   if (sf) sim_.alloc((long)B * N * ldN);
   fmap_.alloc(2L * B * N * 256);
   const long groups = (long)cdiv(H2 * W2, 64) * 4 + 8;
-  psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128);
+  psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128); pcnt_.alloc(2L * B * groups);
   for (int i = 0; i < 2; ++i) { mean_[i].alloc(2L * B * 128); rstd_[i].alloc(2L * B * 128); }
   pyrH_[0] = H8; pyrW_[0] = W8;
   for (int l = 1; l < 4; ++l) { pyrH_[l] = pyrH_[l - 1] / 2; pyrW_[l] = pyrW_[l - 1] / 2; }
@@ -380,11 +380,15 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
                       int slot) {
     ConvShape s = conv_shape(L, src, ld, (long)ih * iw * ld, nimg, ih, iw, stride, pad, pad);
     const int oh = conv_out(ih, L.KH, stride, pad), ow = conv_out(iw, L.KW, stride, pad);
-    EpiBiasStats ep{L.b, dst, (long)oh * ow * L.N, L.N, psum_.p, pm2_.p, 0};
+    EpiBiasStats ep{L.b, dst, (long)oh * ow * L.N, L.N, psum_.p, pm2_.p, 0, pcnt_.p};
     TileChoice t = conv_sf_dispatch(s, L.wscale, ep, st);
-    const int groups = cdiv(oh * ow, t.BM) * (t.BM / 32);
-    ATDN_CHECK((long)nimg * groups * L.N <= psum_.n, "statistics scratch too small");
-    launch_in_finalize(psum_.p, pm2_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p, st);
+    const int groups = t.groups_per_img;
+    ATDN_CHECK((long)nimg * groups * L.N <= psum_.n && (long)nimg * groups <= pcnt_.n, "statistics scratch too small");
+    if (t.counted)
+      launch_in_finalize_cnt(psum_.p, pm2_.p, pcnt_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p,
+                             rstd_[slot].p, st);
+    else
+      launch_in_finalize(psum_.p, pm2_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p, st);
   };
   if (instance) {
     ConvShape s = conv_shape(E.stem, img4_.p, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);

@@ -15,6 +15,9 @@ void launch_prep_images(const float* im1, const float* im2, int B, int H, int W,
 // InstanceNorm statistics from the conv epilogue's per-group partials -> mean, rstd  [nimg][C]
 void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, int groups_per_img, int HW, int C,
                         float eps, float* mean, float* rstd, hipStream_t st);
+// same, group sizes given explicitly (part_cnt [nimg][groups]) — partials of the 2-D tiled conv kernel
+void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const float* part_cnt, int nimg,
+                            int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, hipStream_t st);
 // y = relu((x-mean)*rstd); optional residual: y = relu(r + y), r = res or (res-rmean)*rrstd when rmean given
 void launch_in_apply(float* x, const float* mean, const float* rstd, const float* res, const float* rmean,
                      const float* rrstd, int nimg, long HW, int C, hipStream_t st);

@@ -95,6 +95,55 @@ void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, i
   ATDN_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(1024) void in_finalize_cnt_kernel(const float* __restrict__ ps,
+                                                               const float* __restrict__ pm2,
+                                                               const float* __restrict__ pc, int groups, int HW, int C,
+                                                               float eps, float* __restrict__ mean,
+                                                               float* __restrict__ rstd) {
+  __shared__ double s_n[16][64], s_mu[16][64], s_m2[16][64];
+  const int img = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  if (c < C) {
+    const float* s = ps + (long)img * groups * C + c;
+    const float* m = pm2 + (long)img * groups * C + c;
+    const float* cn = pc + (long)img * groups;
+#pragma unroll 4
+    for (int g = wv; g < groups; g += 16) {
+      const double cnt = (double)cn[g];
+      if (cnt > 0.0) {
+        const double gmu = (double)s[(long)g * C] / cnt;
+        const double tot = n + cnt, d = gmu - mu;
+        mu += d * (cnt / tot);
+        m2 += (double)m[(long)g * C] + d * d * (n * cnt / tot);
+        n = tot;
+      }
+    }
+  }
+  s_n[wv][lane] = n; s_mu[wv][lane] = mu; s_m2[wv][lane] = m2;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    n = 0.0; mu = 0.0; m2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      const double cnt = s_n[k][lane];
+      if (cnt > 0.0) {
+        const double tot = n + cnt, d = s_mu[k][lane] - mu;
+        mu += d * (cnt / tot);
+        m2 += s_m2[k][lane] + d * d * (n * cnt / tot);
+        n = tot;
+      }
+    }
+    mean[img * C + c] = (float)mu;
+    rstd[img * C + c] = (float)(1.0 / sqrt(m2 / (double)HW + (double)eps));
+  }
+}
+void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const float* part_cnt, int nimg,
+                            int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(in_finalize_cnt_kernel, dim3(cdiv(C, 64), nimg), dim3(1024), 0, st, part_sum, part_m2, part_cnt,
+                     groups_per_img, HW, C, eps, mean, rstd);
+  ATDN_HIP(hipGetLastError());
+}
+
 __global__ void in_apply_kernel(float4* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                 const float4* __restrict__ res, const float* __restrict__ rmean,
                                 const float* __restrict__ rrstd, long per_img4, int C, long total4) {
