@@ -47,6 +47,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// value select on a float4 (a ternary on the struct type becomes a pointer select + memcpy and drags every
+// prefetch array into scratch memory)
+__device__ __forceinline__ float4 keep_if(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float mishf_(float x) {
   const float sp = (x > 20.0f) ? x : log1pf(expf(x));

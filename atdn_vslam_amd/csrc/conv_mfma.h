@@ -88,20 +88,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
       ix0[i] = -(1 << 20);
     }
   }
+  // Loads are unconditional (clamped address, value zeroed by a select afterwards): a predicated load makes hipcc
+  // branch around it and wait vmcnt(0) per load, which serialises the whole prefetch.
   const float* wrow[RB];
+  bool wok[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     const int n = n0 + r0 + 32 * j;
-    wrow[j] = (n < g.N) ? (g.w + (long)img * g.wb + (long)n * g.ldw + 4 * s) : nullptr;
+    wok[j] = n < g.N;
+    wrow[j] = g.w + (long)img * g.wb + (long)(wok[j] ? n : 0) * g.ldw + 4 * s;
   }
   const float* s0 = g.src0 + (long)img * g.sb0;
   const float* s1 = (MODE == MODE_TAP && g.src1) ? g.src1 + (long)img * g.sb1 : nullptr;
 
   float4 ra[RA], rb[RB];
+  bool aok[RA];  // validity of the prefetched A rows: applied when the registers are written to LDS, AFTER the
+                 // MFMA block, so that nothing consumes a load result (and waits for it) before the matrix work
   int ky = 0, kx = 0, cc = 0;  // TAP: tap (ky,kx), channel offset cc; ROW: ky, part = kx
   const int ctot = g.C0 + g.C1;
 
-  auto fetch = [&](int q) {
+  auto fetch = [&](int q) __attribute__((always_inline)) {
     if (MODE == MODE_TAP) {
       const float* sp;
       int ld, co;
@@ -110,8 +116,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
       for (int i = 0; i < RA; ++i) {
         const int iy = iy0[i] + ky, ix = ix0[i] + kx;
         const bool ok = ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
-        ra[i] = ok ? *reinterpret_cast<const float4*>(sp + (long)(iy * g.W + ix) * ld + co + 4 * s)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = *reinterpret_cast<const float4*>(sp + (long)(ok ? iy * g.W + ix : 0) * ld + co + 4 * s);
+        ra[i] = v;
+        aok[i] = ok;
       }
       cc += 32;
       if (cc == ctot) { cc = 0; if (++kx == g.KW) { kx = 0; ++ky; } }
@@ -122,14 +129,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
       for (int i = 0; i < RA; ++i) {
         const int iy = iy0[i] + ky, ix = ix0[i] + dx;
         const bool ok = ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
-        ra[i] = ok ? *reinterpret_cast<const float4*>(s0 + (long)(iy * g.W + ix) * g.ld0 + c)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = *reinterpret_cast<const float4*>(s0 + (long)(ok ? iy * g.W + ix : 0) * g.ld0 + c);
+        ra[i] = v;
+        aok[i] = ok;
       }
       if (++kx == g.cpk) { kx = 0; ++ky; }
     }
 #pragma unroll
-    for (int j = 0; j < RB; ++j)
-      rb[j] = wrow[j] ? *reinterpret_cast<const float4*>(wrow[j] + q * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < RB; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow[j] + q * 32);
+      rb[j] = v;
+    }
   };
 
   // ---- MFMA role
@@ -151,9 +161,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
   for (int q = 0; q < g.nchunks; ++q) {
     __syncthreads();  // previous chunk's fragment reads are done
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDS_LD + 4 * s) = ra[i];
+    for (int i = 0; i < RA; ++i)
+      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDS_LD + 4 * s) = keep_if(aok[i], ra[i]);
 #pragma unroll
-    for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = rb[j];
+    for (int j = 0; j < RB; ++j)
+      *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = keep_if(wok[j], rb[j]);
     __syncthreads();
     if (q + 1 < g.nchunks) fetch(q + 1);  // in flight during the MFMAs below
 #pragma unroll
@@ -213,10 +225,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
         }
       }
       if (nok) {
+        if constexpr (Epi::kPrefetch) {
+          // all 16 operand loads of the tile are issued back to back (clamped rows), then applied
+          typename Epi::Aux aux[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m < HoWo) ep(img, m, n, acc[i][j][e]);
+          for (int e = 0; e < 16; ++e) aux[e] = ep.load(img, min(mbase + (e & 3) + 8 * (e >> 2) + 4 * h, HoWo - 1), n);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < HoWo) ep.apply(img, m, n, acc[i][j][e], aux[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < HoWo) ep(img, m, n, acc[i][j][e]);
+          }
         }
       }
     }

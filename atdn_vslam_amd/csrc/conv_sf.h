@@ -48,20 +48,24 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
       ix0[i] = -(1 << 20);
     }
   }
+  // unconditional loads + select (see conv_mfma.h)
   const float* wrow[RB];
+  bool wok[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     const int n = n0 + r0 + 32 * j;
-    wrow[j] = (n < g.N) ? (g.w + (long)img * g.wb + (long)n * g.ldw + 4 * s) : nullptr;
+    wok[j] = n < g.N;
+    wrow[j] = g.w + (long)img * g.wb + (long)(wok[j] ? n : 0) * g.ldw + 4 * s;
   }
   const float* s0 = g.src0 + (long)img * g.sb0;
   const float* s1 = g.src1 ? g.src1 + (long)img * g.sb1 : nullptr;
 
   float4 ra[RA], rb[RB];
+  bool aok[RA];  // applied at LDS-store time (see conv_mfma.h)
   int ky = 0, kx = 0, cc = 0;
   const int ctot = g.C0 + g.C1;
 
-  auto fetch = [&](int q) {
+  auto fetch = [&](int q) __attribute__((always_inline)) {
     const float* sp;
     int ld, co;
     if (cc < g.C0) { sp = s0; ld = g.ld0; co = cc; } else { sp = s1; ld = g.ld1; co = cc - g.C0; }
@@ -69,14 +73,17 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
     for (int i = 0; i < RA; ++i) {
       const int iy = iy0[i] + ky, ix = ix0[i] + kx;
       const bool ok = ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
-      ra[i] = ok ? *reinterpret_cast<const float4*>(sp + (long)(iy * g.W + ix) * ld + co + 4 * s)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = *reinterpret_cast<const float4*>(sp + (long)(ok ? iy * g.W + ix : 0) * ld + co + 4 * s);
+      ra[i] = v;
+      aok[i] = ok;
     }
     cc += 32;
     if (cc == ctot) { cc = 0; if (++kx == g.KW) { kx = 0; ++ky; } }
 #pragma unroll
-    for (int j = 0; j < RB; ++j)
-      rb[j] = wrow[j] ? *reinterpret_cast<const float4*>(wrow[j] + q * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < RB; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow[j] + q * 32);
+      rb[j] = v;
+    }
   };
 
   const int lane = tid & 63, wave = tid >> 6;
@@ -99,9 +106,11 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
   for (int q = 0; q < g.nchunks; ++q) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDS_LD + 4 * s) = ra[i];
+    for (int i = 0; i < RA; ++i)
+      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDS_LD + 4 * s) = keep_if(aok[i], ra[i]);
 #pragma unroll
-    for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = rb[j];
+    for (int j = 0; j < RB; ++j)
+      *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = keep_if(wok[j], rb[j]);
     __syncthreads();
     if (q + 1 < g.nchunks) fetch(q + 1);
 #pragma unroll
@@ -164,10 +173,22 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
         }
       }
       if (nok) {
+        if constexpr (Epi::kPrefetch) {
+          // all 16 operand loads of the tile are issued back to back (clamped rows), then applied
+          typename Epi::Aux aux[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m < HoWo) ep(img, m, n, acc[i][j][e] * wscale);
+          for (int e = 0; e < 16; ++e) aux[e] = ep.load(img, min(mbase + (e & 3) + 8 * (e >> 2) + 4 * h, HoWo - 1), n);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < HoWo) ep.apply(img, m, n, acc[i][j][e] * wscale, aux[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < HoWo) ep(img, m, n, acc[i][j][e] * wscale);
+          }
         }
       }
     }

@@ -64,41 +64,44 @@ __global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const 
     }
     poff[k] = off;
   }
-  const float* wrow[RB];
-#pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    const int n = n0 + r0 + 32 * j;
-    wrow[j] = (n < g.N) ? (g.w + (long)n * g.ldw + 4 * s) : nullptr;
-  }
+  // unconditional loads + select at LDS-store time (see conv_mfma.h); weight row addresses are recomputed per
+  // fetch from one base pointer (clamped to the last valid row) instead of living in 2*RB registers
+  const int nrow0 = n0 + r0;
+  const float* wbase = g.w + 4 * s;
   const float* s0 = g.src0 + (long)img * g.sb0;
   const float* s1 = g.src1 ? g.src1 + (long)img * g.sb1 : nullptr;
   const int nck = (g.C0 + g.C1) >> 5, ntap = g.KH * g.KW;
   const int nstep = nck * ntap;
 
-  float4 pr[NP], wr[RB];
+  float4 pr[NP], wrA[RB], wrB[RB];  // weight tiles are prefetched TWO steps ahead, alternating register sets
   auto fetch_patch = [&](int c) {
     const int cc = c << 5;
     const float* sp; int ld, co;
     if (cc < g.C0) { sp = s0; ld = g.ld0; co = cc; } else { sp = s1; ld = g.ld1; co = cc - g.C0; }
 #pragma unroll
-    for (int k = 0; k < NP; ++k)
-      pr[k] = (poff[k] >= 0) ? *reinterpret_cast<const float4*>(sp + (long)poff[k] * ld + co + 4 * s)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NP; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(sp + (long)(poff[k] >= 0 ? poff[k] : 0) * ld + co + 4 * s);
+      pr[k] = v;
+    }
   };
-  auto fetch_w = [&](int c, int tap) {
-    const int q = tap * nck + c;  // packed K order is [tap][channel chunk]
+  // linear step index st = c * ntap + tap; the packed K order is [tap][channel chunk]
+  auto fetch_w = [&](float4 (&wr)[RB], int st) {
+    const int c = st / ntap, tap = st - c * ntap;
+    const int q = tap * nck + c;
 #pragma unroll
     for (int j = 0; j < RB; ++j)
-      wr[j] = wrow[j] ? *reinterpret_cast<const float4*>(wrow[j] + q * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wr[j] = *reinterpret_cast<const float4*>(wbase + (long)min(nrow0 + 32 * j, g.N - 1) * g.ldw + q * 32);
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int k = 0; k < NP; ++k)
-      if (r0 + 32 * k < C2_PATCH_MAX) *reinterpret_cast<float4*>(Ps + (r0 + 32 * k) * LDS_LD + 4 * s) = pr[k];
+      if (r0 + 32 * k < C2_PATCH_MAX)
+        *reinterpret_cast<float4*>(Ps + (r0 + 32 * k) * LDS_LD + 4 * s) = keep_if(poff[k] >= 0, pr[k]);
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](const float4 (&wr)[RB], int buf) {
 #pragma unroll
-    for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(Ws + (buf * BN + r0 + 32 * j) * LDS_LD + 4 * s) = wr[j];
+    for (int j = 0; j < RB; ++j)
+      *reinterpret_cast<float4*>(Ws + (buf * BN + r0 + 32 * j) * LDS_LD + 4 * s) = keep_if(nrow0 + 32 * j < g.N, wr[j]);
   };
 
   // ---- MFMA roles: wave grid 2 x 2, each wave 2 x TN tiles of 32x32
@@ -122,21 +125,22 @@ __global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const 
   const char* Wb = reinterpret_cast<const char*>(Ws) + (wn * TN * 32 + r) * ROWB + 16 * h;
 
   fetch_patch(0);
-  fetch_w(0, 0);
+  fetch_w(wrA, 0);
+  if (nstep > 1) fetch_w(wrB, 1);
   store_patch();
-  store_w(0);
+  store_w(wrA, 0);
   __syncthreads();
-  int c = 0, tap = 0, ky = 0, kx = 0;
+  if (nstep > 2) fetch_w(wrA, 2);
+  int tap = 0, c = 0, ky = 0, kx = 0;
+  // One step = one (channel chunk, filter tap). Step st (parity P) computes from weight buffer P, then stores
+  // the register set that holds W(st+1) — issued two steps earlier — into buffer 1-P and refills it with W(st+3).
+  // (Plain loop with a runtime parity: a generic lambda kept its by-reference captures in scratch memory, and
+  // every scratch reload is a VMEM op whose wait drains the whole prefetch queue.)
   for (int st = 0; st < nstep; ++st) {
-    // next step's coordinates
-    int c2 = c, tap2 = tap + 1;
-    if (tap2 == ntap) { tap2 = 0; c2 = c + 1; }
-    const bool more = st + 1 < nstep;
-    if (more) fetch_w(c2, tap2);
+    const int P = st & 1;  // wave-uniform: selects the weight buffer and which register set is stored / refilled
     if (tap == 0 && c + 1 < nck) fetch_patch(c + 1);  // lands during this chunk's taps
-
     const char* arow = Pb + (ky * g.PW + kx) * ROWB;
-    const char* brow = Wb + (st & 1) * BN * ROWB;
+    const char* brow = Wb + P * BN * ROWB;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f16x8 ah[2], al[2], bh[TN], bl[TN];
@@ -159,15 +163,17 @@ __global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (more) {
-      if (tap2 == 0) {           // chunk boundary: the patch is replaced, every wave must be done reading it
+    const bool last_tap = (tap + 1 == ntap);
+    if (st + 1 < nstep) {
+      if (last_tap) {  // chunk boundary: the patch is replaced, every wave must be done reading it
         __syncthreads();
         store_patch();
       }
-      store_w((st + 1) & 1);     // the other weight buffer was last read one step ago (barrier since then)
+      if (P == 0) { store_w(wrB, 1); if (st + 3 < nstep) fetch_w(wrB, st + 3); }
+      else        { store_w(wrA, 0); if (st + 3 < nstep) fetch_w(wrA, st + 3); }
       __syncthreads();
     }
-    c = c2; tap = tap2;
+    if (last_tap) { tap = 0; ++c; } else ++tap;
     if (++kx == g.KW) { kx = 0; if (++ky == g.KH) ky = 0; }
   }
 
@@ -213,9 +219,18 @@ __global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const 
         if (lane == 0 && n == 0) ep.part_cnt[(long)img * ep.groups_per_img + grp] = (float)cnt;
       }
       if (nok) {
+        if constexpr (Epi::kPrefetch) {
+          typename Epi::Aux aux[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (mm[e] >= 0) ep(img, mm[e], n, acc[i][j][e] * g.wscale);
+          for (int e = 0; e < 16; ++e) aux[e] = ep.load(img, max(mm[e], 0), n);
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (mm[e] >= 0) ep.apply(img, mm[e], n, acc[i][j][e] * g.wscale, aux[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (mm[e] >= 0) ep(img, mm[e], n, acc[i][j][e] * g.wscale);
+        }
       }
     }
   }

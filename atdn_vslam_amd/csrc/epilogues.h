@@ -11,6 +11,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1 };
 template <int ACT>
 struct EpiBias {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   const float* bias;  // may be null
   float* dst; long ob; int ld;
   float scale;        // applied after bias (mask head: 0.25), 1 otherwise
@@ -24,6 +25,7 @@ struct EpiBias {
 // raw = acc + bias, plus per-(32-row group, channel) partial statistics for InstanceNorm (fnet)
 struct EpiBiasStats {
   static constexpr bool kStats = true;
+  static constexpr bool kPrefetch = false;
   const float* bias;
   float* dst; long ob; int ld;
   float* part_sum; float* part_m2; int groups_per_img;
@@ -36,18 +38,22 @@ struct EpiBiasStats {
 // out = relu(res + relu(acc + bias))      (cnet residual block tail, extractor.py:47-55 with folded BN)
 struct EpiBiasReluAddRelu {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;  // load(): issued for all 16 elements of a tile before any apply()
   const float* bias;
   const float* res; long rb; int ldr;
   float* dst; long ob; int ld;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
+  struct Aux { float r; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const { return {res[(long)img * rb + (long)m * ldr + n]}; }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float y = fmaxf(a + bias[n], 0.f);
-    dst[(long)img * ob + (long)m * ld + n] = fmaxf(res[(long)img * rb + (long)m * ldr + n] + y, 0.f);
+    dst[(long)img * ob + (long)m * ld + n] = fmaxf(x.r + y, 0.f);
   }
 };
 
 // cnet head: channels [0,128) -> tanh -> hidden state; [128,256) -> relu -> context slice of x  (network.py:94-97)
 struct EpiContextSplit {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   const float* bias;
   float* net; long nb;            // [img][pix][128]
   float* inp; long ib; int ldi;   // x buffer, channels [0,128)
@@ -61,6 +67,7 @@ struct EpiContextSplit {
 // y = acc * scale     (all-pairs correlation /sqrt(C), corr.py:63; attention logits)
 struct EpiScale {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   float scale;
   float* dst; long ob; int ld;
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
@@ -71,6 +78,7 @@ struct EpiScale {
 // to_qk (gma.py:57-60): q columns [0,nq) are scaled before the dot product
 struct EpiQK {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   float scale; int nq;
   float* dst; long ob; int ld;
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
@@ -81,6 +89,7 @@ struct EpiQK {
 // transposed store: dst[img][n][m]   (to_v output becomes the K-contiguous "weight" of attention·V)
 struct EpiStoreT {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   float* dst; long ob; int ld;
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
     dst[(long)img * ob + (long)n * ld + m] = a;
@@ -90,11 +99,14 @@ struct EpiStoreT {
 // out = mf + gamma * acc    (gma.py:113)
 struct EpiAggregate {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* gamma;  // device scalar
   const float* mf; long mb; int ldm;
   float* dst; long ob; int ld;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    dst[(long)img * ob + (long)m * ld + n] = mf[(long)img * mb + (long)m * ldm + n] + gamma[0] * a;
+  struct Aux { float x; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const { return {mf[(long)img * mb + (long)m * ldm + n]}; }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
+    dst[(long)img * ob + (long)m * ld + n] = x.x + gamma[0] * a;
   }
 };
 
@@ -102,42 +114,54 @@ struct EpiAggregate {
 //   n <  128: z = sigmoid(.) -> zbuf ;  n >= 128: r = sigmoid(.), store r*h
 struct EpiGruZR {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* bias;  // [256] = bz ‖ br
   const float* h;     // [img][pix][128]
   float* z; float* rh; long ob;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
+  struct Aux { float h; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const {
+    return {h[(long)img * ob + (long)m * 128 + (n & 127)]};
+  }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float v = sigmoidf_(a + bias[n]);
     const long o = (long)img * ob + (long)m * 128;
     if (n < 128) z[o + n] = v;
-    else rh[o + n - 128] = v * h[o + n - 128];
+    else rh[o + n - 128] = v * x.h;
   }
 };
 
 // q convolution + state update (update.py:53-54,60-61): h' = (1-z) h + z tanh(.)
 struct EpiGruQ {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* bias;
   const float* h; const float* z;
   float* hout; long ob;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    const float q = tanhf(a + bias[n]);
+  struct Aux { float h, z; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const {
     const long o = (long)img * ob + (long)m * 128 + n;
-    const float zz = z[o];
-    hout[o] = (1.f - zz) * h[o] + zz * q;
+    return {h[o], z[o]};
+  }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
+    const float q = tanhf(a + bias[n]);
+    hout[(long)img * ob + (long)m * 128 + n] = (1.f - x.z) * x.h + x.z * q;
   }
 };
 
 // flow head tail (update.py:15, network.py:116,111): coords1 += delta; flow = coords1 - coords0
 struct EpiFlowDelta {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* bias;  // [2]
   float* coords1;     // [img][pix][2]
   float* flow4;       // [img][pix][4] (x, y, 0, 0): input of convf1
   float* xflow; int ldx; long xb;  // flow channels inside the GRU input x (motion_features[126:128])
   int W8; long npix;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
+  struct Aux { float c; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const { return {coords1[((long)img * npix + m) * 2 + n]}; }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const long p = (long)img * npix + m;
-    const float c1 = coords1[p * 2 + n] + (a + bias[n]);
+    const float c1 = x.c + (a + bias[n]);
     coords1[p * 2 + n] = c1;
     const float c0 = (n == 0) ? (float)(m % W8) : (float)(m / W8);
     const float f = c1 - c0;
@@ -149,6 +173,7 @@ struct EpiFlowDelta {
 // CLVO `Conv` block tail (layers/conv.py:37): bn(mish(acc + bias)) with eval-BN as scale/shift
 struct EpiMishBN {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   const float* bias; const float* sc; const float* sh;
   float* dst; long ob; int ld;
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
@@ -159,14 +184,16 @@ struct EpiMishBN {
 // CLVO `ResidualConv` tail (layers/conv.py:83-90): bn_out(mish(bn_b(mish(acc + bias)) + skip))
 struct EpiMishBNSkipMishBN {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* bias; const float* sc1; const float* sh1;
   const float* skip; long sb; int lds;
   const float* sc2; const float* sh2;
   float* dst; long ob; int ld;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
+  struct Aux { float s; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const { return {skip[(long)img * sb + (long)m * lds + n]}; }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float y = mishf_(a + bias[n]) * sc1[n] + sh1[n];
-    const float t = y + skip[(long)img * sb + (long)m * lds + n];
-    dst[(long)img * ob + (long)m * ld + n] = mishf_(t) * sc2[n] + sh2[n];
+    dst[(long)img * ob + (long)m * ld + n] = mishf_(y + x.s) * sc2[n] + sh2[n];
   }
 };
 

@@ -11,6 +11,7 @@ namespace atdn {
 template <int ACT>
 struct SfBias {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   const float* bias;  // may be null
   float* dst; long ob; int ld;
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
@@ -23,18 +24,21 @@ struct SfBias {
 // out = relu(res + relu(acc + bias)), res and out in sf
 struct SfBiasReluAddRelu {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* bias;
   const float* res; long rb; int ldr;
   float* dst; long ob; int ld;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
+  struct Aux { float r; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const { return {sf_load(res, (long)img * rb + (long)m * ldr, n)}; }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float y = fmaxf(a + bias[n], 0.f);
-    const float r = sf_load(res, (long)img * rb + (long)m * ldr, n);
-    sf_store(dst, (long)img * ob + (long)m * ld, n, fmaxf(r + y, 0.f));
+    sf_store(dst, (long)img * ob + (long)m * ld, n, fmaxf(x.r + y, 0.f));
   }
 };
 
 struct SfContextSplit {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   const float* bias;
   float* net; long nb;            // sf [img][pix][128]
   float* inp; long ib; int ldi;   // sf x buffer, channels [0,128)
@@ -47,6 +51,7 @@ struct SfContextSplit {
 
 struct SfQK {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   float scale; int nq;
   float* dst; long ob; int ld;
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
@@ -57,6 +62,7 @@ struct SfQK {
 // transposed sf store: dst[img][n][m]  (m is the K index of attention·V)
 struct SfStoreT {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = false;
   float* dst; long ob; int ld;
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
     sf_store(dst, (long)img * ob + (long)n * ld, m, a);
@@ -65,55 +71,69 @@ struct SfStoreT {
 
 struct SfAggregate {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* gamma;
   const float* mf; long mb; int ldm;   // sf
   float* dst; long ob; int ld;          // sf
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    const float x = sf_load(mf, (long)img * mb + (long)m * ldm, n);
-    sf_store(dst, (long)img * ob + (long)m * ld, n, x + gamma[0] * a);
+  struct Aux { float x; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const { return {sf_load(mf, (long)img * mb + (long)m * ldm, n)}; }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
+    sf_store(dst, (long)img * ob + (long)m * ld, n, x.x + gamma[0] * a);
   }
 };
 
 struct SfGruZR {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* bias;
   const float* h;   // sf [img][pix][128]
   float* z;         // fp32 (only the q epilogue reads it)
   float* rh;        // sf
   long ob;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
+  struct Aux { float h; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const {
+    return {sf_load(h, (long)img * ob + (long)m * 128, n & 127)};
+  }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float v = sigmoidf_(a + bias[n]);
     const long o = (long)img * ob + (long)m * 128;
     if (n < 128) z[o + n] = v;
-    else sf_store(rh, o, n - 128, v * sf_load(h, o, n - 128));
+    else sf_store(rh, o, n - 128, v * x.h);
   }
 };
 
 struct SfGruQ {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* bias;
   const float* h;   // sf
   const float* z;   // fp32
   float* hout;      // sf
   long ob;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    const float q = tanhf(a + bias[n]);
+  struct Aux { float h, z; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const {
     const long o = (long)img * ob + (long)m * 128;
-    const float zz = z[o + n];
-    sf_store(hout, o, n, (1.f - zz) * sf_load(h, o, n) + zz * q);
+    return {sf_load(h, o, n), z[o + n]};
+  }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
+    const float q = tanhf(a + bias[n]);
+    sf_store(hout, (long)img * ob + (long)m * 128, n, (1.f - x.z) * x.h + x.z * q);
   }
 };
 
 struct SfFlowDelta {
   static constexpr bool kStats = false;
+  static constexpr bool kPrefetch = true;
   const float* bias;
   float* coords1;   // fp32 [img][pix][2]
   float* flow4;     // fp32 [img][pix][4]
   float* x; int ldx; long xb; int cflow;  // sf GRU input, flow channels cflow, cflow+1
   int W8; long npix;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
+  struct Aux { float c; };
+  __device__ __forceinline__ Aux load(int img, int m, int n) const { return {coords1[((long)img * npix + m) * 2 + n]}; }
+  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux xx) const {
     const long p = (long)img * npix + m;
-    const float c1 = coords1[p * 2 + n] + (a + bias[n]);
+    const float c1 = xx.c + (a + bias[n]);
     coords1[p * 2 + n] = c1;
     const float c0 = (n == 0) ? (float)(m % W8) : (float)(m / W8);
     const float f = c1 - c0;
