@@ -90,12 +90,13 @@ struct SfGruZR {
   float* z;         // fp32 (only the q epilogue reads it)
   float* rh;        // sf
   long ob;
-  struct Aux { float h; };
+  const float* pre; long pb;  // fp32 [img][pix][256]: the iteration-invariant context-channel part of the conv
+  struct Aux { float h, p; };
   __device__ __forceinline__ Aux load(int img, int m, int n) const {
-    return {sf_load(h, (long)img * ob + (long)m * 128, n & 127)};
+    return {sf_load(h, (long)img * ob + (long)m * 128, n & 127), pre[(long)img * pb + (long)m * 256 + n]};
   }
   __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
-    const float v = sigmoidf_(a + bias[n]);
+    const float v = sigmoidf_((a + x.p) + bias[n]);
     const long o = (long)img * ob + (long)m * 128;
     if (n < 128) z[o + n] = v;
     else sf_store(rh, o, n - 128, v * x.h);
@@ -110,13 +111,14 @@ struct SfGruQ {
   const float* z;   // fp32
   float* hout;      // sf
   long ob;
-  struct Aux { float h, z; };
+  const float* pre;  // fp32 [img][pix][128], same per-image stride as h
+  struct Aux { float h, z, p; };
   __device__ __forceinline__ Aux load(int img, int m, int n) const {
     const long o = (long)img * ob + (long)m * 128;
-    return {sf_load(h, o, n), z[o + n]};
+    return {sf_load(h, o, n), z[o + n], pre[o + n]};
   }
   __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
-    const float q = tanhf(a + bias[n]);
+    const float q = tanhf((a + x.p) + bias[n]);
     sf_store(hout, (long)img * ob + (long)m * 128, n, (1.f - x.z) * x.h + x.z * q);
   }
 };

@@ -36,13 +36,17 @@ class GmaNet {
   // im1/im2 NCHW [B,3,H,W] 0..255; flow_init NCHW [B,2,H/8,W/8] or null; outputs NCHW. All device pointers.
   void forward(const float* im1, const float* im2, int B, int iters, const float* flow_init, float* flow_low,
                float* flow_up, hipStream_t st);
+  // B consecutive pairs of one clip: frames NCHW [B+1,3,H,W]; pair b = (frame b, frame b+1). The feature network
+  // runs once per FRAME (B+1 passes instead of 2B).
+  void forward_sequence(const float* frames, int B, int iters, const float* flow_init, float* flow_low, float* flow_up,
+                        hipStream_t st);
   // copy an internal tensor to host (parity tests); returns element count, or -1 for an unknown name
   long debug_read(const char* name, float* host, long capacity, hipStream_t st);
   size_t workspace_bytes() const { return ws_bytes_; }
   // Eager (un-graphed) run on `st` with hipEvents at stage boundaries; ms[] receives the time of each Stage
   // summed over `reps` forwards. Inputs are whatever the last forward() left in the workspace.
   enum Stage { ST_FNET = 0, ST_CORR, ST_POOL, ST_CNET, ST_ATTN, ST_LOOKUP, ST_MOTION, ST_AGG, ST_GRU_ZR, ST_GRU_Q, ST_FLOWHEAD,
-               ST_MASK, ST_COUNT };
+               ST_MASK, ST_GRU_CTX, ST_COUNT };
   void profile(int B, int iters, int reps, float* ms, hipStream_t st);
 
   int H, W, H8, W8, N, ldN, maxB, precision;
@@ -56,6 +60,8 @@ class GmaNet {
   void run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf);
   void iteration_sf(int B, hipStream_t st);
   void capture(int B, int iters);
+  void launch_body(int B, int iters, hipStream_t st);
+  bool seq_ = false;  // current call shares frames between consecutive pairs
 
   StateDict sd_;
   WeightArena arena_;
@@ -64,13 +70,14 @@ class GmaNet {
   EncoderWeights fnet_, cnet_;
   PackedConv convc1_, convc2_, convf1_, convf2_, convm_, to_v_, to_qk_;
   PackedConv gru_zr_[2], gru_q_[2], fh1_, fh2_, mask0_, mask2_;
+  PackedConv gru_zr_ctx_[2], gru_q_ctx_[2];  // sf mode: context-channel (inp) slices, applied once per pair
   const float* gamma_ = nullptr;
   long gamma_off_ = -1;
 
   // workspace
-  DeviceBuf img4_, enc_[4], sim_, scratch_, pcnt_, fmap_, psum_, pm2_, mean_[2], rstd_[2];
+  DeviceBuf img4_, enc_[4], sim_, scratch_, pcnt_, fin_, fmap_, psum_, pm2_, mean_[2], rstd_[2];
   DeviceBuf pyr_[4], h_[2], x_, qk_, attn_, vT_, corrfeat_, cor1_, corflo_, flo1_, z_, rh_, fh_, mask_;
-  DeviceBuf coords1_, flow4_;
+  DeviceBuf coords1_, flow4_, pre_zr_[2], pre_q_[2];
   int pyrH_[4], pyrW_[4];
   size_t ws_bytes_ = 0;
 
@@ -79,7 +86,7 @@ class GmaNet {
   void mark(int stage, hipStream_t st);
 
   hipStream_t cap_stream_ = nullptr;
-  std::map<std::pair<int, int>, hipGraphExec_t> graphs_;
+  std::map<std::pair<int, int>, hipGraphExec_t> graphs_;  // key: (B, iters * 2 + seq)
 };
 
 }  // namespace atdn

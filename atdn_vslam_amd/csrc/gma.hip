@@ -97,6 +97,7 @@ void GmaNet::mark(int stage, hipStream_t st) {
 void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
   ATDN_CHECK(ready_ && B >= 1 && B <= maxB && reps >= 1, "bad profile request");
   for (int i = 0; i < ST_COUNT; ++i) ms[i] = 0.f;
+  seq_ = false;
   for (int r = 0; r < reps; ++r) {
     Timer t;
     timer_ = &t;
@@ -131,9 +132,10 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
 GmaNet::~GmaNet() {
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
-                      &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_};
+                      &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
+                      &pre_zr_[1], &pre_q_[0], &pre_q_[1]};
   for (auto* b : all) b->release();
   arena_.release();
 }
@@ -157,8 +159,18 @@ void GmaNet::finalize() {
   to_qk_ = tap({"att.to_qk"}, false);
   for (int p = 0; p < 2; ++p) {
     const std::string t = std::to_string(p + 1);
-    gru_zr_[p] = tap({u + "gru.convz" + t, u + "gru.convr" + t});
-    gru_q_[p] = tap({u + "gru.convq" + t});
+    if (sf) {
+      // hx = [h(0:128) | inp(128:256) | motion(256:384) | motion_global(384:512)] (update.py:50,130): the inp slice
+      // does not change over the iterations, so its contribution is computed once per pair (run_body_sf)
+      const std::vector<std::pair<int, int>> rest = {{0, 128}, {256, 512}}, ctx = {{128, 256}};
+      gru_zr_[p] = pack_conv_sf_channels(arena_, sd_, {u + "gru.convz" + t, u + "gru.convr" + t}, rest, true);
+      gru_q_[p] = pack_conv_sf_channels(arena_, sd_, {u + "gru.convq" + t}, rest, true);
+      gru_zr_ctx_[p] = pack_conv_sf_channels(arena_, sd_, {u + "gru.convz" + t, u + "gru.convr" + t}, ctx, false);
+      gru_q_ctx_[p] = pack_conv_sf_channels(arena_, sd_, {u + "gru.convq" + t}, ctx, false);
+    } else {
+      gru_zr_[p] = tap({u + "gru.convz" + t, u + "gru.convr" + t});
+      gru_q_[p] = tap({u + "gru.convq" + t});
+    }
   }
   fh1_ = tap({u + "flow_head.conv1"});
   fh2_ = tap({u + "flow_head.conv2"});
@@ -171,6 +183,7 @@ void GmaNet::finalize() {
   for (PackedConv* L : {&convc1_, &convc2_, &convf1_, &convf2_, &convm_, &to_v_, &to_qk_, &gru_zr_[0], &gru_zr_[1],
                         &gru_q_[0], &gru_q_[1], &fh1_, &fh2_, &mask0_, &mask2_})
     resolve(arena_, *L);
+  if (sf) for (PackedConv* L : {&gru_zr_ctx_[0], &gru_zr_ctx_[1], &gru_q_ctx_[0], &gru_q_ctx_[1]}) resolve(arena_, *L);
   gamma_ = arena_.dev(gamma_off_);
 
   // ---- workspace (sized for maxB pairs; everything stays resident in HBM between calls)
@@ -182,7 +195,7 @@ void GmaNet::finalize() {
   if (sf) sim_.alloc((long)B * N * ldN);
   fmap_.alloc(2L * B * N * 256);
   const long groups = (long)cdiv(H2 * W2, 64) * 4 + 8;
-  psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128); pcnt_.alloc(2L * B * groups);
+  psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128); pcnt_.alloc(2L * B * groups); fin_.alloc(2L * B * 8 * 128 * 3 * 2);
   for (int i = 0; i < 2; ++i) { mean_[i].alloc(2L * B * 128); rstd_[i].alloc(2L * B * 128); }
   pyrH_[0] = H8; pyrW_[0] = W8;
   for (int l = 1; l < 4; ++l) { pyrH_[l] = pyrH_[l - 1] / 2; pyrW_[l] = pyrW_[l - 1] / 2; }
@@ -193,6 +206,7 @@ void GmaNet::finalize() {
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
   z_.alloc(n8 * 128); rh_.alloc(n8 * 128); fh_.alloc(n8 * 256); mask_.alloc(n8 * 576);
   coords1_.alloc(n8 * 2); flow4_.alloc(n8 * 4);
+  if (sf) for (int p = 0; p < 2; ++p) { pre_zr_[p].alloc(n8 * 256); pre_q_[p].alloc(n8 * 128); }
   // pad lanes that kernels read but never write must be finite zeros
   ATDN_HIP(hipMemset(corrfeat_.p, 0, corrfeat_.n * sizeof(float)));
   ATDN_HIP(hipMemset(vT_.p, 0, vT_.n * sizeof(float)));
@@ -386,7 +400,7 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
     ATDN_CHECK((long)nimg * groups * L.N <= psum_.n && (long)nimg * groups <= pcnt_.n, "statistics scratch too small");
     if (t.counted)
       launch_in_finalize_cnt(psum_.p, pm2_.p, pcnt_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p,
-                             rstd_[slot].p, st);
+                             rstd_[slot].p, reinterpret_cast<double*>(fin_.p), st);
     else
       launch_in_finalize(psum_.p, pm2_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p, st);
   };
@@ -470,11 +484,12 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
     float* hout = h_[p ^ 1].p;
     const int ph = p ? 2 : 0, pw = p ? 0 : 2;
     ConvShape g = conv_shape(gru_zr_[p], hin, 128, (long)N * 128, B, H8, W8, 1, ph, pw);
-    g.C0 = 128; g.src1 = x_.p; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = XLD;
-    conv_sf_dispatch(g, gru_zr_[p].wscale, SfGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128}, st);
+    g.C0 = 128; g.src1 = x_.p + 128; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = 256;  // [h | motion | motion_global]
+    conv_sf_dispatch(g, gru_zr_[p].wscale,
+                     SfGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128, pre_zr_[p].p, (long)N * 256}, st);
     mark(ST_GRU_ZR, st);
     g.src0 = rh_.p; g.w = gru_q_[p].w; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
-    conv_sf_dispatch(g, gru_q_[p].wscale, SfGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128}, st);
+    conv_sf_dispatch(g, gru_q_[p].wscale, SfGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128, pre_q_[p].p}, st);
     mark(ST_GRU_Q, st);
   }
 
@@ -488,14 +503,15 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
 
 void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   float* f;
-  run_encoder_sf(fnet_, true, 2 * B, st, &f);
-  ConvShape s = conv_shape(fnet_.head, f, 128, (long)N * 128, 2 * B, H8, W8, 1, 0, 0);
+  const int nfeat = seq_ ? B + 1 : 2 * B;  // feature-network passes: one per frame in sequence mode
+  run_encoder_sf(fnet_, true, nfeat, st, &f);
+  ConvShape s = conv_shape(fnet_.head, f, 128, (long)N * 128, nfeat, H8, W8, 1, 0, 0);
   conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fmap_.p, (long)N * 256, 256}, st);
   mark(ST_FNET, st);
 
   ConvShape c;
   c.src0 = fmap_.p; c.ld0 = 256; c.sb0 = (long)N * 256; c.C0 = 256; c.H = 1; c.W = N;
-  c.w = fmap_.p + (long)B * N * 256; c.wb = (long)N * 256; c.ldw = 256; c.N = N; c.nimg = B;
+  c.w = fmap_.p + (long)(seq_ ? 1 : B) * N * 256; c.wb = (long)N * 256; c.ldw = 256; c.N = N; c.nimg = B;
   conv_sf_dispatch(c, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[0].p, (long)N * N, N}, st);
   mark(ST_CORR, st);
   for (int l = 1; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
@@ -515,6 +531,16 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   conv_sf_dispatch(q, 1.f, EpiScale{1.0f, sim_.p, (long)N * ldN, ldN}, st);
   launch_softmax_rows_sf(sim_.p, attn_.p, (long)B * N, N, ldN, st);
   mark(ST_ATTN, st);
+
+  // context-channel part of the six ConvGRU convolutions: identical in every iteration, computed once
+  for (int p = 0; p < 2; ++p) {
+    const int ph = p ? 2 : 0, pw = p ? 0 : 2;
+    ConvShape g = conv_shape(gru_zr_ctx_[p], x_.p, XLD, (long)N * XLD, B, H8, W8, 1, ph, pw);
+    conv_sf_dispatch(g, gru_zr_ctx_[p].wscale, EpiBias<ACT_NONE>{nullptr, pre_zr_[p].p, (long)N * 256, 256, 1.f}, st);
+    g = conv_shape(gru_q_ctx_[p], x_.p, XLD, (long)N * XLD, B, H8, W8, 1, ph, pw);
+    conv_sf_dispatch(g, gru_q_ctx_[p].wscale, EpiBias<ACT_NONE>{nullptr, pre_q_[p].p, (long)N * 128, 128, 1.f}, st);
+  }
+  mark(ST_GRU_CTX, st);
 
   for (int it = 0; it < iters; ++it) iteration_sf(B, st);
 
@@ -539,7 +565,32 @@ void GmaNet::capture(int B, int iters) {
   hipGraphExec_t exec = nullptr;
   ATDN_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   (void)hipGraphDestroy(graph);
-  graphs_[{B, iters}] = exec;
+  graphs_[{B, iters * 2 + (seq_ ? 1 : 0)}] = exec;
+}
+
+void GmaNet::forward_sequence(const float* frames, int B, int iters, const float* flow_init, float* flow_low,
+                               float* flow_up, hipStream_t st) {
+  ATDN_CHECK(ready_, "weights not finalized");
+  ATDN_CHECK(precision == 1, "sequence mode is built for the split-f16 pipeline");
+  ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
+  ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
+  ATDN_CHECK(frames && flow_low && flow_up, "null tensor");
+  // frames 0..B-1 are the first images, frame B the last second image: img4 = [frame 0 .. frame B]
+  launch_prep_images(frames, frames + (long)B * 3 * H * W, B, H, W, img4_.p, st, 1);
+  seq_ = true;
+  launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
+  launch_body(B, iters, st);
+  launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
+}
+
+void GmaNet::launch_body(int B, int iters, hipStream_t st) {
+  if (use_graph_) {
+    auto key = std::make_pair(B, iters * 2 + (seq_ ? 1 : 0));
+    if (!graphs_.count(key)) capture(B, iters);
+    ATDN_HIP(hipGraphLaunch(graphs_[key], st));
+  } else {
+    if (precision == 1) run_body_sf(B, iters, st); else run_body(B, iters, st);
+  }
 }
 
 void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const float* flow_init, float* flow_low,
@@ -548,16 +599,11 @@ void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const
   ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
   ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
   ATDN_CHECK(im1 && im2 && flow_low && flow_up, "null tensor");
-  launch_prep_images(im1, im2, B, H, W, img4_.p, st);
+  seq_ = false;
+  launch_prep_images(im1, im2, B, H, W, img4_.p, st, B);
   if (precision == 1) launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
   else launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
-  if (use_graph_) {
-    auto key = std::make_pair(B, iters);
-    if (!graphs_.count(key)) capture(B, iters);
-    ATDN_HIP(hipGraphLaunch(graphs_[key], st));
-  } else {
-    if (precision == 1) run_body_sf(B, iters, st); else run_body(B, iters, st);
-  }
+  launch_body(B, iters, st);
   launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
 }
 

@@ -10,14 +10,16 @@ struct PyramidLevels {  // correlation pyramid of ONE batch: level l is [B*N][H_
 };
 
 // frames NCHW [B,3,H,W] (0..255) x2 -> NHWC4 [2B][H][W][4] = 2*(x/255)-1, 4th channel 0   (network.py:75-76)
-void launch_prep_images(const float* im1, const float* im2, int B, int H, int W, float* img4, hipStream_t st);
+// n2 = number of images taken from im2 (B for pair mode; 1 in sequence mode: only the clip's last frame)
+void launch_prep_images(const float* im1, const float* im2, int B, int H, int W, float* img4, hipStream_t st, int n2);
 
 // InstanceNorm statistics from the conv epilogue's per-group partials -> mean, rstd  [nimg][C]
 void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, int groups_per_img, int HW, int C,
                         float eps, float* mean, float* rstd, hipStream_t st);
 // same, group sizes given explicitly (part_cnt [nimg][groups]) — partials of the 2-D tiled conv kernel
 void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const float* part_cnt, int nimg,
-                            int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, hipStream_t st);
+                            int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, double* scratch,
+                            hipStream_t st);  // scratch: nimg * 8 * C * 3 doubles
 // y = relu((x-mean)*rstd); optional residual: y = relu(r + y), r = res or (res-rmean)*rrstd when rmean given
 void launch_in_apply(float* x, const float* mean, const float* rstd, const float* res, const float* rmean,
                      const float* rrstd, int nimg, long HW, int C, hipStream_t st);

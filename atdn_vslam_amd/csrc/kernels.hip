@@ -25,10 +25,10 @@ __device__ __forceinline__ float block_reduce(float v, float* sm) {  // blockDim
 }
 
 // ------------------------------------------------------------------ frame preparation
-__global__ void prep_images_kernel(const float* __restrict__ im1, const float* __restrict__ im2, int B, long HW,
+__global__ void prep_images_kernel(const float* __restrict__ im1, const float* __restrict__ im2, int B, int n2, long HW,
                                    float4* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2L * B * HW) return;
+  if (i >= (long)(B + n2) * HW) return;
   const long img = i / HW, p = i - img * HW;
   const float* src = (img < B ? im1 + img * 3 * HW : im2 + (img - B) * 3 * HW) + p;
   float4 v;
@@ -38,9 +38,9 @@ __global__ void prep_images_kernel(const float* __restrict__ im1, const float* _
   v.w = 0.f;
   out[i] = v;
 }
-void launch_prep_images(const float* im1, const float* im2, int B, int H, int W, float* img4, hipStream_t st) {
-  const long n = 2L * B * H * W;
-  hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, im1, im2, B, (long)H * W,
+void launch_prep_images(const float* im1, const float* im2, int B, int H, int W, float* img4, hipStream_t st, int n2) {
+  const long n = (long)(B + n2) * H * W;
+  hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, im1, im2, B, n2, (long)H * W,
                      reinterpret_cast<float4*>(img4));
   ATDN_HIP(hipGetLastError());
 }
@@ -95,21 +95,27 @@ void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, i
   ATDN_HIP(hipGetLastError());
 }
 
+// Two levels so that the merge of ~3700 (count, mean, M2) triples per channel is spread over the chip:
+// level 1: block (channel slab of 64, image, split z of FIN_SPLIT) folds its share of the groups (16 waves stride
+// over them, fp64 Chan merge) into one triple per channel; level 2: one thread per (image, channel) merges the
+// FIN_SPLIT triples in a fixed order and writes mean / rstd.
+constexpr int FIN_SPLIT = 8;
 __global__ __launch_bounds__(1024) void in_finalize_cnt_kernel(const float* __restrict__ ps,
                                                                const float* __restrict__ pm2,
-                                                               const float* __restrict__ pc, int groups, int HW, int C,
-                                                               float eps, float* __restrict__ mean,
-                                                               float* __restrict__ rstd) {
+                                                               const float* __restrict__ pc, int groups, int C,
+                                                               double* __restrict__ part) {
   __shared__ double s_n[16][64], s_mu[16][64], s_m2[16][64];
-  const int img = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int img = blockIdx.y, z = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  const int per = (groups + FIN_SPLIT - 1) / FIN_SPLIT;
+  const int g0 = z * per, g1 = min(groups, g0 + per);
   double n = 0.0, mu = 0.0, m2 = 0.0;
   if (c < C) {
     const float* s = ps + (long)img * groups * C + c;
     const float* m = pm2 + (long)img * groups * C + c;
     const float* cn = pc + (long)img * groups;
-#pragma unroll 4
-    for (int g = wv; g < groups; g += 16) {
+#pragma unroll 8
+    for (int g = g0 + wv; g < g1; g += 16) {
       const double cnt = (double)cn[g];
       if (cnt > 0.0) {
         const double gmu = (double)s[(long)g * C] / cnt;
@@ -133,14 +139,37 @@ __global__ __launch_bounds__(1024) void in_finalize_cnt_kernel(const float* __re
         n = tot;
       }
     }
-    mean[img * C + c] = (float)mu;
-    rstd[img * C + c] = (float)(1.0 / sqrt(m2 / (double)HW + (double)eps));
+    double* o = part + (((long)img * FIN_SPLIT + z) * C + c) * 3;
+    o[0] = n; o[1] = mu; o[2] = m2;
   }
 }
+__global__ void in_finalize_merge_kernel(const double* __restrict__ part, int nimg, int HW, int C, float eps,
+                                         float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nimg * C) return;
+  const int img = i / C, c = i - img * C;
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  for (int z = 0; z < FIN_SPLIT; ++z) {
+    const double* p = part + (((long)img * FIN_SPLIT + z) * C + c) * 3;
+    const double cnt = p[0];
+    if (cnt > 0.0) {
+      const double tot = n + cnt, d = p[1] - mu;
+      mu += d * (cnt / tot);
+      m2 += p[2] + d * d * (n * cnt / tot);
+      n = tot;
+    }
+  }
+  mean[i] = (float)mu;
+  rstd[i] = (float)(1.0 / sqrt(m2 / (double)HW + (double)eps));
+}
 void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const float* part_cnt, int nimg,
-                            int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, hipStream_t st) {
-  hipLaunchKernelGGL(in_finalize_cnt_kernel, dim3(cdiv(C, 64), nimg), dim3(1024), 0, st, part_sum, part_m2, part_cnt,
-                     groups_per_img, HW, C, eps, mean, rstd);
+                            int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, double* scratch,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(in_finalize_cnt_kernel, dim3(cdiv(C, 64), nimg, FIN_SPLIT), dim3(1024), 0, st, part_sum, part_m2,
+                     part_cnt, groups_per_img, C, scratch);
+  ATDN_HIP(hipGetLastError());
+  hipLaunchKernelGGL(in_finalize_merge_kernel, dim3(cdiv(nimg * C, 128)), dim3(128), 0, st, scratch, nimg, HW, C, eps,
+                     mean, rstd);
   ATDN_HIP(hipGetLastError());
 }
 

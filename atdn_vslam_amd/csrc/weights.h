@@ -160,6 +160,38 @@ inline PackedConv pack_conv_sf(WeightArena& A, const StateDict& sd, const std::v
   return L;
 }
 
+// Stack several convs along Cout, keep only input channels in the given [begin,end) ranges (in that order), and pack
+// the result in sf form. Used to split the ConvGRU weights into the iteration-invariant context part and the rest.
+inline PackedConv pack_conv_sf_channels(WeightArena& A, const StateDict& sd, const std::vector<std::string>& names,
+                                        const std::vector<std::pair<int, int>>& ranges, bool has_bias) {
+  StateDict tmp;
+  std::vector<std::string> tnames;
+  for (size_t t = 0; t < names.size(); ++t) {
+    const HostTensor& w = sd.get(names[t] + ".weight");
+    const int Co = (int)w.shape[0], Ci = (int)w.shape[1], KH = (int)w.shape[2], KW = (int)w.shape[3];
+    int Cn = 0;
+    for (auto& r : ranges) Cn += r.second - r.first;
+    std::vector<float> out((size_t)Co * Cn * KH * KW);
+    for (int n = 0; n < Co; ++n) {
+      int c2 = 0;
+      for (auto& r : ranges)
+        for (int c = r.first; c < r.second; ++c, ++c2)
+          std::memcpy(&out[((size_t)n * Cn + c2) * KH * KW], &w.data[((size_t)n * Ci + c) * KH * KW],
+                      sizeof(float) * KH * KW);
+    }
+    const std::string key = "s" + std::to_string(t);
+    const int64_t shp[4] = {Co, Cn, KH, KW};
+    tmp.put(key + ".weight", out.data(), shp, 4);
+    if (has_bias && sd.has(names[t] + ".bias")) {
+      const HostTensor& b = sd.get(names[t] + ".bias");
+      const int64_t bs[1] = {Co};
+      tmp.put(key + ".bias", b.data.data(), bs, 1);
+    }
+    tnames.push_back(key);
+  }
+  return pack_conv_sf(A, tmp, tnames, nullptr, has_bias);
+}
+
 inline long pack_vector(WeightArena& A, const std::vector<float>& v) {
   const long off = A.alloc((long)v.size());
   std::memcpy(A.at(off), v.data(), v.size() * sizeof(float));

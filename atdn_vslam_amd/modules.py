@@ -155,6 +155,31 @@ class RAFTGMA(_NativeModule):
                                                    _ptr(flow_up), _stream()))
         return flow_low, flow_up
 
+    @torch.no_grad()
+    def forward_sequence(self, frames, iters=12, flow_init=None):
+        """Flow of the B consecutive pairs of a clip `frames` [B+1,3,H,W] (pair b = frames[b] -> frames[b+1]), as
+        NeuralSLAM walks a sequence; each frame passes through the feature network once. Returns (flow_low, flow_up)
+        exactly as `forward(frames[:-1], frames[1:], test_mode=True)` does."""
+        _require_gpu(frames, "RAFTGMA.forward_sequence")
+        if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[0] < 2:
+            raise RuntimeError("expected frames [B+1,3,H,W] with B >= 1, got %s" % (tuple(frames.shape),))
+        if self.precision != "split_f16":
+            return self.forward(frames[:-1], frames[1:], iters=iters, flow_init=flow_init, test_mode=True)
+        B, H, W = frames.shape[0] - 1, frames.shape[2], frames.shape[3]
+        with torch.cuda.device(frames.device):
+            fr = frames.float().contiguous()
+            fi = None
+            if flow_init is not None:
+                fi = flow_init.to(frames.device).float().contiguous()
+                if tuple(fi.shape) != (B, 2, H // 8, W // 8):
+                    raise RuntimeError("flow_init must be [B,2,H/8,W/8]")
+            flow_low = torch.empty((B, 2, H // 8, W // 8), dtype=torch.float32, device=frames.device)
+            flow_up = torch.empty((B, 2, H, W), dtype=torch.float32, device=frames.device)
+            h = self._handle(H, W, B)
+            _lib.check(_lib.lib().atdn_gma_forward_sequence(h, _ptr(fr), B, int(iters), _ptr(fi), _ptr(flow_low),
+                                                            _ptr(flow_up), _stream()))
+        return flow_low, flow_up
+
     def debug_read(self, name, shape, H, W):
         """Copy an internal activation of the (H, W) handle to a CPU tensor (parity tests)."""
         out = torch.empty(shape, dtype=torch.float32)

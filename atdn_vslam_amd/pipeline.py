@@ -47,6 +47,14 @@ class OdometryPipeline:
         return self.head.encode(flow), flow
 
     @torch.no_grad()
+    def features_clip(self, frames):
+        """frames [B+1,3,H,W]: B consecutive pairs of one clip -> (feat [B,512], flow_up [B,2,H,W]); the shared
+        frames go through the feature network once (RAFTGMA.forward_sequence)."""
+        frames = self.padder.pad(frames)[0]
+        _, flow = self.flow_net.forward_sequence(frames, iters=self.iters)
+        return self.head.encode(flow), flow
+
+    @torch.no_grad()
     def scan(self, feats):
         """feats [P,512] in sequence order -> (rot [P,3], tr [P,3]) from a zero LSTM state."""
         rot, tr, _ = self.head.scan(feats[:, None, :], hw=self.size)
@@ -62,7 +70,7 @@ class OdometryPipeline:
             out = []
             for s in range(lo, hi, batch):
                 e = min(s + batch, hi)
-                f, _ = self.features(frames[s:e], frames[s + 1:e + 1])
+                f, _ = self.features_clip(frames[s:e + 1])
                 out.append(f)
             return torch.cat(out) if out else torch.zeros((0, 512), device=self.device)
 

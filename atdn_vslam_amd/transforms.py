@@ -73,6 +73,8 @@ class InputPadder:
             self._pad = [pw // 2, pw - pw // 2, 0, ph]
 
     def pad(self, *inputs):
+        if not any(self._pad):  # 376x1232: nothing to pad (neural_slam.py:54) — skip the copy
+            return list(inputs)
         return [torch.nn.functional.pad(x, self._pad, mode="replicate") for x in inputs]
 
     def unpad(self, x):

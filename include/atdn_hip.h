@@ -54,14 +54,21 @@ int atdn_gma_finalize(atdn_gma* h);
 int atdn_gma_forward(atdn_gma* h, const float* im1, const float* im2, int B, int iters, const float* flow_init,
                      float* flow_low, float* flow_up, void* stream);
 
+/* The same for B consecutive pairs of one clip, as NeuralSLAM walks a sequence (neural_slam.py:196-217: frame t is
+ * image2 of pair t-1 and image1 of pair t): frames [B+1,3,H,W]; pair b = (frames[b], frames[b+1]). The feature
+ * network runs once per frame instead of twice. Split-f16 handles only. */
+int atdn_gma_forward_sequence(atdn_gma* h, const float* frames, int B, int iters, const float* flow_init,
+                              float* flow_low, float* flow_up, void* stream);
+
 /* Copies an internal activation to a HOST buffer for parity tests ("fmap", "pyr0".."pyr3", "attn", "net",
  * "x", "corrfeat", "mask", "coords1", "flow4", "qk", "img4"). Returns the number of floats copied, -1 on error. */
 long atdn_gma_debug_read(atdn_gma* h, const char* name, float* host, long capacity, void* stream);
 
 /* Per-stage device time (ms, summed over `reps` eager forwards of batch B), measured with HIP events on
  * `stream`. ms_out has ATDN_GMA_STAGES entries: fnet, corr, pool, cnet, attention, lookup, motion_encoder,
- * aggregate, gru_zr (fused z|r convolution), gru_q, flow_head, mask. */
-#define ATDN_GMA_STAGES 12
+ * aggregate, gru_zr (fused z|r convolution), gru_q, flow_head, mask, gru_ctx (once-per-pair context part of the
+ * GRU convolutions; split-f16 pipeline only). */
+#define ATDN_GMA_STAGES 13
 int atdn_gma_profile(atdn_gma* h, int B, int iters, int reps, float* ms_out, void* stream);
 
 size_t atdn_gma_workspace_bytes(atdn_gma* h);

@@ -274,6 +274,17 @@ def test_gma_c2_kitti_size_matches_golden_and_is_batch_invariant(golden_dir, gsd
     assert not torch.equal(low1, lown)
 
 
+def test_gma_sequence_mode_equals_pair_mode(flow_net):
+    """forward_sequence shares the feature pass of the frame two consecutive pairs have in common; results must
+    be those of the pair-by-pair call."""
+    fr = torch.from_numpy(syn.make_frames(3, 160, 512, seed=33)).to(DEV)
+    low_p, up_p = flow_net(fr[0:2], fr[1:3], iters=4, test_mode=True)
+    low_s, up_s = flow_net.forward_sequence(fr, iters=4)
+    assert torch.equal(up_p, up_s) and torch.equal(low_p, low_s)
+    with pytest.raises(RuntimeError):
+        flow_net.forward_sequence(fr[:1])
+
+
 def test_gma_flow_init_matches_oracle(gsd, flow_net):
     from oracle import gma_ref
     fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=21))
