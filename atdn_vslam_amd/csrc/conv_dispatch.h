@@ -18,7 +18,7 @@ inline TileChoice choose_tile(int nimg, int HoWo, int N) {
   if (N % 96 == 0 && N % 64 != 0) return {128, 96};
   const long t128 = (long)nimg * cdiv(HoWo, 128);
   const int pad128 = round_up(N, 128) - N;
-  if (N >= 128 && pad128 * 20 <= N && t128 * cdiv(N, 128) >= 512) return {128, 128};
+  if (N >= 128 && pad128 * 20 <= N && t128 * cdiv(N, 128) >= 400) return {128, 128};
   if (t128 * cdiv(N, 64) >= 384) return {128, 64};
   return {64, 64};
 }
