@@ -3,6 +3,7 @@
 #include "conv_dispatch_impl.h"
 #include "conv_sf.h"
 #include "conv_sf2.h"
+#include "conv_sf3.h"
 #include "epilogues_sf.h"
 
 namespace atdn {
@@ -15,8 +16,13 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
     // halo-patch kernel: 8x16 output tiles; 128-wide N tiles once they still fill the chip
     const int tiles = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
     TileChoice t2{128, 64, cdiv(Wo, 16) * cdiv(Ho, 8) * 4, true};
-    if (s.N > 64 && (long)tiles * cdiv(s.N, 128) >= 400) { t2.BN = 128; launch_conv_sf2<2>(s, wscale, ep, st); }
-    else launch_conv_sf2<1>(s, wscale, ep, st);
+    // generation 3 (warp-specialised producers/consumers) measures within 2 % of generation 2 on every layer
+    // (tools/microbench_conv.py); generation 2 stays the default, ATDN_CONV_GEN=3 selects the other
+    static const bool gen3 = getenv("ATDN_CONV_GEN") && getenv("ATDN_CONV_GEN")[0] == '3';
+    const bool wide = s.N > 64 && (long)tiles * cdiv(s.N, 128) >= 400;
+    if (wide) t2.BN = 128;
+    if (gen3) { if (wide) launch_conv_sf3<2>(s, wscale, ep, st); else launch_conv_sf3<1>(s, wscale, ep, st); }
+    else      { if (wide) launch_conv_sf2<2>(s, wscale, ep, st); else launch_conv_sf2<1>(s, wscale, ep, st); }
     return t2;
   }
   TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);
