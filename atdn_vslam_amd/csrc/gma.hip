@@ -471,8 +471,12 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   conv_sf_dispatch(s, convm_.wscale, SfBias<ACT_RELU>{convm_.b, mf, (long)N * XLD, XLD}, st);
   mark(ST_MOTION, st);
 
-  s = conv_shape(to_v_, mf, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
-  conv_sf_dispatch(s, to_v_.wscale, SfStoreT{vT_.p, (long)128 * ldN, ldN}, st);
+  // v^T [128][pixels] directly: the projection matrix is the A operand (128 rows), the motion features are the
+  // K-contiguous "weight" rows, so the sf store runs along pixels (no transposed 2-byte scatter)
+  ConvShape v;
+  v.src0 = to_v_.w; v.ld0 = 128; v.sb0 = 0; v.C0 = 128; v.H = 1; v.W = 128;
+  v.w = mf; v.wb = (long)N * XLD; v.ldw = XLD; v.N = N; v.nimg = B;
+  conv_sf_dispatch(v, to_v_.wscale, SfBias<ACT_NONE>{nullptr, vT_.p, (long)128 * ldN, ldN}, st);
   ConvShape a;
   a.src0 = attn_.p; a.ld0 = ldN; a.sb0 = (long)N * ldN; a.C0 = ldN; a.H = 1; a.W = N;
   a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;

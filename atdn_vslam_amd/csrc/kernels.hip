@@ -617,17 +617,22 @@ void launch_in_apply_sf(const float* x, float* y, const float* mean, const float
   ATDN_HIP(hipGetLastError());
 }
 
-// Lookup with the sample arithmetic of lookup_kernel; the 4 waves (levels) of a block stage the pixel's 324
-// samples in LDS and the block stores the 352-channel sf row (11 groups of [32 hi | 32 lo]) as dwords.
+// Lookup with the sample arithmetic of lookup_kernel. The 4 waves (levels) of a block stage the pixel's windows and
+// its 324 samples in LDS and the block stores the 352-channel sf row (11 groups of [32 hi | 32 lo]) as dwords.
+// The un-normalised coordinate of sample (i, j) separates into an x part that depends on i only and a y part that
+// depends on j only, so lanes 0-17 evaluate the 9 + 9 coordinate chains (with the reference's divisions) once per
+// level instead of 81 times. (One-wave-per-pixel forms, with all four levels in one wave, measured 13-25 % slower:
+// the kernel is bound by the scattered 48-byte window segments, not by pixels in flight.)
 __global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr, const float* __restrict__ coords1,
                                                         long npix, float* __restrict__ out, int ldo) {
   __shared__ float win[4][LK_WIN * LK_WIN + 16];
   __shared__ float vals[352];
+  __shared__ float wgt[4][18];   // fractional weight of the 9 x positions then the 9 y positions
+  __shared__ int idx[4][18];     // window column / row of their floor()
   const int lvl = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int Hl = pyr.H[lvl], Wl = pyr.W[lvl];
   const float inv = 1.0f / (float)(1 << lvl);
   const float wm1 = (float)(Wl - 1), hm1 = (float)(Hl - 1);
-  const float sfx = wm1 / 2.f, sfy = hm1 / 2.f;
   float* w = win[lvl];
   if (threadIdx.x >= 324 - 256 && threadIdx.x < 352 - 256) vals[256 + threadIdx.x] = 0.f;  // pad channels 324..351
   for (long p = blockIdx.x; p < npix; p += gridDim.x) {
@@ -642,8 +647,20 @@ __global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr,
         const int wy = c / LK_WIN, wx = c - wy * LK_WIN;
         const int y = wy0 + wy, x = wx0 + wx;
         const bool ok = ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
-        w[c] = ok ? src[(long)y * Wl + x] : 0.f;
+        const float v = src[ok ? (long)y * Wl + x : 0];
+        w[c] = ok ? v : 0.f;
       }
+    }
+    if (lane < 18) {
+      const bool isx = lane < 9;
+      const int d = isx ? lane : lane - 9;
+      const float c0 = isx ? xc : yc, sz1 = isx ? wm1 : hm1;
+      const float pos = c0 + (float)(d - 4);
+      const float g = 2.f * pos / sz1 - 1.f;
+      const float u = (g + 1.f) * (sz1 / 2.f);
+      const float fl = floorf(u);
+      wgt[lvl][lane] = u - fl;
+      idx[lvl][lane] = sane ? min(max((int)fl - (isx ? wx0 : wy0), 0), LK_WIN - 2) : 0;
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -652,22 +669,14 @@ __global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr,
       const int k = lane + 64 * t;
       if (k < 81) {
         const int i = k / 9, j = k - i * 9;
-        float v = 0.f;
-        if (sane) {
-          const float px = xc + (float)(i - 4), py = yc + (float)(j - 4);
-          const float xg = 2.f * px / wm1 - 1.f, yg = 2.f * py / hm1 - 1.f;
-          const float ix = (xg + 1.f) * sfx, iy = (yg + 1.f) * sfy;
-          const float xw = floorf(ix), yn = floorf(iy);
-          const float ww = ix - xw, ee = 1.f - ww, nn = iy - yn, ss = 1.f - nn;
-          const int lx = min(max((int)xw - wx0, 0), LK_WIN - 2), ly = min(max((int)yn - wy0, 0), LK_WIN - 2);
-          const float* q = w + ly * LK_WIN + lx;
-          v = ((q[0] * (ee * ss) + q[1] * (ww * ss)) + q[LK_WIN] * (ee * nn)) + q[LK_WIN + 1] * (ww * nn);
-        }
-        vals[lvl * 81 + k] = v;
+        const float ww = wgt[lvl][i], nn = wgt[lvl][9 + j];
+        const float ee = 1.f - ww, ss = 1.f - nn;
+        const float* q = w + idx[lvl][9 + j] * LK_WIN + idx[lvl][i];
+        const float v = ((q[0] * (ee * ss) + q[1] * (ww * ss)) + q[LK_WIN] * (ee * nn)) + q[LK_WIN + 1] * (ww * nn);
+        vals[lvl * 81 + k] = sane ? v : 0.f;
       }
     }
     __syncthreads();
-    // 352 dwords per row: dword d -> group d/32, word w = d%32: w<16 -> hi halves of channels 2w,2w+1; else lo halves
     unsigned* orow = reinterpret_cast<unsigned*>(out + p * ldo);
     for (int d = threadIdx.x; d < 352; d += 256) {
       const int g = d >> 5, ww = d & 31;
@@ -684,28 +693,42 @@ __global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr,
 void launch_lookup_sf(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
                       hipStream_t st) {
   ATDN_CHECK(ldo == 352, "sf lookup rows are 352 channels (11 groups)");
-  const int grid = (int)std::min<long>(npix_total, 256 * 16);
+  const int grid = (int)std::min<long>(npix_total, 256 * 32);
   hipLaunchKernelGGL(lookup_sf_kernel, dim3(grid), dim3(256), 0, st, pyr, coords1, npix_total, out, ldo);
   ATDN_HIP(hipGetLastError());
 }
 
+// Row staged once in LDS (the fp32 logits are read from HBM a single time), then max / sum / normalise from LDS.
+constexpr int SOFTMAX_LDS_MAX = 12288;  // floats (48 KB): rows up to 12288 columns take the single-read path
 __global__ __launch_bounds__(256) void softmax_rows_sf_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
-                                                              int ld) {
+                                                              int ld, int staged) {
   __shared__ float sm[4];
+  extern __shared__ float rowbuf[];
   const float* row = x + (long)blockIdx.x * ld;
   float* orow = y + (long)blockIdx.x * ld;
   float mx = -INFINITY;
-  for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, row[i]);
-  mx = block_reduce<true>(mx, sm);
+  if (staged) {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {  // ld % 32 == 0: float4 reads stay inside the padded row
+      const float4 v = *reinterpret_cast<const float4*>(row + i);
+      *reinterpret_cast<float4*>(rowbuf + i) = v;
+      mx = fmaxf(mx, v.x);
+      if (i + 1 < n) mx = fmaxf(mx, v.y);
+      if (i + 2 < n) mx = fmaxf(mx, v.z);
+      if (i + 3 < n) mx = fmaxf(mx, v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, row[i]);
+  }
+  mx = block_reduce<true>(mx, sm);  // (contains the barrier that publishes rowbuf)
+  const float* src = staged ? rowbuf : row;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += expf(row[i] - mx);
+  for (int i = threadIdx.x; i < n; i += 256) s += expf(src[i] - mx);
   s = block_reduce<false>(s, sm);
-  // pairs of adjacent columns -> one dword in the hi plane and one in the lo plane
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   for (int i2 = threadIdx.x; i2 < ld / 2; i2 += 256) {
     const int c = 2 * i2;
-    const float a = (c < n) ? expf(row[c] - mx) / s : 0.f;
-    const float b = (c + 1 < n) ? expf(row[c + 1] - mx) / s : 0.f;
+    const float a = (c < n) ? expf(src[c] - mx) / s : 0.f;
+    const float b = (c + 1 < n) ? expf(src[c + 1] - mx) / s : 0.f;
     const SfPair pa = sf_split(a), pb = sf_split(b);
     _Float16* q = sf_ptr(orow, 0, c);
     h2 hi = {pa.hi, pb.hi}, lo = {pa.lo, pb.lo};
@@ -715,7 +738,9 @@ __global__ __launch_bounds__(256) void softmax_rows_sf_kernel(const float* __res
 }
 void launch_softmax_rows_sf(const float* x, float* y, long rows, int n, int ld, hipStream_t st) {
   ATDN_CHECK(ld % 32 == 0, "sf rows need ld % 32 == 0");
-  hipLaunchKernelGGL(softmax_rows_sf_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, y, n, ld);
+  const int staged = (ld <= SOFTMAX_LDS_MAX) ? 1 : 0;
+  hipLaunchKernelGGL(softmax_rows_sf_kernel, dim3((unsigned)rows), dim3(256), staged ? (size_t)ld * sizeof(float) : 0, st,
+                     x, y, n, ld, staged);
   ATDN_HIP(hipGetLastError());
 }
 
