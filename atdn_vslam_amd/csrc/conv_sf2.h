@@ -25,18 +25,31 @@ struct Conv2Geom {
   float wscale;
 };
 
-constexpr int C2_PATCH_MAX = 192;  // pixels: 8x16 tile with 3x3 (180), 1x5 (160), 5x1 (192)
+// patch pixels an TH x TW output tile needs for the supported filters (3x3, 1x5, 5x1): 8x16 -> 192, 16x16 -> 324
+constexpr int c2_patch_max(int TH, int TW) {
+  int a = (TH + 2) * (TW + 2), b = TH * (TW + 4), c = (TH + 4) * TW;
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+constexpr int C2_PATCH_MAX = c2_patch_max(8, 16);
 
+// An M tile is TH x TW output pixels handled by TH*TW/32 row-tiles: TH*TW/64 x 2 waves (2 x TN MFMA tiles each),
+// NT = TH*TW*2 threads. 8x16 (256 threads, 2 blocks per CU) for small grids; 16x16 (512 threads, 1 block per CU)
+// halves the weight-tile traffic per FLOP — with 128x128 tiles the loop needs the whole L2 gather bandwidth
+// (27 B/clk/CU at full matrix rate), which is what bounds it.
 template <int TH, int TW, int TN, class Epi>
-__global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const Epi ep) {
-  static_assert(TH * TW == 128, "M tile is 128 output pixels");
+__global__ __launch_bounds__(TH * TW * 2) void conv_sf2_kernel(const Conv2Geom g, const Epi ep) {
+  static_assert((TH * TW) % 128 == 0, "M tile is a multiple of 128 output pixels");
+  constexpr int NT = TH * TW * 2;
+  constexpr int RSTEP = NT / 8;                  // LDS rows covered by one pass of the loader threads
+  constexpr int PMAX = c2_patch_max(TH, TW);
   constexpr int BN = 64 * TN;
-  constexpr int RB = BN / 32;                    // weight float4 per thread per step
-  constexpr int NP = (C2_PATCH_MAX * 8 + 255) / 256;  // patch float4 per thread per chunk
+  constexpr int RB = BN / RSTEP;                 // weight float4 per thread per step
+  static_assert(RB >= 1 && BN % RSTEP == 0, "weight tile must be a whole number of loader passes");
+  constexpr int NP = (PMAX + RSTEP - 1) / RSTEP; // patch float4 per thread per chunk
   constexpr int ROWB = LDS_LD * 4;
-  __shared__ __attribute__((aligned(16))) float lds[(C2_PATCH_MAX + 2 * BN) * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float lds[(PMAX + 2 * BN) * LDS_LD];
   float* Ps = lds;
-  float* Ws = lds + C2_PATCH_MAX * LDS_LD;
+  float* Ws = lds + PMAX * LDS_LD;
 
   const int tid = threadIdx.x;
   const int tiles_img = g.tiles_x * g.tiles_y;
@@ -55,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const 
   int poff[NP];  // input pixel index of this thread's patch rows, -1 = zero padding / unused
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    const int prow = r0 + 32 * k;
+    const int prow = r0 + RSTEP * k;
     int off = -1;
     if (prow < npatch) {
       const int py = prow / g.PW, px = prow - py * g.PW;
@@ -90,18 +103,18 @@ __global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const 
     const int q = tap * nck + c;
 #pragma unroll
     for (int j = 0; j < RB; ++j)
-      wr[j] = *reinterpret_cast<const float4*>(wbase + (long)min(nrow0 + 32 * j, g.N - 1) * g.ldw + q * 32);
+      wr[j] = *reinterpret_cast<const float4*>(wbase + (long)min(nrow0 + RSTEP * j, g.N - 1) * g.ldw + q * 32);
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int k = 0; k < NP; ++k)
-      if (r0 + 32 * k < C2_PATCH_MAX)
-        *reinterpret_cast<float4*>(Ps + (r0 + 32 * k) * LDS_LD + 4 * s) = keep_if(poff[k] >= 0, pr[k]);
+      if (r0 + RSTEP * k < PMAX)
+        *reinterpret_cast<float4*>(Ps + (r0 + RSTEP * k) * LDS_LD + 4 * s) = keep_if(poff[k] >= 0, pr[k]);
   };
   auto store_w = [&](const float4 (&wr)[RB], int buf) {
 #pragma unroll
     for (int j = 0; j < RB; ++j)
-      *reinterpret_cast<float4*>(Ws + (buf * BN + r0 + 32 * j) * LDS_LD + 4 * s) = keep_if(nrow0 + 32 * j < g.N, wr[j]);  // the select also gives the
+      *reinterpret_cast<float4*>(Ws + (buf * BN + r0 + RSTEP * j) * LDS_LD + 4 * s) = keep_if(nrow0 + RSTEP * j < g.N, wr[j]);  // the select also gives the
       // LDS store its own source registers: storing straight from wr[] makes the refill of wr[] (issued right
       // after) wait for the store to drain (measured: -28 % whole-forward throughput)
   };
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const 
         for (int e = 0; e < 16; ++e)
           if (mm[e] >= 0) { const float d = v[e] - mean; m2 += d * d; }
         m2 += __shfl_xor(m2, 32);
-        const int grp = tloc * 4 + wm * 2 + i;
+        const int grp = tloc * (TH * TW / 32) + wm * 2 + i;
         if (h == 0 && nok) {
           const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
           ep.part_sum[o] = sum;
@@ -242,12 +255,13 @@ __global__ __launch_bounds__(256) void conv_sf2_kernel(const Conv2Geom g, const 
 inline bool conv_sf2_eligible(const ConvShape& s) {
   if (s.stride != 1 || s.KH * s.KW == 1 || s.wb != 0) return false;
   const int PH = 8 + s.KH - 1, PW = 16 + s.KW - 1;
-  return PH * PW <= C2_PATCH_MAX;
+  const int PH2 = 16 + s.KH - 1, PW2 = 16 + s.KW - 1;
+  return PH * PW <= c2_patch_max(8, 16) && PH2 * PW2 <= c2_patch_max(16, 16);
 }
 
-template <int TN, class Epi>
+template <int TN, class Epi, int TH = 8>
 inline void launch_conv_sf2(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
-  constexpr int TH = 8, TW = 16;
+  constexpr int TW = 16;
   Conv2Geom g{};
   g.src0 = s.src0; g.src1 = s.src1; g.sb0 = s.sb0; g.sb1 = s.sb1; g.ld0 = s.ld0; g.ld1 = s.ld1;
   g.C0 = s.C0; g.C1 = s.C1; g.H = s.H; g.W = s.W;
@@ -260,9 +274,9 @@ inline void launch_conv_sf2(const ConvShape& s, float wscale, Epi ep, hipStream_
   g.tiles_x = cdiv(g.Wo, TW); g.tiles_y = cdiv(g.Ho, TH);
   g.nimg = s.nimg; g.ntile_n = cdiv(s.N, 64 * TN);
   g.w = s.w; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;
-  set_groups(ep, g.tiles_x * g.tiles_y * 4);
+  set_groups(ep, g.tiles_x * g.tiles_y * (TH * TW / 32));
   const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf2_kernel<TH, TW, TN, Epi>), dim3(nblk), dim3(256), 0, st, g, ep);
+  hipLaunchKernelGGL((conv_sf2_kernel<TH, TW, TN, Epi>), dim3(nblk), dim3(TH * TW * 2), 0, st, g, ep);
   ATDN_HIP(hipGetLastError());
 }
 

@@ -13,11 +13,17 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
   const int Ho = conv_out(s.H, s.KH, s.stride, s.padH), Wo = conv_out(s.W, s.KW, s.stride, s.padW);
   static const bool use_v2 = !(getenv("ATDN_NO_HALO") && getenv("ATDN_NO_HALO")[0] == '1');
   if (use_v2 && conv_sf2_eligible(s)) {
-    // halo-patch kernel: 8x16 output tiles; 128-wide N tiles once they still fill the chip
+    // halo-patch kernel. 16x16 output tiles x 128 channels (512 threads, half the weight traffic per FLOP) when
+    // that grid still covers the chip, else 8x16 tiles with 128- or 64-wide N tiles.
+    static const int big_min = getenv("ATDN_BIG_TILE_MIN") ? atoi(getenv("ATDN_BIG_TILE_MIN")) : 224;
+    const int tiles16 = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 16);
+    if (s.N > 64 && (long)tiles16 * cdiv(s.N, 128) >= big_min) {
+      TileChoice t3{256, 128, cdiv(Wo, 16) * cdiv(Ho, 16) * 8, true};
+      launch_conv_sf2<2, Epi, 16>(s, wscale, ep, st);
+      return t3;
+    }
     const int tiles = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
     TileChoice t2{128, 64, cdiv(Wo, 16) * cdiv(Ho, 8) * 4, true};
-    // generation 3 (warp-specialised producers/consumers) measures within 2 % of generation 2 on every layer
-    // (tools/microbench_conv.py); generation 2 stays the default, ATDN_CONV_GEN=3 selects the other
     static const bool gen3 = getenv("ATDN_CONV_GEN") && getenv("ATDN_CONV_GEN")[0] == '3';
     const bool wide = s.N > 64 && (long)tiles * cdiv(s.N, 128) >= 400;
     if (wide) t2.BN = 128;
