@@ -37,6 +37,8 @@ class ClvoNet {
   Lin pack_linear(const std::string& wkey, const std::string& bkey, const std::vector<int>* perm = nullptr);
 
   DeviceBuf in4_, bufA_, bufB_, bufS_, flat_, gates_, x2_;
+  DeviceBuf pre_, hseq_, x2seq_;  // scan scratch, grown on demand: [T*Bs][2048], [(T+1)*Bs][512], [T*Bs][512]
+  void ensure_scan(long rows, int Bs);
 };
 
 }  // namespace atdn

@@ -7,6 +7,7 @@ namespace atdn {
 extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
 extern template TileChoice conv_dispatch<MODE_ROW, EpiMishBN>(const ConvShape&, EpiMishBN, hipStream_t);
 extern template TileChoice conv_dispatch<MODE_ROW, EpiMishBNSkipMishBN>(const ConvShape&, EpiMishBNSkipMishBN, hipStream_t);
+extern template TileChoice conv_dispatch<MODE_TAP, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
 
 ClvoNet::ClvoNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) {
   ATDN_CHECK(max_batch >= 1 && max_batch <= 256, "max_batch out of range");
@@ -22,7 +23,7 @@ ClvoNet::ClvoNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) 
 }
 
 ClvoNet::~ClvoNet() {
-  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &gates_, &x2_}) b->release();
+  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &gates_, &x2_, &pre_, &hseq_, &x2seq_}) b->release();
   arena_.release();
 }
 
@@ -134,21 +135,44 @@ void ClvoNet::encode(const float* flow, int B, float* feat, hipStream_t st) {
   launch_linear(fc_.w, flat_.p, 832, 832, nullptr, nullptr, 0, 0, fc_.b, nullptr, 1, feat, 512, 512, B, st);
 }
 
+void ClvoNet::ensure_scan(long rows, int Bs) {
+  if (pre_.n < rows * 2048) { pre_.release(); pre_.alloc(rows * 2048); }
+  if (hseq_.n < (rows + Bs) * 512) { hseq_.release(); hseq_.alloc((rows + Bs) * 512); }
+  if (x2seq_.n < rows * 512) { x2seq_.release(); x2seq_.alloc(rows * 512); }
+}
+
+// The recurrence of odometry/network.py:137-140 restructured so that only what is truly sequential stays in the
+// per-step loop. lstm1 does not depend on lstm2, so: (1) input projections of ALL steps in one MFMA GEMM,
+// (2) scan 1: one fused kernel per step (W_hh·h + gates + cell), (3) lstm_linear + lstm2 input projection batched
+// over all steps, (4) scan 2, (5) both regressors batched. 2 small launches per step instead of 6.
 void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, float* tr, hipStream_t st) {
   ATDN_CHECK(ready_, "weights not finalized");
   ATDN_CHECK(Bs >= 1 && Bs <= maxB && T >= 1, "bad sequence shape");
+  const long rows = (long)T * Bs;
+  ensure_scan(rows, Bs);
   float* h1 = state; float* c1 = state + (long)Bs * 512; float* h2 = state + 2L * Bs * 512; float* c2 = state + 3L * Bs * 512;
+  const long sb = (long)Bs * 512;
+  auto gemm = [&](const float* x, const Lin& L, float* y, int N) {  // y[rows][N] = x[rows][512]·W^T + b on the MFMA engine
+    ConvShape s;
+    s.src0 = x; s.ld0 = 512; s.sb0 = 0; s.C0 = 512; s.H = 1; s.W = (int)rows;
+    s.w = L.w; s.ldw = 512; s.N = N; s.nimg = 1;
+    conv_dispatch<MODE_TAP>(s, EpiBias<ACT_NONE>{L.b, y, 0, N, 1.f}, st);
+  };
+  auto scan = [&](const Lin& hh, float* h, float* c) {  // hseq_[0] = incoming h, hseq_[t+1] = h after step t
+    ATDN_HIP(hipMemcpyAsync(hseq_.p, h, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+    for (int t = 0; t < T; ++t)
+      launch_lstm_rec(pre_.p + (long)t * Bs * 2048, hh.w, hh.b, hseq_.p + t * sb, c, hseq_.p + (t + 1) * sb, Bs, 512, st);
+    ATDN_HIP(hipMemcpyAsync(h, hseq_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+  };
+  gemm(feat, lstm1_ih_, pre_.p, 2048);
+  scan(lstm1_hh_, h1, c1);
+  launch_linear(lstm_lin_.w, hseq_.p + sb, 512, 512, nullptr, nullptr, 0, 0, lstm_lin_.b, nullptr, 1, x2seq_.p, 512, 512,
+                (int)rows, st);
+  gemm(x2seq_.p, lstm2_ih_, pre_.p, 2048);
+  scan(lstm2_hh_, h2, c2);
   const MlpHead R{rot_[0].w, rot_[0].b, rot_[1].w, rot_[1].b, rot_[2].w};
   const MlpHead Tt{tr_[0].w, tr_[0].b, tr_[1].w, tr_[1].b, tr_[2].w};
-  for (int t = 0; t < T; ++t) {
-    const float* f = feat + (long)t * Bs * 512;
-    launch_linear(lstm1_ih_.w, f, 512, 512, lstm1_hh_.w, h1, 512, 512, lstm1_ih_.b, lstm1_hh_.b, 0, gates_.p, 2048, 2048, Bs, st);
-    launch_lstm_cell(gates_.p, c1, h1, Bs, 512, st);
-    launch_linear(lstm_lin_.w, h1, 512, 512, nullptr, nullptr, 0, 0, lstm_lin_.b, nullptr, 1, x2_.p, 512, 512, Bs, st);
-    launch_linear(lstm2_ih_.w, x2_.p, 512, 512, lstm2_hh_.w, h2, 512, 512, lstm2_ih_.b, lstm2_hh_.b, 0, gates_.p, 2048, 2048, Bs, st);
-    launch_lstm_cell(gates_.p, c2, h2, Bs, 512, st);
-    launch_mlp_heads(h2, Bs, R, Tt, rot + (long)t * Bs * 3, tr + (long)t * Bs * 3, st);
-  }
+  launch_mlp_heads(hseq_.p + sb, (int)rows, R, Tt, rot, tr, st);
 }
 
 }  // namespace atdn

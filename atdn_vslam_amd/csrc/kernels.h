@@ -52,6 +52,10 @@ void launch_linear(const float* W0, const float* x0, int K0, int ldx0, const flo
                    hipStream_t st);
 // LSTMCell pointwise part, gate order i,f,g,o; gates [B][4*Hd]; c in/out, h out
 void launch_lstm_cell(const float* gates, float* c, float* h, int B, int Hd, hipStream_t st);
+// One recurrent LSTM step with the input projection already done: gates = pre[b] + (Whh·h_in[b] + b_hh), then the
+// pointwise cell update (gate order i,f,g,o). One wave per hidden unit; h_out must not alias h_in.
+void launch_lstm_rec(const float* pre, const float* Whh, const float* bhh, const float* h_in, float* c, float* h_out,
+                     int B, int Hd, hipStream_t st);
 // both regressors (512 -> 128 -> 64 -> 3, Mish, last layer no bias): out rot [B][3], tr [B][3]
 struct MlpHead { const float *w0, *b0, *w1, *b1, *w2; };
 void launch_mlp_heads(const float* h2, int B, MlpHead rot, MlpHead tr, float* rot_out, float* tr_out, hipStream_t st);
