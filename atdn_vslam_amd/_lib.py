@@ -32,6 +32,7 @@ SIGNATURES = {
     "atdn_pose_transform_f32": (C.c_int, [_vp, _vp, _vp]),
     "atdn_pose_rel2abs": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "atdn_pose_accumulate_f32": (C.c_int, [_vp, _vp, _vp]),
+    "atdn_resize_frames": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "atdn_corr_lookup": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "atdn_corr_pyramid": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "atdn_conv2d_nhwc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,

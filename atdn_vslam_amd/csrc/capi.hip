@@ -37,6 +37,49 @@ struct atdn_clvo { ClvoNet net; atdn_clvo(int H, int W, int B) : net(H, W, B) {}
     return 1;                                             \
   }
 
+// ---- antialiased resize tables (ATen upsample_bilinear2d_aa weight computation, in fp32)
+namespace {
+struct ResizePlan { int Hin, Win, Hout, Wout; ResizeTable* ty = nullptr; ResizeTable* tx = nullptr; float* tmp = nullptr; long tmp_n = 0; };
+std::vector<ResizePlan> g_resize_plans;
+
+std::vector<ResizeTable> make_resize_table(int in, int out) {
+  std::vector<ResizeTable> tab(out);
+  const float scale = (float)in / (float)out;                  // area_pixel_compute_scale, align_corners = false
+  const float support = (scale >= 1.0f) ? 1.0f * scale : 1.0f; // interp_size (2) * 0.5 [* scale]
+  const float invscale = (scale >= 1.0f) ? 1.0f / scale : 1.0f;
+  for (int i = 0; i < out; ++i) {
+    const float center = scale * ((float)i + 0.5f);
+    int xmin = (int)(center - support + 0.5f); if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5f); if (xmax > in) xmax = in;
+    int size = xmax - xmin;
+    ATDN_CHECK(size >= 1 && size <= RESIZE_TAPS, "resize ratio outside the supported range (down-scaling by more than 3.5x)");
+    float total = 0.f;
+    ResizeTable t{};
+    t.start = xmin; t.count = size;
+    for (int j = 0; j < size; ++j) {
+      float x = ((float)(j + xmin) - center + 0.5f) * invscale;
+      if (x < 0.f) x = -x;
+      const float w = (x < 1.0f) ? 1.0f - x : 0.0f;
+      t.w[j] = w; total += w;
+    }
+    if (total != 0.f) for (int j = 0; j < size; ++j) t.w[j] /= total;
+    tab[i] = t;
+  }
+  return tab;
+}
+ResizePlan& resize_plan(int Hin, int Win, int Hout, int Wout) {
+  for (auto& p : g_resize_plans) if (p.Hin == Hin && p.Win == Win && p.Hout == Hout && p.Wout == Wout) return p;
+  ResizePlan p{Hin, Win, Hout, Wout};
+  auto ty = make_resize_table(Hin, Hout), tx = make_resize_table(Win, Wout);
+  ATDN_HIP(hipMalloc(&p.ty, ty.size() * sizeof(ResizeTable)));
+  ATDN_HIP(hipMalloc(&p.tx, tx.size() * sizeof(ResizeTable)));
+  ATDN_HIP(hipMemcpy(p.ty, ty.data(), ty.size() * sizeof(ResizeTable), hipMemcpyHostToDevice));
+  ATDN_HIP(hipMemcpy(p.tx, tx.data(), tx.size() * sizeof(ResizeTable), hipMemcpyHostToDevice));
+  g_resize_plans.push_back(p);
+  return g_resize_plans.back();
+}
+}  // namespace
+
 // host pose algebra helpers
 template <class T>
 static void euler_yxz(const T* r, T* R) {  // transforms.py:79-81
@@ -247,6 +290,20 @@ int atdn_conv2d_nhwc(const float* src, int nimg, int H, int W, int Cin, const fl
     throw;
   }
   A.release();
+  ATDN_API_END
+}
+
+int atdn_resize_frames(const float* src, int planes, int Hin, int Win, int Hout, int Wout, float* dst, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(src && dst && planes >= 1 && Hin >= 1 && Win >= 1 && Hout >= 1 && Wout >= 1, "bad argument");
+  ResizePlan& p = resize_plan(Hin, Win, Hout, Wout);
+  const long need = (Hin != Hout && Win != Wout) ? (long)planes * Hin * Wout : 0;
+  if (need > p.tmp_n) {
+    if (p.tmp) (void)hipFree(p.tmp);
+    ATDN_HIP(hipMalloc(&p.tmp, (size_t)need * sizeof(float)));
+    p.tmp_n = need;
+  }
+  launch_resize_aa(src, planes, Hin, Win, p.ty, p.tx, Hout, Wout, p.tmp, dst, (hipStream_t)stream);
   ATDN_API_END
 }
 

@@ -551,6 +551,50 @@ void launch_mlp_heads(const float* h2, int B, MlpHead rot, MlpHead tr, float* ro
   ATDN_HIP(hipGetLastError());
 }
 
+// one pass along x (axis == 1) or y (axis == 0); dst has the resized extent on that axis
+__global__ void resize_aa_kernel(const float* __restrict__ src, const ResizeTable* __restrict__ tab, int planes, int Hin,
+                                 int Win, int Hout, int Wout, int axis, float* __restrict__ dst) {
+  const long total = (long)planes * Hout * Wout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wout);
+    const long r = i / Wout;
+    const int y = (int)(r % Hout);
+    const long pl = r / Hout;
+    const ResizeTable t = tab[axis ? x : y];
+    const float* s = src + pl * (long)Hin * Win;
+    float acc = 0.f;
+    if (axis) {
+      const float* row = s + (long)y * Win + t.start;
+      for (int k = 0; k < t.count; ++k) acc += t.w[k] * row[k];
+    } else {
+      const float* col = s + (long)t.start * Win + x;
+      for (int k = 0; k < t.count; ++k) acc += t.w[k] * col[(long)k * Win];
+    }
+    dst[i] = acc;
+  }
+}
+void launch_resize_aa(const float* src, int planes, int Hin, int Win, const ResizeTable* ty, const ResizeTable* tx,
+                      int Hout, int Wout, float* tmp, float* dst, hipStream_t st) {
+  // ATen's separable antialias kernel interpolates the LAST dimension first (horizontal), then vertical
+  const long n1 = (long)planes * Hin * Wout, n2 = (long)planes * Hout * Wout;
+  const bool need_x = Win != Wout, need_y = Hin != Hout;
+  const float* cur = src;
+  if (need_x) {
+    float* out = need_y ? tmp : dst;
+    hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)std::min<long>(cdivl(n1, 256), 8192)), dim3(256), 0, st, cur, tx,
+                       planes, Hin, Win, Hin, Wout, 1, out);
+    ATDN_HIP(hipGetLastError());
+    cur = out;
+  }
+  if (need_y) {
+    hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)std::min<long>(cdivl(n2, 256), 8192)), dim3(256), 0, st, cur, ty,
+                       planes, Hin, Wout, Hout, Wout, 0, dst);
+    ATDN_HIP(hipGetLastError());
+  } else if (!need_x) {
+    ATDN_HIP(hipMemcpyAsync(dst, src, (size_t)n2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }

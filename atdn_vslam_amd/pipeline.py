@@ -16,12 +16,22 @@ SLAM_SIZE = (376, 1232)  # neural_slam.py:198
 
 
 def resize_frames(frames, size=SLAM_SIZE):
-    """torchvision's tensor resize (bilinear, antialias) as NeuralSLAM applies it (neural_slam.py:198,220)."""
-    lead = frames.dim() == 3
-    x = frames[None] if lead else frames
-    if tuple(x.shape[-2:]) != tuple(size):
-        x = F.interpolate(x.float(), size=list(size), mode="bilinear", align_corners=False, antialias=True)
-    return x[0] if lead else x
+    """torchvision's tensor resize (bilinear, antialias) as NeuralSLAM applies it (neural_slam.py:198,220), on the
+    GPU through libatdn_hip (atdn_resize_frames)."""
+    import ctypes as C
+    from . import _lib
+    if tuple(frames.shape[-2:]) == tuple(size):
+        return frames
+    if not frames.is_cuda:
+        raise RuntimeError("resize_frames: the MI355X path needs tensors on a HIP device")
+    x = frames.float().contiguous()
+    out = torch.empty(tuple(x.shape[:-2]) + tuple(size), dtype=torch.float32, device=x.device)
+    planes = int(x.numel() // (x.shape[-2] * x.shape[-1]))
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().atdn_resize_frames(C.c_void_p(x.data_ptr()), planes, x.shape[-2], x.shape[-1], size[0],
+                                                 size[1], C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
 
 
 class OdometryPipeline:

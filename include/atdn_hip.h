@@ -108,6 +108,14 @@ int atdn_pose_rel2abs(const float* rot, const float* tr, int T, double* poses);
 int atdn_pose_accumulate_f32(float* pose16, const float* rot, const float* tr);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Frame front-end  —  replaces TF.resize(im, (376, 1232)) (neural_slam.py:198,220)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* torchvision tensor resize = bilinear with antialiasing, align_corners = False: src [planes,Hin,Win] (planes = any
+ * product of leading dims, e.g. B*3) -> dst [planes,Hout,Wout]. Weight tables are cached per geometry. */
+int atdn_resize_frames(const float* src, int planes, int Hin, int Win, int Hout, int Wout, float* dst, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Individual kernels, exported for unit parity tests and roofline micro-benchmarks
  * ------------------------------------------------------------------------------------------------- */
 

@@ -304,6 +304,20 @@ def test_gma_module_contract(flow_net):
         flow_net(torch.zeros(1, 3, 161, 512, device=DEV), torch.zeros(1, 3, 161, 512, device=DEV), test_mode=True)
 
 
+def test_resize_matches_torchvision_semantics():
+    """NeuralSLAM resizes every frame to 376x1232 with torchvision's tensor resize = antialiased bilinear."""
+    from atdn_vslam_amd.pipeline import resize_frames
+    for (h, w), size in (((376, 1241), (376, 1232)), ((370, 1226), (376, 1232)), ((375, 1242), (376, 1232)),
+                         ((480, 1640), (376, 1232))):
+        fr = torch.from_numpy(syn.make_frames(2, h, w, seed=41))
+        ref = F.interpolate(fr, size=list(size), mode="bilinear", align_corners=False, antialias=True)
+        got = resize_frames(fr.to(DEV), size).cpu()
+        assert tuple(got.shape) == (2, 3) + size
+        assert _maxerr(got, ref) < 2e-4, ((h, w), _maxerr(got, ref))   # values 0..255
+    same = torch.rand(1, 3, 376, 1232, device=DEV)
+    assert resize_frames(same) is same
+
+
 # ----------------------------------------------------------------------------- CLVO head
 @pytest.fixture(scope="module")
 def hsd():
