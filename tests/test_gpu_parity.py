@@ -383,3 +383,31 @@ def test_flow_plus_head_end_to_end_matches_golden(golden_dir, flow_net, hsd):
     rot, tr = head(up)
     assert _maxerr(rot.cpu(), torch.from_numpy(g["rot"])) < 1e-5
     assert _maxerr(tr.cpu(), torch.from_numpy(g["tr"])) < 1e-5
+
+
+def test_visual_odometry_matches_neuralslam_golden(golden_dir, gsd, hsd):
+    """The frame-by-frame caller (resize -> flow -> head -> transform -> pose accumulation) against the poses the
+    reference's NeuralSLAM returned for the same 4 synthetic KITTI-sized frames (tests/golden/slam.npz)."""
+    from atdn_vslam_amd.pipeline import VisualOdometry
+    g = np.load(os.path.join(golden_dir, "slam.npz"))
+    frames = torch.from_numpy(syn.make_frames(4, 376, 1241, seed=int(g["seed_frames"])))
+    vo = VisualOdometry(gsd, hsd, device=DEV)
+    for i in range(4):
+        pose = vo(frames[i])
+        assert pose.dtype == torch.float32 and tuple(pose.shape) == (4, 4)
+        assert _maxerr(pose, torch.from_numpy(g["poses"][i])) < 2e-5, i
+    vo.reset()
+    assert torch.equal(vo(frames[0]), torch.eye(4))
+
+
+def test_sequence_pipeline_matches_frame_by_frame(gsd, hsd):
+    """OdometryPipeline.run_sequence (clip batches + one ordered scan) == VisualOdometry frame by frame."""
+    from atdn_vslam_amd.pipeline import OdometryPipeline, VisualOdometry, resize_frames
+    frames = torch.from_numpy(syn.make_frames(6, 376, 1241, seed=12)).to(DEV)
+    pipe = OdometryPipeline(gsd, hsd, device=DEV, max_batch=3)
+    poses = pipe.run_sequence(resize_frames(frames), batch=3)
+    assert poses.dtype == torch.float64 and tuple(poses.shape) == (6, 4, 4)
+    vo = VisualOdometry(gsd, hsd, device=DEV)
+    for i in range(6):
+        p = vo(frames[i])
+    assert _maxerr(poses[-1].float(), p) < 5e-5   # fp64 vs fp32 pose accumulation
