@@ -4,6 +4,7 @@
 #include "conv_sf.h"
 #include "conv_sf2.h"
 #include "conv_sf3.h"
+#include "conv_sf4.h"
 #include "epilogues_sf.h"
 
 namespace atdn {
@@ -15,20 +16,24 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
   if (use_v2 && conv_sf2_eligible(s)) {
     // halo-patch kernel. 16x16 output tiles x 128 channels (512 threads, half the weight traffic per FLOP) when
     // that grid still covers the chip, else 8x16 tiles with 128- or 64-wide N tiles.
+    // generation 4 (weights by LDS-DMA) is the default; ATDN_CONV_GEN=2 (register-staged weights) and =3 (warp-
+    // specialised) select the other kernels, all within a few % of each other (tools/microbench_conv.py)
+    static const int gen = getenv("ATDN_CONV_GEN") ? atoi(getenv("ATDN_CONV_GEN")) : 4;
     static const int big_min = getenv("ATDN_BIG_TILE_MIN") ? atoi(getenv("ATDN_BIG_TILE_MIN")) : 224;
     const int tiles16 = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 16);
     if (s.N > 64 && (long)tiles16 * cdiv(s.N, 128) >= big_min) {
       TileChoice t3{256, 128, cdiv(Wo, 16) * cdiv(Ho, 16) * 8, true};
-      launch_conv_sf2<2, Epi, 16>(s, wscale, ep, st);
+      if (gen == 2) launch_conv_sf2<2, Epi, 16>(s, wscale, ep, st);
+      else launch_conv_sf4<2, Epi, 16>(s, wscale, ep, st);
       return t3;
     }
     const int tiles = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
     TileChoice t2{128, 64, cdiv(Wo, 16) * cdiv(Ho, 8) * 4, true};
-    static const bool gen3 = getenv("ATDN_CONV_GEN") && getenv("ATDN_CONV_GEN")[0] == '3';
     const bool wide = s.N > 64 && (long)tiles * cdiv(s.N, 128) >= 400;
     if (wide) t2.BN = 128;
-    if (gen3) { if (wide) launch_conv_sf3<2>(s, wscale, ep, st); else launch_conv_sf3<1>(s, wscale, ep, st); }
-    else      { if (wide) launch_conv_sf2<2>(s, wscale, ep, st); else launch_conv_sf2<1>(s, wscale, ep, st); }
+    if (gen == 3)      { if (wide) launch_conv_sf3<2>(s, wscale, ep, st); else launch_conv_sf3<1>(s, wscale, ep, st); }
+    else if (gen == 2) { if (wide) launch_conv_sf2<2>(s, wscale, ep, st); else launch_conv_sf2<1>(s, wscale, ep, st); }
+    else               { if (wide) launch_conv_sf4<2>(s, wscale, ep, st); else launch_conv_sf4<1>(s, wscale, ep, st); }
     return t2;
   }
   TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);

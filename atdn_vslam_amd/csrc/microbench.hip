@@ -46,8 +46,30 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
     us_out[1] = time_sf3<1>(s, ep, reps, st);
     us_out[2] = time_sf3<3>(s, ep, reps, st);
     us_out[3] = time_sf3<7>(s, ep, reps, st);
-    us_out[4] = time_sf3<15>(s, ep, reps, st);
-    us_out[5] = time_sf3<4>(s, ep, reps, st);
+    {  // generation 4, 16x16 tiles
+      hipEvent_t a, b;
+      ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
+      launch_conv_sf4<2, SfBias<ACT_RELU>, 16>(s, 1.f, ep, st);
+      ATDN_HIP(hipEventRecord(a, st));
+      for (int i = 0; i < reps; ++i) launch_conv_sf4<2, SfBias<ACT_RELU>, 16>(s, 1.f, ep, st);
+      ATDN_HIP(hipEventRecord(b, st));
+      ATDN_HIP(hipEventSynchronize(b));
+      float ms = 0.f;
+      ATDN_HIP(hipEventElapsedTime(&ms, a, b));
+      us_out[4] = ms * 1000.f / reps;
+    }
+    {  // generation 4: weight tiles by LDS-DMA, 8x16 tiles
+      hipEvent_t a, b;
+      ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
+      launch_conv_sf4<2, SfBias<ACT_RELU>, 8>(s, 1.f, ep, st);
+      ATDN_HIP(hipEventRecord(a, st));
+      for (int i = 0; i < reps; ++i) launch_conv_sf4<2, SfBias<ACT_RELU>, 8>(s, 1.f, ep, st);
+      ATDN_HIP(hipEventRecord(b, st));
+      ATDN_HIP(hipEventSynchronize(b));
+      float ms = 0.f;
+      ATDN_HIP(hipEventElapsedTime(&ms, a, b));
+      us_out[5] = ms * 1000.f / reps;
+    }
     {  // generation 2 with 16x16 output tiles (512 threads)
       hipEvent_t a, b;
       ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));

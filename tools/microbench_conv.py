@@ -8,7 +8,7 @@ from atdn_vslam_amd import _lib
 L = C.CDLL(_lib.LIB_PATH)
 out = (C.c_float * 8)()
 names = ["gen3 full", "gen3 -global loads", "gen3 -loads -LDS stores", "gen3 -loads -stores -ds_reads",
-         "gen3 MFMA only (no barriers)", "gen3 -ds_reads only", "gen2 16x16 tiles (512 thr)", "gen2 full"]
+         "gen4 LDS-DMA 16x16", "gen4 LDS-DMA 8x16", "gen2 16x16 tiles (512 thr)", "gen2 full"]
 for (nimg, H, W, Cc, N, KH, KW) in ((8, 47, 154, 384, 256, 1, 5), (8, 47, 154, 256, 192, 3, 3), (8, 47, 154, 128, 256, 3, 3)):
     torch.cuda.synchronize()
     rc = L.atdn_microbench_conv(nimg, H, W, Cc, N, KH, KW, 20, out)
