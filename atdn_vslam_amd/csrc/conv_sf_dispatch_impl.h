@@ -5,6 +5,7 @@
 #include "conv_sf2.h"
 #include "conv_sf3.h"
 #include "conv_sf4.h"
+#include "conv_sfd.h"
 #include "epilogues_sf.h"
 
 namespace atdn {
@@ -39,6 +40,17 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
   TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);
   t.groups_per_img = cdiv(Ho * Wo, t.BM) * (t.BM / 32);
   set_groups(ep, t.groups_per_img);
+  // conv_sfd (both tiles by LDS-DMA) measured 2-4 % slower than the register-staged conv_sf on these GEMM / 1x1 /
+  // strided shapes (the A tile streams from HBM or needs per-lane padding logic either way): opt-in only
+  static const bool dma = getenv("ATDN_GEMM_DMA") && getenv("ATDN_GEMM_DMA")[0] == '1';
+  if (dma) {
+    if (t.BM == 128 && t.BN == 128) launch_conv_sfd<2, 2, 2, 2>(s, wscale, ep, st);
+    else if (t.BM == 128 && t.BN == 64) launch_conv_sfd<2, 1, 2, 2>(s, wscale, ep, st);
+    else if (t.BM == 128 && t.BN == 96) launch_conv_sfd<1, 3, 4, 1>(s, wscale, ep, st);
+    else if (t.BM == 128 && t.BN == 32) launch_conv_sfd<1, 1, 4, 1>(s, wscale, ep, st);
+    else launch_conv_sfd<1, 1, 2, 2>(s, wscale, ep, st);
+    return t;
+  }
   if (t.BM == 128 && t.BN == 128) launch_conv_sf<2, 2, 2, 2>(s, wscale, ep, st);
   else if (t.BM == 128 && t.BN == 64) launch_conv_sf<2, 1, 2, 2>(s, wscale, ep, st);
   else if (t.BM == 128 && t.BN == 96) launch_conv_sf<1, 3, 4, 1>(s, wscale, ep, st);

@@ -5,6 +5,8 @@
 #include "conv_sf.h"
 #include "epilogues_sf.h"
 
+namespace atdn { const float* zero_line(); }
+
 namespace atdn {
 
 extern template TileChoice conv_dispatch<MODE_TAP, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
@@ -218,6 +220,7 @@ void GmaNet::finalize() {
                       &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_, &corrfeat_, &cor1_, &corflo_, &flo1_, &z_,
                       &rh_, &fh_, &mask_, &coords1_, &flow4_};
   for (auto* b : all) ws_bytes_ += (size_t)b->n * sizeof(float);
+  (void)zero_line();  // allocate the shared zero line now: never inside a stream capture
   ATDN_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
   ready_ = true;
 }

@@ -595,6 +595,16 @@ void launch_resize_aa(const float* src, int planes, int Hin, int Win, const Resi
   }
 }
 
+const float* zero_line() {
+  static float* z = nullptr;
+  if (!z) {
+    ATDN_HIP(hipMalloc(&z, 256));
+    ATDN_HIP(hipMemset(z, 0, 256));
+    ATDN_HIP(hipDeviceSynchronize());
+  }
+  return z;
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
