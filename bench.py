@@ -194,7 +194,7 @@ def main():
                        "all-gather of 512-d features, replicated LSTM scan" % world},
             # achieved = ALGORITHMIC flops / launch time; the kernel executes 3 f16 MFMAs per algorithmic product, so
             # the matrix pipe runs at 3x `achieved` (mfma_executed_*); peak = dense f16 MFMA.
-            "roofline": {"bound": "mfma", "kernel": "conv_sf2_kernel<16,16,2,SfGruZR> (fused z|r ConvGRU convolution, 16x16-pixel x 128-channel tiles)",
+            "roofline": {"bound": "mfma", "kernel": "conv_sf4_kernel<16,16,2,SfGruZR> (fused z|r ConvGRU convolution: 16x16-pixel x 128-channel tiles, LDS-DMA weights)",
                          "achieved": zr_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": zr_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic("SfGruZR", B),
                          "launch_ms": zr_launch_ms, "flop_per_launch": GRU_ZR_FLOP * B,
