@@ -411,3 +411,32 @@ def test_sequence_pipeline_matches_frame_by_frame(gsd, hsd):
     for i in range(6):
         p = vo(frames[i])
     assert _maxerr(poses[-1].float(), p) < 5e-5   # fp64 vs fp32 pose accumulation
+
+
+def test_large_batch_tile_path_matches_single_pairs(gsd):
+    """At 8 pairs per launch the dispatcher switches to 16x16-pixel tiles / 128x128 GEMM tiles (the configuration
+    bench.py times). The K order of every accumulation is the same for all tile shapes, so each pair must come out
+    exactly as in a single-pair call, which the golden tests cover."""
+    net = RAFTGMA(max_batch=8)
+    net.load_state_dict(gsd)
+    net = net.to(DEV)
+    fr = torch.from_numpy(syn.make_frames(9, 376, 1232, seed=55)).to(DEV)
+    low8, up8 = net.forward_sequence(fr, iters=12)
+    assert tuple(up8.shape) == (8, 2, 376, 1232) and torch.isfinite(up8).all()
+    for b in (0, 3, 7):
+        low1, up1 = net(fr[b:b + 1], fr[b + 1:b + 2], iters=12, test_mode=True)
+        assert _maxerr(up8[b:b + 1], up1) < 1e-5, b   # observed: bit-identical
+
+
+@pytest.mark.parametrize("hw", [(192, 640), (384, 1280)])
+def test_other_frame_sizes_match_oracle(gsd, hw):
+    """Nothing in the kernels is specialised to 47x154: two more geometries against the CPU oracle."""
+    from oracle import gma_ref
+    H, W = hw
+    net = RAFTGMA(max_batch=1)
+    net.load_state_dict(gsd)
+    net = net.to(DEV)
+    fr = torch.from_numpy(syn.make_frames(2, H, W, seed=61))
+    low, up = net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=3, test_mode=True)
+    ref_low, ref_up = gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=3)
+    assert _maxerr(low.cpu(), ref_low) < 2e-4 and _maxerr(up.cpu(), ref_up) < 1e-3
