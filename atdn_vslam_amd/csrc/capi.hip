@@ -16,6 +16,7 @@ extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_RELU>>(const Conv
 extern template TileChoice conv_dispatch<MODE_TAP, EpiScale>(const ConvShape&, EpiScale, hipStream_t);
 
 extern template TileChoice conv_sf_dispatch<EpiBias<ACT_NONE>>(const ConvShape&, float, EpiBias<ACT_NONE>, hipStream_t);
+extern template TileChoice conv_sf_dispatch<SfBias<ACT_NONE>>(const ConvShape&, float, SfBias<ACT_NONE>, hipStream_t);
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
@@ -333,8 +334,27 @@ int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const
     s.KH = KH; s.KW = KW; s.stride = stride; s.padH = padH; s.padW = padW;
     s.w = L.w; s.ldw = L.ldw; s.N = Cout; s.nimg = nimg;
     const int Ho = conv_out(H, KH, stride, padH), Wo = conv_out(W, KW, stride, padW);
-    conv_sf_dispatch(s, L.wscale, EpiBias<ACT_NONE>{L.b, dst, (long)Ho * Wo * Cout, Cout, 1.f}, st);
-    ATDN_HIP(hipStreamSynchronize(st));
+    s.wfrag = L.wf;
+    // ATDN_SF_CONV_EPILOGUE=sf (tests): write split-f16 through the SfBias epilogue, then unpack — exercises the
+    // channel-vector sf store; needs Cout % 32 == 0. Default: fp32 output through EpiBias.
+    const char* mode = getenv("ATDN_SF_CONV_EPILOGUE");
+    if (mode && mode[0] == 's' && Cout % 32 == 0) {
+      float* osf = nullptr;
+      const long orows = (long)nimg * Ho * Wo;
+      ATDN_HIP(hipMalloc(&osf, (size_t)orows * Cout * sizeof(float)));
+      try {
+        conv_sf_dispatch(s, L.wscale, SfBias<ACT_NONE>{L.b, osf, (long)Ho * Wo * Cout, Cout}, st);
+        launch_from_sf(osf, dst, orows, Cout, st);
+        ATDN_HIP(hipStreamSynchronize(st));
+      } catch (...) {
+        (void)hipFree(osf);
+        throw;
+      }
+      (void)hipFree(osf);
+    } else {
+      conv_sf_dispatch(s, L.wscale, EpiBias<ACT_NONE>{L.b, dst, (long)Ho * Wo * Cout, Cout, 1.f}, st);
+      ATDN_HIP(hipStreamSynchronize(st));
+    }
   } catch (...) {
     (void)hipFree(tmp);
     A.release();

@@ -1,0 +1,379 @@
+// Split-f16 halo-patch convolution, generation 6: weights never touch LDS.
+//
+// Generations 2-5 stream a [BN][32-chunk] weight tile through LDS every (chunk, tap) step and pay one workgroup
+// barrier per step for it; with two waves per SIMD that lock-step is what holds the matrix pipe at ~40 % busy
+// (tools/microbench_conv.py: registers, LDS-DMA, two- and three-deep rings all land within 3 % of each other).
+// Here every wave loads ITS OWN weight fragments straight from global memory (L2/L1-resident: the whole layer is
+// 1-2 MB) into registers in MFMA operand layout, one step ahead of use:
+//   lane (r = lane & 31, h = lane >> 5) holds, for output channel n0 + (wn*TN + j)*32 + r and K sub-step t,
+//   the 16-byte slots 2t+h (hi) and 4+2t+h (lo) of that row's 128-byte [32 hi | 32 lo] chunk.
+// Only the activation patch lives in LDS, so the only barriers are the two around its refresh at a chunk boundary
+// (every KH*KW steps); between them the waves of a block run free and overlap each other's LDS reads and MFMAs.
+// The wave grid is WM x WN over (TH*TW pixels) x (BN channels); WN = BN/32 makes the weight loads non-redundant.
+// KH x KW is a template parameter: the tap loop is unrolled, tap offsets are immediates and wait counts exact.
+//
+// Epilogues that provide the channel-vector form (`kVec4`: store4 / load4 / apply4 on 4 consecutive channels of
+// one pixel) run with the MFMA operands swapped — weights as the row operand — so a lane ends up with 16 channels
+// of ONE pixel (4 runs of 4): its epilogue traffic is 8- and 16-byte accesses instead of 2-byte ones, 4x fewer
+// VMEM instructions. Epilogues without it (InstanceNorm statistics need the pixel-major registers) keep the
+// classic orientation.
+#pragma once
+#include <type_traits>
+#include "conv_sf2.h"
+
+namespace atdn {
+
+// which kernel shapes an epilogue is instantiated for on this path (bit 0: 3x3, bit 1: 1x5 and 5x1)
+template <class E, class = void> struct epi_gen6 : std::integral_constant<int, 0> {};
+template <class E> struct epi_gen6<E, std::void_t<decltype(E::kGen6)>> : std::integral_constant<int, E::kGen6> {};
+template <class E, class = void> struct epi_vec4 : std::false_type {};
+template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bool_constant<E::kVec4> {};
+
+// ABL (diagnostic builds only, wrong results): bit0 no weight loads in the loop, bit1 no patch refresh, bit2 no LDS reads in the loop
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false>
+__global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int TM = TH * TW / 32 / WM, TN = BN / 32 / WN;
+  static_assert(TM * WM * 32 == TH * TW && TN * WN * 32 == BN, "wave grid must tile the block");
+  static_assert(32 % TW == 0 || TW % 32 == 0, "a 32-pixel MFMA row tile must cover whole tile rows");
+  constexpr int NTAP = KH * KW;
+  constexpr int RSTEP = NT / 8;
+  constexpr int PROWS = (TH + KH - 1) * (TW + KW - 1);
+  constexpr int PW = TW + KW - 1;
+  constexpr int NP = (PROWS + RSTEP - 1) / RSTEP;
+  constexpr int ROWB = LDS_LD * 4;
+  // LDS pitch between patch rows: a multiple of 256 B, so the two tile rows that one ds_read_b128 lane group
+  // ({0-3,12-15,20-27}, ... : pixels x..x+3, x+12..x+15 of one row and x+4..x+11 of the next) touches land on
+  // 16 distinct 16-byte bank slots (pixel pitch 144 B = 9 slots, 9 odd); PW*144 alone gives 2-way conflicts
+  constexpr int RS = (PW * ROWB + 255) / 256 * 256;
+  constexpr bool SWAP = epi_vec4<Epi>::value;
+  __shared__ __attribute__((aligned(256))) char Pbytes[(TH + KH - 1) * RS];
+
+  const int tid = threadIdx.x;
+  const int tiles_img = g.tiles_x * g.tiles_y;
+  const int nblk = g.nimg * tiles_img * g.ntile_n;
+  const int id = xcd_remap(blockIdx.x, nblk);
+  const int tile_n = id % g.ntile_n;
+  const int tmg = id / g.ntile_n;
+  const int img = tmg / tiles_img;
+  const int tloc = tmg - img * tiles_img;
+  const int ty0 = (tloc / g.tiles_x) * TH, tx0 = (tloc % g.tiles_x) * TW;
+  const int n0 = tile_n * BN;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  // ---- patch loader role (registers, true zero padding)
+  const int s = tid & 7, r0 = tid >> 3;
+  // per patch row of this thread: (pixel offset in the image + 1, 0 = zero padding) << 12 | LDS offset / 16
+  static_assert((TH + KH - 1) * RS / 16 <= 4096, "LDS offset field");
+  unsigned pmeta[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int prow = r0 + RSTEP * k;
+    unsigned off = 0;
+    const int py = prow / PW, px = prow - py * PW;
+    if (prow < PROWS) {
+      const int iy = ty0 - g.padH + py, ix = tx0 - g.padW + px;
+      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) off = (unsigned)(iy * g.W + ix) + 1u;
+    }
+    pmeta[k] = (off << 12) | (unsigned)((py * RS + px * ROWB + 16 * s) >> 4);
+  }
+  const float* s0 = g.src0 + (long)img * g.sb0;
+  const float* s1 = g.src1 ? g.src1 + (long)img * g.sb1 : nullptr;
+  const int nck = (g.C0 + g.C1) >> 5;
+
+  float4 pr[NP];
+  auto fetch_patch = [&](int c) {
+    const int cc = c << 5;
+    const float* sp; int ld, co;
+    if (cc < g.C0) { sp = s0; ld = g.ld0; co = cc; } else { sp = s1; ld = g.ld1; co = cc - g.C0; }
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      pr[k] = *reinterpret_cast<const float4*>(sp + (long)((pmeta[k] >> 12) ? (pmeta[k] >> 12) - 1 : 0) * ld + co + 4 * s);
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      if (r0 + RSTEP * k < PROWS)
+        *reinterpret_cast<float4*>(Pbytes + ((pmeta[k] & 0xFFFu) << 4)) = keep_if((pmeta[k] >> 12) != 0, pr[k]);
+  };
+
+  // ---- MFMA roles
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  int a_off[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = (wm * TM + i) * 32 + r;
+    a_off[i] = (p / TW) * RS + (p % TW) * ROWB + 16 * h;
+  }
+  const char* Pb = Pbytes;
+  // weight fragment rows (clamped: accumulators of rows >= N are never stored)
+  const float* wrow[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+    if constexpr (FRAGW)  // fragment-major weights: [n/32][q][t][hi|lo][lane] x 16 B, one contiguous KiB per wave load
+      wrow[j] = g.w + (long)min((n0 >> 5) + wn * TN + j, ((g.N + 31) >> 5) - 1) * (NTAP * nck) * 1024 + lane * 4;
+    else
+      wrow[j] = g.w + (long)min(n0 + (wn * TN + j) * 32 + r, g.N - 1) * g.ldw + 4 * h;
+
+  // weight fragments of the current step and of the next two (requested two steps ahead of use)
+  struct WFrag { f16x8 hi[2][TN], lo[2][TN]; };
+  WFrag w0, w1, w2;
+  auto load_w = [&](WFrag& f, int c, int tap) {
+    const int q = tap * nck + c;  // packed K order is [tap][channel chunk]
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if constexpr (FRAGW) {
+          f.hi[t][j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512);
+          f.lo[t][j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512 + 256);
+        } else {
+          f.hi[t][j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t);
+          f.lo[t][j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t + 16);
+        }
+      }
+  };
+
+  fetch_patch(0);
+  load_w(w0, 0, 0);
+  if (NTAP > 1) load_w(w1, 0, 1); else if (nck > 1) load_w(w1, 1, 0);
+  store_patch();
+  __syncthreads();
+  // activation fragments are software-pipelined at half-step granularity: while the 3*TM*TN MFMAs of K sub-step t
+  // run, the ds_reads of the next sub-step fill the other register set (set index = t)
+  f16x8 ah[2][TM], al[2][TM];
+  auto read_a = [&](int set, int tap, int t) {
+    const char* arow = Pb + (tap / KW) * RS + (tap % KW) * ROWB;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ah[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t);
+      al[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t + 64);
+    }
+  };
+  auto mfma_half = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (SWAP) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.hi[t][j], al[t][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.lo[t][j], ah[t][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.hi[t][j], ah[t][i], acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t][i], w0.hi[t][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], w0.lo[t][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], w0.hi[t][j], acc[i][j], 0, 0, 0);
+        }
+      }
+  };
+  read_a(0, 0, 0);
+  for (int c = 0; c < nck; ++c) {
+    const bool more = c + 1 < nck;
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      if (!(ABL & 2) && tap == 0 && more) fetch_patch(c + 1);  // lands during this chunk's taps
+      if (!(ABL & 1)) {
+        if (tap + 2 < NTAP) load_w(w2, c, tap + 2);
+        else if (more) load_w(w2, c + 1, tap + 2 - NTAP);
+      }
+      if (!(ABL & 4)) read_a(1, tap, 1);
+      mfma_half(0);
+      if (!(ABL & 4) && tap + 1 < NTAP) read_a(0, tap + 1, 0);
+      mfma_half(1);
+      w0 = w1;
+      w1 = w2;
+      if (tap + 1 == NTAP && more) {  // chunk boundary: every wave is done reading the patch, then it is replaced
+        if (!(ABL & 2)) {
+          asm volatile("s_barrier" ::: "memory");
+          store_patch();
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (!(ABL & 4)) read_a(0, 0, 0);
+      }
+    }
+  }
+
+  if constexpr ((ABL & 8) != 0) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot += acc[i][j][e];
+    if (tot == 1.2345e-30f) ep(img, 0, 0, tot);
+    return;
+  }
+  if constexpr (SWAP) {
+    // ---- channel-vector epilogue: lane r owns pixel pbase + r; registers 4k..4k+3 are channels nb + 8k + 4h + (0..3)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int p = (wm * TM + i) * 32 + r;
+      const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+      const bool pok = oy < g.Ho && ox < g.Wo;
+      const int m = pok ? oy * g.Wo + ox : 0;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + (wn * TN + j) * 32 + 4 * h;
+        if constexpr (Epi::kPrefetch) {
+          typename Epi::Aux4 aux[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) aux[k] = ep.load4(img, m, min(nb + 8 * k, g.N - 4));
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (pok && nb + 8 * k < g.N)
+              ep.apply4(img, m, nb + 8 * k,
+                        make_float4(acc[i][j][4 * k] * g.wscale, acc[i][j][4 * k + 1] * g.wscale,
+                                    acc[i][j][4 * k + 2] * g.wscale, acc[i][j][4 * k + 3] * g.wscale), aux[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (pok && nb + 8 * k < g.N)
+              ep.store4(img, m, nb + 8 * k,
+                        make_float4(acc[i][j][4 * k] * g.wscale, acc[i][j][4 * k + 1] * g.wscale,
+                                    acc[i][j][4 * k + 2] * g.wscale, acc[i][j][4 * k + 3] * g.wscale));
+        }
+      }
+    }
+    return;
+  }
+  // ---- epilogue (as conv_sf2.h, TM x TN tiles per wave)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pbase = (wm * TM + i) * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + r;
+      const bool nok = n < g.N;
+      int mm[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = pbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+        mm[e] = (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
+      }
+      if constexpr (Epi::kStats) {
+        const float bias = nok ? ep.bias[n] : 0.f;
+        float v[16];
+        float sum = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          v[e] = acc[i][j][e] * g.wscale + bias;
+          if (mm[e] >= 0) { sum += v[e]; ++cnt; }
+        }
+        sum += __shfl_xor(sum, 32);
+        cnt += __shfl_xor(cnt, 32);
+        const float mean = sum / (float)(cnt > 0 ? cnt : 1);
+        float m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (mm[e] >= 0) { const float d = v[e] - mean; m2 += d * d; }
+        m2 += __shfl_xor(m2, 32);
+        const int grp = tloc * (TH * TW / 32) + wm * TM + i;
+        if (h == 0 && nok) {
+          const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
+          ep.part_sum[o] = sum;
+          ep.part_m2[o] = m2;
+        }
+        if (lane == 0 && n == 0) ep.part_cnt[(long)img * ep.groups_per_img + grp] = (float)cnt;
+      }
+      if (nok) {
+        if constexpr (Epi::kPrefetch) {
+          typename Epi::Aux aux[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) aux[e] = ep.load(img, max(mm[e], 0), n);
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (mm[e] >= 0) ep.apply(img, mm[e], n, acc[i][j][e] * g.wscale, aux[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (mm[e] >= 0) ep(img, mm[e], n, acc[i][j][e] * g.wscale);
+        }
+      }
+    }
+  }
+}
+
+template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false>
+inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
+  constexpr int TW = 16;
+  ATDN_CHECK(s.KH == KH && s.KW == KW && s.stride == 1, "kernel shape does not match the instantiation");
+  Conv2Geom g{};
+  g.src0 = s.src0; g.src1 = s.src1; g.sb0 = s.sb0; g.sb1 = s.sb1; g.ld0 = s.ld0; g.ld1 = s.ld1;
+  g.C0 = s.C0; g.C1 = s.C1; g.H = s.H; g.W = s.W;
+  g.KH = s.KH; g.KW = s.KW; g.padH = s.padH; g.padW = s.padW;
+  g.Ho = conv_out(s.H, s.KH, 1, s.padH); g.Wo = conv_out(s.W, s.KW, 1, s.padW);
+  g.PH = TH + s.KH - 1; g.PW = TW + s.KW - 1;
+  ATDN_CHECK(s.C0 % 32 == 0 && s.C1 % 32 == 0 && s.C0 > 0 && s.ld0 % 4 == 0, "TAP-mode channel constraints");
+  ATDN_CHECK(s.ldw % 4 == 0 && s.ldw >= s.KH * s.KW * (s.C0 + s.C1), "weight rows too short");
+  ATDN_CHECK(!epi_vec4<Epi>::value || s.N % 4 == 0, "channel-vector epilogue needs N % 4 == 0");
+  ATDN_CHECK((long)s.H * s.W < (1L << 20) - 1, "image too large for the packed patch descriptor");
+  g.tiles_x = cdiv(g.Wo, TW); g.tiles_y = cdiv(g.Ho, TH);
+  g.nimg = s.nimg; g.ntile_n = cdiv(s.N, BN);
+  g.w = FRAGW ? s.wfrag : s.w; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;
+  ATDN_CHECK(g.w != nullptr, "missing weight copy for this kernel");
+  set_groups(ep, g.tiles_x * g.tiles_y * (TH * TW / 32));
+  const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
+  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
+  ATDN_HIP(hipGetLastError());
+}
+
+
+// Picks the block width for N output channels and launches the 8x16-pixel, fragment-major-weight kernel.
+// Returns false when this path does not serve the shape (the caller falls back to generation 4).
+template <int KH, int KW, class Epi>
+inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out) {
+  const int Ho = conv_out(s.H, s.KH, 1, s.padH), Wo = conv_out(s.W, s.KW, 1, s.padW);
+  const long tiles = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
+  // block width: the one of {256, 128, 64} that pads N least (ties: the widest, it shares the patch among more
+  // channels); N = 96 has its own 2x3-wave block. Measured (tools/microbench_conv.py, B = 8): N = 256 -> 256-wide
+  // 163 us vs 64-wide 174 us; N = 192 -> 64-wide 154 us vs 128- or 256-wide 186 us.
+  int bn = 64;
+  if (s.N == 96 && KH == 3) bn = 96;
+  else {
+    int best = cdiv(s.N, 64) * 64;
+    for (int c : {128, 256})
+      if (cdiv(s.N, c) * c <= best) { best = cdiv(s.N, c) * c; bn = c; }
+  }
+  // small grids: narrower blocks (more of them) until the chip is covered
+  while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
+  *bn_out = bn;
+  switch (bn) {
+    case 64:  launch_conv_sf6<8, 64, 2, 2, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true;  // 4 waves of 64 px x 32 ch
+    case 128: launch_conv_sf6<8, 128, 1, 4, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true;
+    case 256: launch_conv_sf6<8, 256, 1, 8, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true;
+    default: break;
+  }
+  if constexpr (KH == 3) {
+    if (bn == 96) { launch_conv_sf6<8, 96, 2, 3, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true; }
+  }
+  return false;
+}
+
+template <class Epi>
+inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out) {
+  constexpr int kinds = epi_gen6<Epi>::value;
+  if (kinds == 0 || !s.wfrag || s.stride != 1) return false;
+  if (epi_vec4<Epi>::value && (s.N % 4) != 0) return false;
+  if (s.C0 % 32 != 0 || s.C1 % 32 != 0 || s.C0 <= 0 || s.ld0 % 4 != 0) return false;
+  if constexpr ((kinds & 1) != 0) {
+    if (s.KH == 3 && s.KW == 3) return conv_sf6_try_shape<3, 3>(s, wscale, ep, st, bn_out);
+  }
+  if constexpr ((kinds & 2) != 0) {
+    if (s.KH == 1 && s.KW == 5) return conv_sf6_try_shape<1, 5>(s, wscale, ep, st, bn_out);
+    if (s.KH == 5 && s.KW == 1) return conv_sf6_try_shape<5, 1>(s, wscale, ep, st, bn_out);
+  }
+  return false;
+}
+
+}  // namespace atdn

@@ -5,6 +5,7 @@
 #include "conv_sf2.h"
 #include "conv_sf3.h"
 #include "conv_sf4.h"
+#include "conv_sf6.h"
 #include "conv_sfd.h"
 #include "epilogues_sf.h"
 
@@ -19,7 +20,13 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
     // that grid still covers the chip, else 8x16 tiles with 128- or 64-wide N tiles.
     // generation 4 (weights by LDS-DMA) is the default; ATDN_CONV_GEN=2 (register-staged weights) and =3 (warp-
     // specialised) select the other kernels, all within a few % of each other (tools/microbench_conv.py)
-    static const int gen = getenv("ATDN_CONV_GEN") ? atoi(getenv("ATDN_CONV_GEN")) : 4;
+    // generation 6 (fragment-major weights straight to registers, no per-step barrier) serves 3x3 / 1x5 / 5x1 kernels
+    // of the epilogues that opt in (kGen6); everything else, and ATDN_CONV_GEN=4, stays on generation 4
+    static const int gen = getenv("ATDN_CONV_GEN") ? atoi(getenv("ATDN_CONV_GEN")) : 6;
+    if (gen >= 6) {
+      int bn = 0;
+      if (conv_sf6_try(s, wscale, ep, st, &bn)) return TileChoice{128, bn, cdiv(Wo, 16) * cdiv(Ho, 8) * 4, true};
+    }
     static const int big_min = getenv("ATDN_BIG_TILE_MIN") ? atoi(getenv("ATDN_BIG_TILE_MIN")) : 224;
     const int tiles16 = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 16);
     if (s.N > 64 && (long)tiles16 * cdiv(s.N, 128) >= big_min) {

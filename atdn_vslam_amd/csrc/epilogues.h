@@ -20,6 +20,19 @@ struct EpiBias {
     if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
     dst[(long)img * ob + (long)m * ld + n] = v * scale;
   }
+  // channel-vector form (conv_sf6.h): channels n..n+3 of pixel m; 3x3 halo kernels only
+  static constexpr bool kVec4 = true;
+  static constexpr int kGen6 = 1;
+  __device__ __forceinline__ void store4(int img, int m, int n, float4 a) const {
+    if (bias) { a.x += bias[n]; a.y += bias[n + 1]; a.z += bias[n + 2]; a.w += bias[n + 3]; }
+    if (ACT == ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    float* d = dst + (long)img * ob + (long)m * ld + n;
+    if ((ld & 3) == 0 && (ob & 3) == 0) {
+      *reinterpret_cast<float4*>(d) = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+    } else {
+      d[0] = a.x * scale; d[1] = a.y * scale; d[2] = a.z * scale; d[3] = a.w * scale;
+    }
+  }
 };
 
 // raw = acc + bias, plus per-(32-row group, channel) partial statistics for InstanceNorm (fnet)
@@ -30,6 +43,7 @@ struct EpiBiasStats {
   float* dst; long ob; int ld;
   float* part_sum; float* part_m2; int groups_per_img;
   float* part_cnt = nullptr;  // valid rows per group (only the 2-D tiled kernel writes it)
+  static constexpr int kGen6 = 1;  // conv_sf6.h, classic (pixel-major) orientation
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
     dst[(long)img * ob + (long)m * ld + n] = a + bias[n];
   }

@@ -19,6 +19,14 @@ struct SfBias {
     if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
     sf_store(dst, (long)img * ob + (long)m * ld, n, v);
   }
+  // channel-vector form (conv_sf6.h): channels n..n+3 of pixel m
+  static constexpr bool kVec4 = true;
+  static constexpr int kGen6 = 1;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
+  __device__ __forceinline__ void store4(int img, int m, int n, float4 a) const {
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + n); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    if (ACT == ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    sf_store4(dst, (long)img * ob + (long)m * ld, n, a);
+  }
 };
 
 // out = relu(res + relu(acc + bias)), res and out in sf
@@ -33,6 +41,19 @@ struct SfBiasReluAddRelu {
   __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float y = fmaxf(a + bias[n], 0.f);
     sf_store(dst, (long)img * ob + (long)m * ld, n, fmaxf(x.r + y, 0.f));
+  }
+  static constexpr bool kVec4 = true;
+  static constexpr int kGen6 = 1;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
+  struct Aux4 { float4 r; };
+  __device__ __forceinline__ Aux4 load4(int img, int m, int n) const { return {sf_load4(res, (long)img * rb + (long)m * ldr, n)}; }
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x) const {
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    float4 o;
+    o.x = fmaxf(x.r.x + fmaxf(a.x + b.x, 0.f), 0.f);
+    o.y = fmaxf(x.r.y + fmaxf(a.y + b.y, 0.f), 0.f);
+    o.z = fmaxf(x.r.z + fmaxf(a.z + b.z, 0.f), 0.f);
+    o.w = fmaxf(x.r.w + fmaxf(a.w + b.w, 0.f), 0.f);
+    sf_store4(dst, (long)img * ob + (long)m * ld, n, o);
   }
 };
 
@@ -101,6 +122,24 @@ struct SfGruZR {
     if (n < 128) z[o + n] = v;
     else sf_store(rh, o, n - 128, v * x.h);
   }
+  static constexpr bool kVec4 = true;
+  static constexpr int kGen6 = 2;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
+  struct Aux4 { float4 h, p; };
+  __device__ __forceinline__ Aux4 load4(int img, int m, int n) const {
+    return {sf_load4(h, (long)img * ob + (long)m * 128, n & 127),
+            *reinterpret_cast<const float4*>(pre + (long)img * pb + (long)m * 256 + n)};
+  }
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x) const {
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    float4 v;
+    v.x = sigmoidf_((a.x + x.p.x) + b.x);
+    v.y = sigmoidf_((a.y + x.p.y) + b.y);
+    v.z = sigmoidf_((a.z + x.p.z) + b.z);
+    v.w = sigmoidf_((a.w + x.p.w) + b.w);
+    const long o = (long)img * ob + (long)m * 128;
+    if (n < 128) *reinterpret_cast<float4*>(z + o + n) = v;
+    else sf_store4(rh, o, n - 128, make_float4(v.x * x.h.x, v.y * x.h.y, v.z * x.h.z, v.w * x.h.w));
+  }
 };
 
 struct SfGruQ {
@@ -120,6 +159,22 @@ struct SfGruQ {
   __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float q = tanhf((a + x.p) + bias[n]);
     sf_store(hout, (long)img * ob + (long)m * 128, n, (1.f - x.z) * x.h + x.z * q);
+  }
+  static constexpr bool kVec4 = true;
+  static constexpr int kGen6 = 2;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
+  struct Aux4 { float4 h, z, p; };
+  __device__ __forceinline__ Aux4 load4(int img, int m, int n) const {
+    const long o = (long)img * ob + (long)m * 128;
+    return {sf_load4(h, o, n), *reinterpret_cast<const float4*>(z + o + n), *reinterpret_cast<const float4*>(pre + o + n)};
+  }
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x) const {
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    float4 o;
+    o.x = (1.f - x.z.x) * x.h.x + x.z.x * tanhf((a.x + x.p.x) + b.x);
+    o.y = (1.f - x.z.y) * x.h.y + x.z.y * tanhf((a.y + x.p.y) + b.y);
+    o.z = (1.f - x.z.z) * x.h.z + x.z.z * tanhf((a.z + x.p.z) + b.z);
+    o.w = (1.f - x.z.w) * x.h.w + x.z.w * tanhf((a.w + x.p.w) + b.w);
+    sf_store4(hout, (long)img * ob + (long)m * 128, n, o);
   }
 };
 

@@ -41,7 +41,7 @@ ConvShape conv_shape(const PackedConv& L, const float* src, int ld, long sb, int
   ConvShape s;
   s.src0 = src; s.ld0 = ld; s.sb0 = sb; s.C0 = L.C;
   s.H = H; s.W = W; s.KH = L.KH; s.KW = L.KW; s.stride = stride; s.padH = padH; s.padW = padW;
-  s.w = L.w; s.ldw = L.ldw; s.N = L.N; s.nimg = nimg;
+  s.w = L.w; s.wfrag = L.wf; s.ldw = L.ldw; s.N = L.N; s.nimg = nimg;
   return s;
 }
 
@@ -329,7 +329,7 @@ void GmaNet::iteration(int B, hipStream_t st) {
     g.C0 = 128; g.src1 = x_.p; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = XLD;
     conv_dispatch<MODE_TAP>(g, EpiGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128}, st);
     mark(ST_GRU_ZR, st);
-    g.src0 = rh_.p; g.w = gru_q_[p].w; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
+    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_dispatch<MODE_TAP>(g, EpiGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128}, st);
     mark(ST_GRU_Q, st);
   }
@@ -495,7 +495,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
     conv_sf_dispatch(g, gru_zr_[p].wscale,
                      SfGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128, pre_zr_[p].p, (long)N * 256}, st);
     mark(ST_GRU_ZR, st);
-    g.src0 = rh_.p; g.w = gru_q_[p].w; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
+    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_sf_dispatch(g, gru_q_[p].wscale, SfGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128, pre_q_[p].p}, st);
     mark(ST_GRU_Q, st);
   }

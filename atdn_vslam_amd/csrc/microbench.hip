@@ -1,100 +1,193 @@
 // Diagnostic micro-benchmark of the halo-patch kernels on a ConvGRU-shaped problem (not on the product path).
 #include "../../include/atdn_hip.h"
 #include "conv_sf_dispatch_impl.h"
+#include "conv_sf6.h"
 #include "kernels.h"
 
+using namespace atdn;
+
+// us_out[12]: gen-6 (8x16 pixels x 256 / 128 / 64 channels), its ablation ladder on the 256-wide block (diagnostic
+// builds that skip work: wrong results, timing only), then generations 4, 3 and 2 for reference.
+extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH, int KW, int reps, float* us_out) {
+  try {
+    hipStream_t st = nullptr;
+    const long npix = (long)nimg * H * W;
+    float *x, *w, *wf, *y, *bias;
+    const int K = KH * KW * C;
+    ATDN_CHECK(C % 32 == 0 && N % 32 == 0, "microbench shapes are multiples of 32");
+    ATDN_HIP(hipMalloc(&x, npix * C * 4)); ATDN_HIP(hipMalloc(&w, (long)N * K * 4)); ATDN_HIP(hipMalloc(&wf, (long)N * K * 4));
+    ATDN_HIP(hipMalloc(&y, npix * N * 4)); ATDN_HIP(hipMalloc(&bias, N * 4));
+    // pseudo-random f16 bit patterns of moderate magnitude (zero data would overclock the chip); ATDN_MB_ZERO=1
+    // shows how much of a time is the clock the chip holds on real operands
+    std::vector<unsigned short> hx((size_t)npix * C * 2), hw((size_t)N * K * 2);
+    unsigned v = 12345u;
+    for (auto& e : hx) { v = v * 1664525u + 1013904223u; e = (unsigned short)(0x3000 + ((v >> 16) & 0x0FFF) + ((v >> 31) << 15)); }
+    for (auto& e : hw) { v = v * 1664525u + 1013904223u; e = (unsigned short)(0x3000 + ((v >> 16) & 0x0FFF) + ((v >> 31) << 15)); }
+    if (getenv("ATDN_MB_ZERO")) { std::fill(hx.begin(), hx.end(), 0); std::fill(hw.begin(), hw.end(), 0); }
+    ATDN_HIP(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    ATDN_HIP(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    ATDN_HIP(hipMemcpy(wf, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));  // same bytes: order is irrelevant for timing
+    ATDN_HIP(hipMemset(bias, 0, N * 4));
+    ConvShape s;
+    s.src0 = x; s.ld0 = C; s.sb0 = (long)H * W * C; s.C0 = C; s.H = H; s.W = W;
+    s.KH = KH; s.KW = KW; s.stride = 1; s.padH = KH / 2; s.padW = KW / 2;
+    s.w = w; s.wfrag = wf; s.ldw = K; s.N = N; s.nimg = nimg;
+    using E = SfBias<ACT_RELU>;
+    E ep{bias, y, (long)H * W * N, N};
+    auto time_it = [&](auto&& go) {
+      hipEvent_t a, b;
+      ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
+      for (int i = 0; i < 2 * reps; ++i) go();  // warm-up: clocks and caches settle before the timed launches
+      ATDN_HIP(hipEventRecord(a, st));
+      for (int i = 0; i < reps; ++i) go();
+      ATDN_HIP(hipEventRecord(b, st));
+      ATDN_HIP(hipEventSynchronize(b));
+      float ms = 0.f;
+      ATDN_HIP(hipEventElapsedTime(&ms, a, b));
+      (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+      return ms * 1000.f / reps;
+    };
+#define ATDN_MB_SF6(BN, WM, WN, ABL)                                                                   \
+    time_it([&]() {                                                                                \
+      if (KH == 3 && KW == 3) launch_conv_sf6<8, BN, WM, WN, 3, 3, E, ABL, true>(s, 1.f, ep, st);    \
+      else if (KH == 1 && KW == 5) launch_conv_sf6<8, BN, WM, WN, 1, 5, E, ABL, true>(s, 1.f, ep, st); \
+      else launch_conv_sf6<8, BN, WM, WN, 5, 1, E, ABL, true>(s, 1.f, ep, st);                       \
+    })
+    us_out[0] = ATDN_MB_SF6(256, 1, 8, 0);
+    us_out[1] = ATDN_MB_SF6(128, 1, 4, 0);
+    us_out[2] = ATDN_MB_SF6(64, 2, 2, 0);
+    us_out[3] = ATDN_MB_SF6(256, 1, 8, 8);    // no epilogue
+    us_out[4] = ATDN_MB_SF6(256, 1, 8, 9);    // ... and no weight loads in the loop
+    us_out[5] = ATDN_MB_SF6(256, 1, 8, 13);   // ... and no LDS reads in the loop
+    us_out[6] = ATDN_MB_SF6(256, 1, 8, 15);   // ... and no patch refresh: the bare MFMA stream of this tiling
+#undef ATDN_MB_SF6
+    us_out[7] = time_it([&]() { launch_conv_sf4<2, E, 16>(s, 1.f, ep, st); });
+    us_out[8] = time_it([&]() { launch_conv_sf4<2, E, 8>(s, 1.f, ep, st); });
+    us_out[9] = time_it([&]() { launch_conv_sf3<2, E, 0>(s, 1.f, ep, st); });
+    us_out[10] = time_it([&]() { launch_conv_sf2<2, E, 16>(s, 1.f, ep, st); });
+    us_out[11] = time_it([&]() { launch_conv_sf2<2, E, 8>(s, 1.f, ep, st); });
+    (void)hipFree(x); (void)hipFree(w); (void)hipFree(wf); (void)hipFree(y); (void)hipFree(bias);
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  }
+}
+
+// ---- MFMA ceilings under DVFS: the split-f16 product pattern (3 MFMAs per operand pair) on random or zero data,
+// operands held in registers or re-read from a conflict-free LDS image every step, for both f16 MFMA shapes.
 namespace atdn {
-template <int ABL>
-static float time_sf3(const ConvShape& s, const SfBias<ACT_RELU>& ep, int reps, hipStream_t st) {
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int SHAPE, int SRC>
+__global__ __launch_bounds__(256) void mfma_ceiling_kernel(const float* __restrict__ data, float* __restrict__ out, int steps) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 128 * 32];  // A image 128 rows x 128 B, B image likewise
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 2 * 128 * 32; i += 256) lds[i] = data[i];
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;
+  const char* Ab = reinterpret_cast<const char*>(lds);
+  const char* Bb = Ab + 128 * 128;
+  float total = 0.f;
+  if constexpr (SHAPE == 0) {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+    auto rd = [&]() {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[t][i] = *reinterpret_cast<const f16x8*>(Ab + ((wm * 2 + i) * 32 + r) * 128 + (((2 * t + h) ^ sw) << 4));
+          al[t][i] = *reinterpret_cast<const f16x8*>(Ab + ((wm * 2 + i) * 32 + r) * 128 + (((4 + 2 * t + h) ^ sw) << 4));
+          bh[t][i] = *reinterpret_cast<const f16x8*>(Bb + ((wn * 2 + i) * 32 + r) * 128 + (((2 * t + h) ^ sw) << 4));
+          bl[t][i] = *reinterpret_cast<const f16x8*>(Bb + ((wn * 2 + i) * 32 + r) * 128 + (((4 + 2 * t + h) ^ sw) << 4));
+        }
+    };
+    rd();
+    for (int s = 0; s < steps; ++s) {
+      if constexpr (SRC == 1) { asm volatile("" ::: "memory"); rd(); }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t][i], bh[t][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], bl[t][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], bh[t][j], acc[i][j], 0, 0, 0);
+          }
+    }
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) total += acc[i][j][e];
+  } else {
+    const int r = lane & 15, q = lane >> 4, sw = (r >> 1) & 7;  // 16 rows x 4 k-groups of 8
+    f32x4_t acc[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    f16x8 ah[4], al[4], bh[4], bl[4];
+    auto rd = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(Ab + ((wm * 4 + i) * 16 + r) * 128 + ((q ^ sw) << 4));
+        al[i] = *reinterpret_cast<const f16x8*>(Ab + ((wm * 4 + i) * 16 + r) * 128 + (((4 + q) ^ sw) << 4));
+        bh[i] = *reinterpret_cast<const f16x8*>(Bb + ((wn * 4 + i) * 16 + r) * 128 + ((q ^ sw) << 4));
+        bl[i] = *reinterpret_cast<const f16x8*>(Bb + ((wn * 4 + i) * 16 + r) * 128 + (((4 + q) ^ sw) << 4));
+      }
+    };
+    rd();
+    for (int s = 0; s < steps; ++s) {
+      if constexpr (SRC == 1) { asm volatile("" ::: "memory"); rd(); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 4; ++e) total += acc[i][j][e];
+  }
+  out[blockIdx.x * 256 + tid] = total;
+}
+
+template <int SHAPE, int SRC>
+static float time_ceiling(const float* data, float* out, int steps, int launches, hipStream_t st) {
   hipEvent_t a, b;
   ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
-  launch_conv_sf3<2, SfBias<ACT_RELU>, ABL>(s, 1.f, ep, st);
+  for (int i = 0; i < launches / 4 + 1; ++i) hipLaunchKernelGGL((mfma_ceiling_kernel<SHAPE, SRC>), dim3(512), dim3(256), 0, st, data, out, steps);
   ATDN_HIP(hipEventRecord(a, st));
-  for (int i = 0; i < reps; ++i) launch_conv_sf3<2, SfBias<ACT_RELU>, ABL>(s, 1.f, ep, st);
+  for (int i = 0; i < launches; ++i) hipLaunchKernelGGL((mfma_ceiling_kernel<SHAPE, SRC>), dim3(512), dim3(256), 0, st, data, out, steps);
   ATDN_HIP(hipEventRecord(b, st));
   ATDN_HIP(hipEventSynchronize(b));
   float ms = 0.f;
   ATDN_HIP(hipEventElapsedTime(&ms, a, b));
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  return ms * 1000.f / reps;
+  const double flop = 512.0 * 4 * steps * (64.0 * 64 * 32 * 2 * 3) * launches;
+  return (float)(flop / (ms * 1e-3) / 1e12);
 }
 }  // namespace atdn
-using namespace atdn;
 
-extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH, int KW, int reps, float* us_out) {
+// tf_out[8]: {32x32x16, 16x16x32} x {registers, LDS re-read} x {random, zero} executed TFLOP/s
+extern "C" int atdn_microbench_mfma(int steps, int launches, float* tf_out) {
   try {
     hipStream_t st = nullptr;
-    const long npix = (long)nimg * H * W;
-    float *x, *w, *y, *bias;
-    const int K = KH * KW * C;
-    ATDN_HIP(hipMalloc(&x, npix * C * 4)); ATDN_HIP(hipMalloc(&w, (long)N * K * 4));
-    ATDN_HIP(hipMalloc(&y, npix * N * 4)); ATDN_HIP(hipMalloc(&bias, N * 4));
-    // pseudo-random f16 bit patterns of moderate magnitude (zero data would overclock the chip)
-    std::vector<unsigned short> hx((size_t)npix * C * 2), hw((size_t)N * K * 2);
-    unsigned v = 12345u;
-    for (auto& e : hx) { v = v * 1664525u + 1013904223u; e = (unsigned short)(0x3000 + ((v >> 16) & 0x0FFF) + ((v >> 31) << 15)); }
-    for (auto& e : hw) { v = v * 1664525u + 1013904223u; e = (unsigned short)(0x3000 + ((v >> 16) & 0x0FFF) + ((v >> 31) << 15)); }
-    ATDN_HIP(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
-    ATDN_HIP(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
-    ATDN_HIP(hipMemset(bias, 0, N * 4));
-    ConvShape s;
-    s.src0 = x; s.ld0 = C; s.sb0 = (long)H * W * C; s.C0 = C; s.H = H; s.W = W;
-    s.KH = KH; s.KW = KW; s.stride = 1; s.padH = KH / 2; s.padW = KW / 2;
-    s.w = w; s.ldw = K; s.N = N; s.nimg = nimg;
-    SfBias<ACT_RELU> ep{bias, y, (long)H * W * N, N};
-    us_out[0] = time_sf3<0>(s, ep, reps, st);
-    us_out[1] = time_sf3<1>(s, ep, reps, st);
-    us_out[2] = time_sf3<3>(s, ep, reps, st);
-    us_out[3] = time_sf3<7>(s, ep, reps, st);
-    {  // generation 4, 16x16 tiles
-      hipEvent_t a, b;
-      ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
-      launch_conv_sf4<2, SfBias<ACT_RELU>, 16>(s, 1.f, ep, st);
-      ATDN_HIP(hipEventRecord(a, st));
-      for (int i = 0; i < reps; ++i) launch_conv_sf4<2, SfBias<ACT_RELU>, 16>(s, 1.f, ep, st);
-      ATDN_HIP(hipEventRecord(b, st));
-      ATDN_HIP(hipEventSynchronize(b));
-      float ms = 0.f;
-      ATDN_HIP(hipEventElapsedTime(&ms, a, b));
-      us_out[4] = ms * 1000.f / reps;
+    float *rnd, *zero, *out;
+    const size_t n = 2 * 128 * 32;
+    ATDN_HIP(hipMalloc(&rnd, n * 4)); ATDN_HIP(hipMalloc(&zero, n * 4)); ATDN_HIP(hipMalloc(&out, 512 * 256 * 4));
+    std::vector<unsigned short> h(n * 2);
+    unsigned v = 777u;
+    for (auto& e : h) { v = v * 1664525u + 1013904223u; e = (unsigned short)(0x3000 + ((v >> 16) & 0x0FFF) + ((v >> 31) << 15)); }
+    ATDN_HIP(hipMemcpy(rnd, h.data(), n * 4, hipMemcpyHostToDevice));
+    ATDN_HIP(hipMemset(zero, 0, n * 4));
+    int k = 0;
+    for (const float* d : {(const float*)rnd, (const float*)zero}) {
+      tf_out[k++] = time_ceiling<0, 0>(d, out, steps, launches, st);
+      tf_out[k++] = time_ceiling<0, 1>(d, out, steps, launches, st);
+      tf_out[k++] = time_ceiling<1, 0>(d, out, steps, launches, st);
+      tf_out[k++] = time_ceiling<1, 1>(d, out, steps, launches, st);
     }
-    {  // generation 4: weight tiles by LDS-DMA, 8x16 tiles
-      hipEvent_t a, b;
-      ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
-      launch_conv_sf4<2, SfBias<ACT_RELU>, 8>(s, 1.f, ep, st);
-      ATDN_HIP(hipEventRecord(a, st));
-      for (int i = 0; i < reps; ++i) launch_conv_sf4<2, SfBias<ACT_RELU>, 8>(s, 1.f, ep, st);
-      ATDN_HIP(hipEventRecord(b, st));
-      ATDN_HIP(hipEventSynchronize(b));
-      float ms = 0.f;
-      ATDN_HIP(hipEventElapsedTime(&ms, a, b));
-      us_out[5] = ms * 1000.f / reps;
-    }
-    {  // generation 2 with 16x16 output tiles (512 threads)
-      hipEvent_t a, b;
-      ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
-      launch_conv_sf2<2, SfBias<ACT_RELU>, 16>(s, 1.f, ep, st);
-      ATDN_HIP(hipEventRecord(a, st));
-      for (int i = 0; i < reps; ++i) launch_conv_sf2<2, SfBias<ACT_RELU>, 16>(s, 1.f, ep, st);
-      ATDN_HIP(hipEventRecord(b, st));
-      ATDN_HIP(hipEventSynchronize(b));
-      float ms = 0.f;
-      ATDN_HIP(hipEventElapsedTime(&ms, a, b));
-      us_out[6] = ms * 1000.f / reps;
-    }
-    {  // generation 2 (single-role waves) for reference
-      hipEvent_t a, b;
-      ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
-      launch_conv_sf2<2>(s, 1.f, ep, st);
-      ATDN_HIP(hipEventRecord(a, st));
-      for (int i = 0; i < reps; ++i) launch_conv_sf2<2>(s, 1.f, ep, st);
-      ATDN_HIP(hipEventRecord(b, st));
-      ATDN_HIP(hipEventSynchronize(b));
-      float ms = 0.f;
-      ATDN_HIP(hipEventElapsedTime(&ms, a, b));
-      us_out[7] = ms * 1000.f / reps;
-    }
-    (void)hipFree(x); (void)hipFree(w); (void)hipFree(y); (void)hipFree(bias);
+    (void)hipFree(rnd); (void)hipFree(zero); (void)hipFree(out);
     return 0;
   } catch (const std::exception& e) {
     set_last_error(e.what());

@@ -36,6 +36,20 @@ __device__ __forceinline__ void sf_store(float* base, long off, int c, float v) 
   q[0] = p.hi;
   q[32] = p.lo;
 }
+// four consecutive channels c..c+3 (c % 4 == 0): one 8-byte access for the hi parts, one for the lo parts
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sf_store4(float* base, long off, int c, float4 v) {
+  const SfPair a = sf_split(v.x), b = sf_split(v.y), d = sf_split(v.z), e = sf_split(v.w);
+  _Float16* q = sf_ptr(base, off, c);
+  *reinterpret_cast<f16x4*>(q) = f16x4{a.hi, b.hi, d.hi, e.hi};
+  *reinterpret_cast<f16x4*>(q + 32) = f16x4{a.lo, b.lo, d.lo, e.lo};
+}
+__device__ __forceinline__ float4 sf_load4(const float* base, long off, int c) {
+  const _Float16* q = sf_ptr(base, off, c);
+  const f16x4 hi = *reinterpret_cast<const f16x4*>(q), lo = *reinterpret_cast<const f16x4*>(q + 32);
+  return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2],
+                     (float)hi[3] + (float)lo[3]);
+}
 __device__ __forceinline__ float sf_load(const float* base, long off, int c) {
   const _Float16* q = sf_ptr(base, off, c);
   return (float)q[0] + (float)q[32];

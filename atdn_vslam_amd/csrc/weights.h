@@ -47,6 +47,9 @@ struct PackedConv {
   float wscale = 1.f;  // sf packing: accumulator multiplier (power of two)
   const float* w = nullptr;
   const float* b = nullptr;
+  // sf packing of 3x3 / 1x5 / 5x1 kernels: a second copy in MFMA-fragment order (conv_sf6.h)
+  long wf_off = -1;
+  const float* wf = nullptr;
 };
 
 class WeightArena {
@@ -130,6 +133,27 @@ inline PackedConv pack_conv(WeightArena& A, const StateDict& sd, const std::vect
   return L;
 }
 
+// Fragment-major copy of an sf-packed weight matrix for conv_sf6.h: [ceil(N/32)][K/32][t = 0,1][hi, lo][lane] x 16 B.
+// Lane (r = lane & 31, h = lane >> 5) of the wave that owns output channels nt*32 .. nt*32+31 finds, for K chunk q and
+// K sub-step t, its hi operand (16-byte slot 2t+h of row nt*32+r, chunk q) and its lo operand (slot 4+2t+h) at
+// ((nt*nq + q)*4 + 2t + {0,1})*1024 + lane*16 bytes: every wave load is one contiguous KiB. Rows >= N are zero.
+inline void pack_fragment_major(WeightArena& A, PackedConv& L) {
+  const int nq = L.ldw / 32, ntile = (L.N + 31) / 32;
+  L.wf_off = A.alloc((long)ntile * nq * 1024);
+  const float* w = A.at(L.w_off);  // (alloc may have moved the arena: take the pointers after it)
+  float* f = A.at(L.wf_off);
+  for (int nt = 0; nt < ntile; ++nt)
+    for (int q = 0; q < nq; ++q)
+      for (int t = 0; t < 2; ++t)
+        for (int hl = 0; hl < 2; ++hl)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int r = lane & 31, h = lane >> 5, row = nt * 32 + r, slot = 4 * hl + 2 * t + h;
+            float* d = f + ((((long)nt * nq + q) * 4 + 2 * t + hl) * 64 + lane) * 4;
+            if (row < L.N) std::memcpy(d, w + (long)row * L.ldw + q * 32 + slot * 4, 16);
+            else std::memset(d, 0, 16);
+          }
+}
+
 // Same as pack_conv(TAP) but in split-f16 form (sf.h): every 32-float K-chunk of a row becomes [32 hi | 32 lo]
 // halves; all weights of the layer are pre-multiplied by 2^p so that max|w| lands in [1,2) and L.wscale = 2^-p.
 inline PackedConv pack_conv_sf(WeightArena& A, const StateDict& sd, const std::vector<std::string>& names,
@@ -157,6 +181,7 @@ inline PackedConv pack_conv_sf(WeightArena& A, const StateDict& sd, const std::v
         hrow[q * 64 + 32 + j] = lo;
       }
   }
+  if ((L.KH == 3 && L.KW == 3) || (L.KH == 1 && L.KW == 5) || (L.KH == 5 && L.KW == 1)) pack_fragment_major(A, L);
   return L;
 }
 
@@ -201,6 +226,7 @@ inline long pack_vector(WeightArena& A, const std::vector<float>& v) {
 inline void resolve(const WeightArena& A, PackedConv& L) {
   L.w = A.dev(L.w_off);
   L.b = A.dev(L.b_off);
+  L.wf = L.wf_off >= 0 ? A.dev(L.wf_off) : nullptr;
 }
 
 }  // namespace atdn

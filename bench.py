@@ -194,7 +194,7 @@ def main():
                        "all-gather of 512-d features, replicated LSTM scan" % world},
             # achieved = ALGORITHMIC flops / launch time; the kernel executes 3 f16 MFMAs per algorithmic product, so
             # the matrix pipe runs at 3x `achieved` (mfma_executed_*); peak = dense f16 MFMA.
-            "roofline": {"bound": "mfma", "kernel": "conv_sf4_kernel<16,16,2,SfGruZR> (fused z|r ConvGRU convolution: 16x16-pixel x 128-channel tiles, LDS-DMA weights)",
+            "roofline": {"bound": "mfma", "kernel": "conv_sf6_kernel<8,16,256,1,8,1,5|5,1,SfGruZR> (fused z|r ConvGRU convolution: 8x16-pixel x 256-channel blocks, fragment-major weights straight to registers)",
                          "achieved": zr_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": zr_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic("SfGruZR", B),
                          "launch_ms": zr_launch_ms, "flop_per_launch": GRU_ZR_FLOP * B,

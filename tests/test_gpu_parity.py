@@ -102,6 +102,43 @@ def test_split_f16_engine_matches_fp64(case):
     assert _maxerr(got, ref) < 2e-5, _maxerr(got, ref)
 
 
+HALO_CASES = [
+    # (Cin, Cout, KH, KW, padH, padW, H, W, nimg): stride-1 kernels served by conv_sf6.h (fragment-major weights)
+    (256, 192, 3, 3, 1, 1, 47, 154, 3),   # 192-wide block (6 waves)
+    (128, 96, 3, 3, 1, 1, 30, 41, 8),     # 96-wide block (3 waves), ragged tiles
+    (64, 64, 3, 3, 1, 1, 23, 37, 12),     # 64-wide block (2 waves)
+    (384, 256, 1, 5, 0, 2, 47, 154, 4),   # z|r ConvGRU shape, 256-wide block (8 waves)
+    (384, 128, 5, 1, 2, 0, 47, 154, 6),   # q ConvGRU shape, vertical taps
+    (128, 320, 3, 3, 1, 1, 17, 33, 9),    # two N tiles of 256, the second one partial
+    (96, 32, 3, 3, 1, 1, 9, 200, 2),      # small grid: falls to the narrowest block
+]
+
+
+@pytest.mark.parametrize("sf_out", [0, 1])
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_split_f16_halo_kernels_match_fp64(case, sf_out, monkeypatch):
+    """Generation-6 halo kernels, both epilogue orientations: fp32 output (EpiBias) and split-f16 output through
+    the channel-vector SfBias store (decoded again by from_sf), against an fp64 convolution."""
+    cin, cout, kh, kw, ph, pw, H, W, nimg = case
+    if sf_out:
+        monkeypatch.setenv("ATDN_SF_CONV_EPILOGUE", "sf")
+    else:
+        monkeypatch.delenv("ATDN_SF_CONV_EPILOGUE", raising=False)
+    r = np.random.RandomState(hash(case) & 0xFFFF)
+    x = torch.from_numpy(r.normal(0, 1, (nimg, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((r.uniform(-1, 1, (cout, cin, kh, kw)) * np.sqrt(3.0 / (cin * kh * kw))).astype(np.float32))
+    b = torch.from_numpy(r.uniform(-0.5, 0.5, (cout,)).astype(np.float32))
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=1, padding=(ph, pw))
+    xd = _nhwc(x).to(DEV)
+    out = torch.full((nimg, ref.shape[2], ref.shape[3], cout), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.check(_lib.lib().atdn_conv2d_nhwc_sf(_vp(xd), nimg, H, W, cin, _vp(w), _vp(b), cout, kh, kw, 1, ph, pw,
+                                              _vp(out), _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert _maxerr(got, ref) < 2e-5, _maxerr(got, ref)
+
+
 def test_conv_engine_rejects_bad_shapes():
     x = torch.zeros(1, 8, 8, 24, device=DEV)
     w = torch.zeros(8, 24, 3, 3)

@@ -1,0 +1,16 @@
+"""Executed-FLOP ceilings of the split-f16 MFMA pattern under DVFS (diagnostic): random vs zero operands,
+registers vs LDS re-reads, 32x32x16 vs 16x16x32 f16 MFMA."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+from atdn_vslam_amd import _lib
+L = C.CDLL(_lib.LIB_PATH)
+out = (C.c_float * 8)()
+torch.cuda.synchronize()
+assert L.atdn_microbench_mfma(2000, 200, out) == 0
+names = ["32x32x16 regs", "32x32x16 LDS re-read", "16x16x32 regs", "16x16x32 LDS re-read"]
+for d, data in enumerate(("random", "zero")):
+    for i, n in enumerate(names):
+        print("%-7s %-22s %8.0f TF/s executed" % (data, n, out[d * 4 + i]))
