@@ -2,7 +2,10 @@
 MI355X_MICROARCH.md prescribes). Units: the counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B read
 requests at 64 B for 16-B-per-lane loads, so the read side is doubled (guide §HBM); WRITE_SIZE is exact.
 
-    python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_prefix>
+    python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_prefix> [batch]
+
+`batch` (pairs per launch of the profiled run, default 8 = bench.py's default) is recorded as `_batch`: bench.py only
+quotes a traffic figure measured at the batch it runs.
 """
 import collections
 import csv
@@ -17,7 +20,7 @@ def load(path):
     return d
 
 
-def main(fetch_csv, write_csv, prefix):
+def main(fetch_csv, write_csv, prefix, batch=8):
     f, w = load(fetch_csv), load(write_csv)
     out = {}
     for k in sorted(set(f) | set(w)):
@@ -25,7 +28,9 @@ def main(fetch_csv, write_csv, prefix):
         wa = sum(w.get(k, [0.0])) / max(1, len(w.get(k, [])))
         out[k.replace("atdn::", "")] = {"launches": len(f.get(k, [])), "fetch_size_kib_avg": fa, "write_size_kib_avg": wa,
                                         "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
-    json.dump(out, open(prefix + ".json", "w"), indent=1, sort_keys=True)
+    js = dict(out)
+    js["_batch"] = int(batch)
+    json.dump(js, open(prefix + ".json", "w"), indent=1, sort_keys=True)
     with open(prefix + ".csv", "w") as fh:
         fh.write("kernel,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_MB_per_launch(2xFETCH+WRITE)\n")
         for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
@@ -34,4 +39,4 @@ def main(fetch_csv, write_csv, prefix):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
