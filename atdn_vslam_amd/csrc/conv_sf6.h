@@ -235,11 +235,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
                                     acc[i][j][4 * k + 2] * g.wscale, acc[i][j][4 * k + 3] * g.wscale), aux[k]);
         } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (pok && nb + 8 * k < g.N)
-              ep.store4(img, m, nb + 8 * k,
-                        make_float4(acc[i][j][4 * k] * g.wscale, acc[i][j][4 * k + 1] * g.wscale,
-                                    acc[i][j][4 * k + 2] * g.wscale, acc[i][j][4 * k + 3] * g.wscale));
+          for (int k = 0; k < 4; ++k) {
+            const int n = nb + 8 * k;
+            if (pok && n + 4 <= g.N) {
+              ep.store4(img, m, n, make_float4(acc[i][j][4 * k] * g.wscale, acc[i][j][4 * k + 1] * g.wscale,
+                                               acc[i][j][4 * k + 2] * g.wscale, acc[i][j][4 * k + 3] * g.wscale));
+            } else if (pok) {  // N % 4 != 0: the last run is partial, element-wise
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) ep(img, m, n + e, acc[i][j][4 * k + e] * g.wscale);
+            }
+          }
         }
       }
     }
@@ -316,7 +322,7 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
   g.PH = TH + s.KH - 1; g.PW = TW + s.KW - 1;
   ATDN_CHECK(s.C0 % 32 == 0 && s.C1 % 32 == 0 && s.C0 > 0 && s.ld0 % 4 == 0, "TAP-mode channel constraints");
   ATDN_CHECK(s.ldw % 4 == 0 && s.ldw >= s.KH * s.KW * (s.C0 + s.C1), "weight rows too short");
-  ATDN_CHECK(!epi_vec4<Epi>::value || s.N % 4 == 0, "channel-vector epilogue needs N % 4 == 0");
+  ATDN_CHECK(!epi_vec4<Epi>::value || !Epi::kPrefetch || s.N % 4 == 0, "channel-vector epilogue with operand loads needs N % 4 == 0");
   ATDN_CHECK((long)s.H * s.W < (1L << 20) - 1, "image too large for the packed patch descriptor");
   g.tiles_x = cdiv(g.Wo, TW); g.tiles_y = cdiv(g.Ho, TH);
   g.nimg = s.nimg; g.ntile_n = cdiv(s.N, BN);
@@ -364,7 +370,8 @@ template <class Epi>
 inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out) {
   constexpr int kinds = epi_gen6<Epi>::value;
   if (kinds == 0 || !s.wfrag || s.stride != 1) return false;
-  if (epi_vec4<Epi>::value && (s.N % 4) != 0) return false;
+  if (epi_vec4<Epi>::value && Epi::kPrefetch && (s.N % 4) != 0) return false;
+  if (s.N < 4) return false;
   if (s.C0 % 32 != 0 || s.C1 % 32 != 0 || s.C0 <= 0 || s.ld0 % 4 != 0) return false;
   if constexpr ((kinds & 1) != 0) {
     if (s.KH == 3 && s.KW == 3) return conv_sf6_try_shape<3, 3>(s, wscale, ep, st, bn_out);

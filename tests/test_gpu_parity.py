@@ -111,6 +111,7 @@ HALO_CASES = [
     (384, 128, 5, 1, 2, 0, 47, 154, 6),   # q ConvGRU shape, vertical taps
     (128, 320, 3, 3, 1, 1, 17, 33, 9),    # two N tiles of 256, the second one partial
     (96, 32, 3, 3, 1, 1, 9, 200, 2),      # small grid: falls to the narrowest block
+    (256, 126, 3, 3, 1, 1, 47, 154, 4),   # motion-encoder conv: N % 4 != 0, partial last channel run
 ]
 
 
