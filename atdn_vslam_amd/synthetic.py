@@ -13,7 +13,7 @@ import zlib
 
 import numpy as np
 
-from .weights_spec import F32, clvo_state_spec, gma_state_spec
+from .weights_spec import F32, clvo_state_spec, gma_state_spec, vae_state_spec
 
 
 def _rs(seed, key):
@@ -80,6 +80,14 @@ def make_clvo_state(seed=0):
     for key, (shape, _) in clvo_state_spec().items():
         out[key] = _fill(key, shape, seed + 17, gain=1.0)
     out["encoder_CNN.0.weight"] = _rs(seed, "dw").uniform(0.5, 1.5, (2, 1, 1, 1)).astype(np.float32)
+    return out
+
+
+def make_vae_state(seed=0):
+    """Synthetic MappingVAE encoder + mean_lin state (numpy arrays)."""
+    out = {}
+    for key, (shape, _) in vae_state_spec().items():
+        out[key] = _fill(key, shape, seed + 29, gain=1.2)
     return out
 
 

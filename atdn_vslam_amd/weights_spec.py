@@ -128,3 +128,25 @@ def clvo_state_spec():
         _lin(s, head + ".1.linear", 64, 128)
         _lin(s, head + ".2", 3, 64, bias=False)
     return s
+
+
+VAE_CHANNELS = (3, 16, 16, 32, 64, 128, 128)
+
+
+def vae_state_spec():
+    """Ordered {key: (shape, dtype)} of the part of MappingVAE().state_dict() relocalisation uses: the encoder and
+    `mean_lin` (atdn_vslam/localization/network.py:29-45). The decoder only serves the VAE's training loss."""
+    s = OrderedDict()
+    _conv(s, "encoder.0.conv", 3, 3, 7, 7)
+    _bn(s, "encoder.0.bn", 3)
+    for i in range(1, 7):
+        cin, cout = VAE_CHANNELS[i - 1], VAE_CHANNELS[i]
+        p = "encoder.%d." % i
+        _conv(s, p + "conv.0.conv", cin, cin, 3, 3)
+        _bn(s, p + "conv.0.bn", cin)
+        _conv(s, p + "conv.1.conv", cout, cin, 3, 3)
+        _bn(s, p + "conv.1.bn", cout)
+        _conv(s, p + "skip_layer", cout, cin, 1, 1)
+        _bn(s, p + "out_block.1", cout)
+    _conv(s, "mean_lin", 128, 128, 1, 1)
+    return s

@@ -38,3 +38,52 @@ def test_ate_alignment_properties():
     e = ev.ate_rmse(noisy, gt, "se3")
     assert 0.1 < e < 0.2
     assert abs(ev.ate_rmse(gt, gt, "none")) == 0.0
+
+
+def test_forward_backward_fusion_matches_reference(golden_dir):
+    """eval/kalman.py run by tests/golden/make_golden_slam.py on the reference's own GT.txt / ATDN_prediction.txt."""
+    g = np.load(os.path.join(golden_dir, "kalman.npz"))
+    rf, tf = ev.relative_motions(g["forward"])
+    np.testing.assert_allclose(rf, g["rot_f"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(tf, g["tr_f"], rtol=0, atol=1e-12)
+    back = ev.reverse_backward_run(g["backward"])
+    np.testing.assert_allclose(ev.kitti_rows(back), g["backward_transformed"], rtol=0, atol=1e-10)
+    rb, tb = ev.relative_motions(back)
+    np.testing.assert_allclose(rb, g["rot_b"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(tb, g["tr_b"], rtol=0, atol=1e-10)
+    std = ev.motion_std(g["real"], g["forward"], back)
+    np.testing.assert_allclose(np.stack(std), g["std"], rtol=1e-9, atol=1e-14)
+    fused = ev.fuse_forward_backward(g["forward"], g["backward"], std)
+    assert fused.shape == (48, 4, 4)
+    np.testing.assert_allclose(ev.kitti_rows(fused), g["fused_rows"], rtol=0, atol=1e-9)
+    # the fused motion lies between the two runs, axis by axis
+    fr, _ = ev.relative_motions(fused)
+    assert np.all(fr <= np.maximum(rf, rb) + 1e-9) and np.all(fr >= np.minimum(rf, rb) - 1e-9)
+
+
+def test_kalman_fuse_weights():
+    x = ev.kalman_fuse(np.array([[1.0, 1.0, 1.0]]), np.array([[3.0, 3.0, 3.0]]), [1.0, 1.0, 1e-9], [1.0, 3.0, 1.0])
+    np.testing.assert_allclose(x, [[2.0, 1.2, 1.0]], atol=1e-9)
+
+
+def test_rpe_properties():
+    gt = _trajectory(120, 3)
+    t0, r0 = ev.rpe(gt, gt)
+    assert t0 < 1e-12 and r0 < 1e-6
+    # a rigid motion of the whole trajectory changes no relative pose
+    M = np.eye(4)
+    M[:3, :3] = pose_ref.euler2matrix([0.2, 0.1, -0.3])
+    M[:3, 3] = [3.0, 1.0, -2.0]
+    moved = np.stack([M @ p for p in gt])
+    t, r = ev.rpe(moved, gt)
+    assert t < 1e-9 and r < 1e-6
+    # a constant extra rotation per step shows up as exactly that angle
+    step = np.eye(4)
+    step[:3, :3] = pose_ref.euler2matrix([0.0, 0.0, 0.01])
+    drift = [np.eye(4)]
+    for i in range(120):
+        drift.append(drift[-1] @ (np.linalg.inv(gt[i]) @ gt[i + 1]) @ step)
+    t, r = ev.rpe(np.stack(drift), gt)
+    assert abs(r - 0.01) < 1e-6
+    t5, r5 = ev.rpe(np.stack(drift), gt, delta=5)
+    assert r5 > r
