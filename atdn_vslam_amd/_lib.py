@@ -29,6 +29,12 @@ SIGNATURES = {
     "atdn_clvo_encode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "atdn_clvo_step": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "atdn_clvo_destroy": (None, [_vp]),
+    "atdn_vae_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),
+    "atdn_vae_load": (C.c_int, [_vp, C.c_char_p, _vp, _i64p, C.c_int]),
+    "atdn_vae_finalize": (C.c_int, [_vp]),
+    "atdn_vae_embedding_shape": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "atdn_vae_encode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "atdn_vae_destroy": (None, [_vp]),
     "atdn_pose_transform_f32": (C.c_int, [_vp, _vp, _vp]),
     "atdn_pose_rel2abs": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "atdn_pose_accumulate_f32": (C.c_int, [_vp, _vp, _vp]),

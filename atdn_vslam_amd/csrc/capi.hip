@@ -5,6 +5,7 @@
 
 #include "clvo.h"
 #include "gma.h"
+#include "vae.h"
 #include "conv_sf.h"
 #include "epilogues_sf.h"
 
@@ -26,6 +27,7 @@ using namespace atdn;
 
 struct atdn_gma { GmaNet net; atdn_gma(int H, int W, int B, int prec) : net(H, W, B, prec) {} };
 struct atdn_clvo { ClvoNet net; atdn_clvo(int H, int W, int B) : net(H, W, B) {} };
+struct atdn_vae { VaeEncoder net; atdn_vae(int H, int W, int B) : net(H, W, B) {} };
 
 #define ATDN_API_BEGIN try {
 #define ATDN_API_END                                      \
@@ -196,6 +198,39 @@ int atdn_clvo_step(atdn_clvo* h, const float* feat, int T, int Bs, float* state,
   ATDN_API_END
 }
 void atdn_clvo_destroy(atdn_clvo* h) { delete h; }
+
+int atdn_vae_create(atdn_vae** out, int H, int W, int max_batch) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(out, "null out pointer");
+  *out = new atdn_vae(H, W, max_batch);
+  ATDN_API_END
+}
+int atdn_vae_load(atdn_vae* h, const char* key, const float* data, const int64_t* shape, int rank) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && key && data && rank >= 0 && rank <= 4, "bad state-dict entry");
+  h->net.state().put(key, data, shape, rank);
+  ATDN_API_END
+}
+int atdn_vae_finalize(atdn_vae* h) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.finalize();
+  ATDN_API_END
+}
+int atdn_vae_embedding_shape(const atdn_vae* h, int* out_h, int* out_w) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && out_h && out_w, "null argument");
+  *out_h = h->net.out_h();
+  *out_w = h->net.out_w();
+  ATDN_API_END
+}
+int atdn_vae_encode(atdn_vae* h, const float* images, int B, float* mu, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && images && mu, "null argument");
+  h->net.encode(images, B, mu, (hipStream_t)stream);
+  ATDN_API_END
+}
+void atdn_vae_destroy(atdn_vae* h) { delete h; }
 
 // ------------------------------------------------------------------ pose algebra (host)
 int atdn_pose_transform_f32(const float* rot, const float* tr, float* mat16) {

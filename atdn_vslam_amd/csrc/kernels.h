@@ -46,6 +46,8 @@ void launch_upsample(const float* mask, const float* flow4, int B, int H8, int W
 // flow NCHW [B,2,H,W] -> NHWC4: (x/std_c)*dw_w[c] + dw_b[c]    (normalizations.py:8-10, odometry/network.py:64)
 void launch_prep_flow(const float* flow, int B, int H, int W, const float* dw_w, const float* dw_b, float* out4,
                       hipStream_t st);
+// MappingVAE input normalisation: images NCHW [B,3,H,W] (0..255) -> NHWC4 (x/255 - mean)/std, 4th channel 0
+void launch_prep_rgb(const float* images, int B, int H, int W, float* out4, hipStream_t st);
 // y[b][n] = act( W0[n]·x0[b] (+ W1[n]·x1[b]) + b0[n] (+ b1[n]) ),  act: 0 none, 1 mish
 void launch_linear(const float* W0, const float* x0, int K0, int ldx0, const float* W1, const float* x1, int K1,
                    int ldx1, const float* b0, const float* b1, int act, float* y, int ldy, int N, int B,

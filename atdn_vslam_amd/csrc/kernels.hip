@@ -417,6 +417,27 @@ void launch_prep_flow(const float* flow, int B, int H, int W, const float* dw_w,
   ATDN_HIP(hipGetLastError());
 }
 
+// MappingVAE input: NCHW 0..255 -> NHWC4 with get_rgb_norm() applied (utils/normalizations.py:4-6: x/255, then
+// (x - mean)/std with the ImageNet statistics), 4th channel 0
+__global__ void prep_rgb_kernel(const float* __restrict__ img, int B, long HW, float4* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  const long b = i / HW, p = i - b * HW;
+  const float* s = img + b * 3 * HW + p;
+  float4 v;
+  v.x = ((s[0] / 255.0f) - 0.485f) / 0.229f;
+  v.y = ((s[HW] / 255.0f) - 0.456f) / 0.224f;
+  v.z = ((s[2 * HW] / 255.0f) - 0.406f) / 0.225f;
+  v.w = 0.f;
+  out[i] = v;
+}
+void launch_prep_rgb(const float* images, int B, int H, int W, float* out4, hipStream_t st) {
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(prep_rgb_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, images, B, (long)H * W,
+                     reinterpret_cast<float4*>(out4));
+  ATDN_HIP(hipGetLastError());
+}
+
 // one wave per output feature n, all batch rows; K multiples of 4, rows 16-byte aligned
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ W0, const float* __restrict__ x0, int K0,
                                                      int ldx0, const float* __restrict__ W1,

@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .weights_spec import F32, clvo_state_spec, gma_state_spec
+from .weights_spec import F32, clvo_state_spec, gma_state_spec, vae_state_spec
 
 _BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked", "rel_ind")
 
@@ -283,3 +283,57 @@ class ATDNVO(_NativeModule):
             self._state = self._state.to(flows.device)
         rot, tr, self._state = self.scan(feat[None], self._state, hw=tuple(flows.shape[2:]))
         return rot[0], tr[0]
+
+
+class MappingVAE(_NativeModule):
+    """Embedding half of the reference's MappingVAE (atdn_vslam/localization/network.py): `forward(image)` returns
+    the reference's 4-tuple `(mu, logvar, latent, decoded)` with `logvar = decoded = None` — the non-variational
+    model has no logvar, and the decoder only feeds the training loss (NeuralSLAM.__create_map), which is not on
+    this path. `mu` [B,128,H/64,W/64] is what relocalisation compares (neural_slam.py:355-383)."""
+
+    def __init__(self, variational=False):
+        super().__init__()
+        if variational:
+            raise NotImplementedError("only the shipped configuration MappingVAE() (non-variational)")
+        self.var = False
+        _build_tree(self, vae_state_spec())
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # checkpoints written by the reference also hold the decoder: not needed for the embedding
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("decoder.") and not k.startswith("module.decoder.")}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def _handle(self, H, W, B):
+        key = (H, W)
+        fp = self._fingerprint()
+        ent = self._handles.get(key)
+        if ent is not None and (ent[1] != fp or ent[3] < B):
+            ent[2](ent[0])
+            ent = None
+        if ent is None:
+            L = _lib.lib()
+            h = C.c_void_p()
+            _lib.check(L.atdn_vae_create(C.byref(h), H, W, B))
+            _lib.load_state(L.atdn_vae_load, h, self.state_dict())
+            _lib.check(L.atdn_vae_finalize(h))
+            ent = (h, fp, L.atdn_vae_destroy, B)
+            self._handles[key] = ent
+        return ent[0]
+
+    @torch.no_grad()
+    def forward(self, image):
+        _require_gpu(image, "MappingVAE.forward")
+        if image.dim() == 3:
+            image = image.unsqueeze(0)
+        if image.dim() != 4 or image.shape[1] != 3:
+            raise RuntimeError("expected image [B,3,H,W], got %s" % (tuple(image.shape),))
+        B, _, H, W = image.shape
+        with torch.cuda.device(image.device):
+            im = image.float().contiguous()
+            h = self._handle(H, W, B)
+            oh, ow = C.c_int(), C.c_int()
+            _lib.check(_lib.lib().atdn_vae_embedding_shape(h, C.byref(oh), C.byref(ow)))
+            mu = torch.empty((B, oh.value * ow.value, 128), dtype=torch.float32, device=image.device)
+            _lib.check(_lib.lib().atdn_vae_encode(h, _ptr(im), B, _ptr(mu), _stream()))
+        mu = mu.view(B, oh.value, ow.value, 128).permute(0, 3, 1, 2).contiguous()
+        return mu, None, mu, None

@@ -20,6 +20,7 @@ extern "C" {
 
 typedef struct atdn_gma atdn_gma;   /* RAFTGMA flow network handle */
 typedef struct atdn_clvo atdn_clvo; /* ATDNVO pose head handle */
+typedef struct atdn_vae atdn_vae;   /* MappingVAE encoder handle (relocalisation embedding) */
 
 int atdn_version(void);
 const char* atdn_last_error(void);
@@ -95,6 +96,22 @@ int atdn_clvo_encode(atdn_clvo* h, const float* flow, int B, float* feat, void* 
  *   rot, tr [T,Bs,3] (Euler yxz radians, translation). */
 int atdn_clvo_step(atdn_clvo* h, const float* feat, int T, int Bs, float* state, float* rot, float* tr, void* stream);
 void atdn_clvo_destroy(atdn_clvo* h);
+
+/* ---------------------------------------------------------------------------------------------------
+ * MappingVAE encoder  —  replaces the embedding half of atdn_vslam/localization/network.py `MappingVAE.forward`
+ * (57-70, non-variational: mu = mean_lin(encoder(get_rgb_norm()(image)))), which NeuralSLAM's relocalisation
+ * evaluates for every keyframe and query (slam_framework/neural_slam.py:88-103,158-164,355-383). State-dict keys
+ * as in MappingVAE().state_dict() (encoder.*, mean_lin.*); decoder.* keys are accepted and ignored by the host
+ * mirror (the decoder only feeds the VAE's training loss, which stays on stock PyTorch).
+ * ------------------------------------------------------------------------------------------------- */
+int atdn_vae_create(atdn_vae** out, int H, int W, int max_batch);
+int atdn_vae_load(atdn_vae* h, const char* key, const float* data, const int64_t* shape, int rank);
+int atdn_vae_finalize(atdn_vae* h);
+/* size of the embedding map: six stride-2 blocks, 376x1232 -> 6x20 */
+int atdn_vae_embedding_shape(const atdn_vae* h, int* out_h, int* out_w);
+/* images [B,3,H,W] float32 with values 0..255 (device) -> mu [B][out_h*out_w][128] channels-last (device) */
+int atdn_vae_encode(atdn_vae* h, const float* images, int B, float* mu, void* stream);
+void atdn_vae_destroy(atdn_vae* h);
 
 /* ---------------------------------------------------------------------------------------------------
  * Pose algebra (host, no GPU)  —  replaces atdn_vslam/utils/transforms.py

@@ -111,3 +111,29 @@ def test_pose_algebra(golden_dir):
     np.testing.assert_allclose(pose_ref.kitti_rows(absolute), g["kitti_rows"], rtol=0, atol=1e-12)
     for (h, w), pad in zip(g["pad_dims"], g["pads"]):
         assert pose_ref.pad_amounts(int(h), int(w)) == list(pad)
+
+
+def test_vae_encoder_oracle_matches_reference(golden_dir):
+    """oracle/vae_ref.py against the imported reference's MappingVAE on the same synthetic weights and frames."""
+    from oracle import vae_ref
+    g = np.load(os.path.join(golden_dir, "vae.npz"))
+    sd = syn.to_torch(syn.make_vae_state(seed=int(g["seed_weights"])))
+    frames = torch.from_numpy(syn.make_frames(5, 376, 1232, seed=int(g["seed_frames"])))[:2]
+    taps = {}
+    mu = vae_ref.vae_encode(sd, frames, taps)
+    assert tuple(mu.shape) == (2, 128, 6, 20)
+    np.testing.assert_allclose(mu.numpy(), g["mu"], rtol=0, atol=2e-5)
+    for k, v in taps.items():
+        sub = v[:, :, ::max(1, v.shape[2] // 12), ::max(1, v.shape[3] // 16)].numpy()
+        np.testing.assert_allclose(sub, g[k], rtol=0, atol=2e-5, err_msg=k)
+
+
+def test_vae_state_layout_matches_reference(golden_dir):
+    import json
+    from atdn_vslam_amd.weights_spec import vae_state_spec
+    keys = {k: tuple(s) for k, s in json.load(open(os.path.join(golden_dir, "state_keys.json")))["vae"]}
+    spec = vae_state_spec()
+    for k, (shape, _) in spec.items():
+        assert k in keys and keys[k] == tuple(shape), k
+    # everything the spec leaves out belongs to the decoder (training loss only)
+    assert all(k.startswith("decoder.") for k in keys if k not in spec)
