@@ -47,3 +47,75 @@ def test_vae_checkpoint_with_decoder_keys_loads(vsd):
     net.load_state_dict(full)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 376, 1232))  # CPU tensor: no fallback
+
+
+class _Args:
+    def __init__(self, path):
+        self.device = DEV
+        self.keyframes_path = path
+
+
+@pytest.fixture(scope="module")
+def gsd():
+    return syn.to_torch(syn.make_gma_state(seed=1))
+
+
+@pytest.fixture(scope="module")
+def hsd():
+    return syn.to_torch(syn.make_clvo_state(seed=1))
+
+
+def test_neuralslam_odometry_mode_matches_reference(golden_dir, gsd, hsd, tmp_path):
+    """Same call sequence as the reference run behind tests/golden/slam.npz: poses per call, keyframe count, and
+    the files the reference writes (rgb/000000.pth uint8 [3,376,1232]; poses.pth [K,12] at end_odometry)."""
+    from atdn_vslam_amd.slam import NeuralSLAM
+    g = np.load(os.path.join(golden_dir, "slam.npz"))
+    kf = os.path.join(str(tmp_path), "kf")
+    slam = NeuralSLAM(_Args(kf), odometry_weights=hsd, flow_weights={"module." + k: v for k, v in gsd.items()})
+    assert slam.mode() == "idle"
+    with pytest.raises(Exception):
+        slam(torch.zeros(3, 376, 1241))          # called in an invalid state
+    slam.start_odometry()
+    assert slam.mode() == "odometry"
+    frames = torch.from_numpy(syn.make_frames(4, 376, 1241, seed=int(g["seed_frames"])))
+    for i in range(4):
+        pose = slam(frames[i])
+        assert float((pose - torch.from_numpy(g["poses"][i])).abs().max()) < 2e-5, i
+    assert len(slam) == int(g["n_keyframes"])
+    first = torch.load(os.path.join(kf, "rgb", "000000.pth"))
+    assert first.dtype == torch.uint8 and tuple(first.shape) == (3, 376, 1232)
+    assert torch.equal(slam[0].pose, torch.eye(4)) and slam.get_keyframe(0).rgb_file_name.endswith("000000.pth")
+    # no trained MappingVAE: poses are persisted, the state machine stops in "mapping" with a clear error
+    with pytest.raises(RuntimeError, match="MappingVAE"):
+        slam.end_odometry()
+    assert slam.mode() == "mapping"
+    saved = torch.load(os.path.join(kf, "poses.pth"))
+    assert tuple(saved.shape) == (len(slam), 12) and torch.equal(saved[0], torch.eye(4).flatten()[:12])
+    # with weights it embeds the keyframes and relocalises
+    slam.end_odometry(mapping_weights=syn.to_torch(syn.make_vae_state(seed=2)))
+    assert slam.mode() == "relocalization" and slam[0].embedding is not None
+    init, refined, dist = slam(first.float())
+    assert float(dist[0]) < 1e-3 and torch.equal(init, slam[0].pose)
+
+
+def test_neuralslam_relocalization_matches_reference(golden_dir, gsd, hsd, vsd, tmp_path):
+    """The keyframe directory of tests/golden/make_golden_slam.py rebuilt from seeds; NeuralSLAM started in
+    "relocalization" mode must return the reference's distances, initial and refined poses for both queries
+    (the second one with the head's LSTM state carried over from the first, as in the reference)."""
+    from atdn_vslam_amd.slam import NeuralSLAM
+    g = np.load(os.path.join(golden_dir, "reloc.npz"))
+    frames = torch.from_numpy(syn.make_frames(5, 376, 1232, seed=int(g["seed_frames"])))
+    kf = os.path.join(str(tmp_path), "kf")
+    os.makedirs(os.path.join(kf, "rgb"))
+    for i in range(3):
+        torch.save(frames[i].byte(), os.path.join(kf, "rgb", "%06d.pth" % i))
+    torch.save(torch.from_numpy(g["keyframe_poses"]), os.path.join(kf, "poses.pth"))
+    torch.save(vsd, os.path.join(kf, "MappingVAE_weights.pth"))
+    slam = NeuralSLAM(_Args(kf), odometry_weights=hsd, flow_weights=gsd, start_mode="relocalization")
+    assert slam.mode() == "relocalization" and len(slam) == 3
+    for name, q in (("near1", frames[1].byte().float()), ("new", frames[4].byte().float())):
+        init, refined, dist = slam(q)
+        np.testing.assert_allclose(dist.numpy(), g[name + "_distances"], rtol=0, atol=2e-3)   # |mu| ~ 10, 15360 dims
+        assert int(torch.argmin(dist)) == int(np.argmin(g[name + "_distances"]))
+        np.testing.assert_allclose(init.numpy(), g[name + "_initial"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(refined.numpy(), g[name + "_refined"], rtol=0, atol=5e-5)
