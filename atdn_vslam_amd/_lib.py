@@ -35,6 +35,14 @@ SIGNATURES = {
     "atdn_vae_embedding_shape": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "atdn_vae_encode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "atdn_vae_destroy": (None, [_vp]),
+    "atdn_clvo_trainer_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "atdn_clvo_trainer_load": (C.c_int, [_vp, C.c_char_p, _vp, _i64p, C.c_int]),
+    "atdn_clvo_trainer_finalize": (C.c_int, [_vp]),
+    "atdn_clvo_trainer_forward_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32p, _vp]),
+    "atdn_clvo_trainer_gradients": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_long)]),
+    "atdn_clvo_trainer_adamw_step": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_int, _vp]),
+    "atdn_clvo_trainer_read": (C.c_long, [_vp, C.c_char_p, C.c_int, _vp, C.c_long, _vp]),
+    "atdn_clvo_trainer_destroy": (None, [_vp]),
     "atdn_pose_transform_f32": (C.c_int, [_vp, _vp, _vp]),
     "atdn_pose_rel2abs": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "atdn_pose_accumulate_f32": (C.c_int, [_vp, _vp, _vp]),

@@ -6,6 +6,7 @@
 #include "clvo.h"
 #include "gma.h"
 #include "vae.h"
+#include "clvo_train.h"
 #include "conv_sf.h"
 #include "epilogues_sf.h"
 
@@ -28,6 +29,7 @@ using namespace atdn;
 struct atdn_gma { GmaNet net; atdn_gma(int H, int W, int B, int prec) : net(H, W, B, prec) {} };
 struct atdn_clvo { ClvoNet net; atdn_clvo(int H, int W, int B) : net(H, W, B) {} };
 struct atdn_vae { VaeEncoder net; atdn_vae(int H, int W, int B) : net(H, W, B) {} };
+struct atdn_clvo_trainer { ClvoTrainer net; atdn_clvo_trainer(int H, int W, int B, int T) : net(H, W, B, T) {} };
 
 #define ATDN_API_BEGIN try {
 #define ATDN_API_END                                      \
@@ -231,6 +233,55 @@ int atdn_vae_encode(atdn_vae* h, const float* images, int B, float* mu, void* st
   ATDN_API_END
 }
 void atdn_vae_destroy(atdn_vae* h) { delete h; }
+
+int atdn_clvo_trainer_create(atdn_clvo_trainer** out, int H, int W, int batch, int sequence_length) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(out, "null out pointer");
+  *out = new atdn_clvo_trainer(H, W, batch, sequence_length);
+  ATDN_API_END
+}
+int atdn_clvo_trainer_load(atdn_clvo_trainer* h, const char* key, const float* data, const int64_t* shape, int rank) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && key && data && rank >= 0 && rank <= 4, "bad state-dict entry");
+  h->net.state().put(key, data, shape, rank);
+  ATDN_API_END
+}
+int atdn_clvo_trainer_finalize(atdn_clvo_trainer* h) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.finalize();
+  ATDN_API_END
+}
+int atdn_clvo_trainer_forward_backward(atdn_clvo_trainer* h, const float* flows, const float* true_rot, const float* true_tr,
+                                       float* pred_rot, float* pred_tr, float* loss_out, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && flows && true_rot && true_tr && loss_out, "null argument");
+  *loss_out = h->net.forward_backward(flows, true_rot, true_tr, pred_rot, pred_tr, (hipStream_t)stream);
+  ATDN_API_END
+}
+int atdn_clvo_trainer_gradients(atdn_clvo_trainer* h, float** device_ptr, long* count) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && device_ptr && count, "null argument");
+  *device_ptr = h->net.grad_buffer();
+  *count = h->net.grad_count();
+  ATDN_API_END
+}
+int atdn_clvo_trainer_adamw_step(atdn_clvo_trainer* h, float lr, float weight_decay, float eps, int step, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.adamw_step(lr, weight_decay, eps, step, (hipStream_t)stream);
+  ATDN_API_END
+}
+long atdn_clvo_trainer_read(atdn_clvo_trainer* h, const char* key, int kind, float* host, long capacity, void* stream) {
+  try {
+    ATDN_CHECK(h && key && host, "null argument");
+    return h->net.read(key, kind, host, capacity, (hipStream_t)stream);
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+void atdn_clvo_trainer_destroy(atdn_clvo_trainer* h) { delete h; }
 
 // ------------------------------------------------------------------ pose algebra (host)
 int atdn_pose_transform_f32(const float* rot, const float* tr, float* mat16) {

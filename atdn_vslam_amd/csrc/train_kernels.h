@@ -1,0 +1,79 @@
+// Kernels of the CLVO training step that are not convolutions (clvo_train.hip): train-mode BatchNorm + Mish forward
+// and backward on NHWC16 maps with per-call statistics groups, zero-stuffing for transposed convolutions, weight
+// gradients of the thin convolutions, small dense GEMMs, LSTM cell forward/backward, loss and AdamW.
+// Reference semantics: torch.nn.BatchNorm2d (training), nn.Mish, nn.LSTMCell, odometry/loss.py, torch.optim.AdamW.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace atdn {
+
+// ---- weight packing for the ROW-mode conv engine, on the device (weights change every iteration)
+// forward:   dst[n][ky*ldr + kx*Cpix + c] = w[n][c][ky][kx]                         rows = N
+// transposed (for the data gradient): dst[c][ky*ldr + kx*Cpix + n] = w[n][c][KH-1-ky][KW-1-kx]   rows = Cin
+// ldr = round_up(KW*Cpix, 32); every other entry of dst is written as 0.
+void launch_pack_row(const float* w, int N, int Cin, int Cpix, int KH, int KW, bool transposed, float* dst, hipStream_t st);
+
+// ---- train-mode BatchNorm over NHWC16 maps; G statistic groups of P pixels each (a group = one forward() call)
+constexpr int BN_C = 16;
+int bn_partial_blocks(long P);  // blocks per group the reduction kernels use
+// part[G][nblk][2][16]: sum and sum of squares of a = mish(z) (mish=true) or of z itself
+void launch_bn_stats(const float* z, int G, long P, bool mish, float* part, hipStream_t st);
+// mean/rstd [G][16]; running stats updated sequentially over the G calls (momentum 0.1, unbiased variance)
+void launch_bn_finalize(const float* part, int G, long P, float* running_mean, float* running_var, float* mean,
+                        float* rstd, hipStream_t st);
+// y = (act(z) - mean) * rstd * gamma + beta (+ add), act = mish or identity
+void launch_bn_apply(const float* z, int G, long P, bool mish, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, const float* add, float* y, hipStream_t st);
+// backward: part[G][nblk][2][16] = sum dy, sum dy*xhat
+void launch_bn_bwd_stats(const float* dy, const float* z, int G, long P, bool mish, const float* mean, const float* rstd,
+                         float* part, hipStream_t st);
+// sums[G][2][16] from the partials; dgamma += sum_g sum dy*xhat, dbeta += sum_g sum dy
+void launch_bn_bwd_finalize(const float* part, int G, long P, float* sums, float* dgamma, float* dbeta, hipStream_t st);
+// dz = gamma*rstd*(dy - sum_dy/P - xhat*sum_dyx/P) * act'(z); part_db[G][nblk][16] = per-block sums of dz
+void launch_bn_bwd_apply(const float* dy, const float* z, int G, long P, bool mish, const float* mean, const float* rstd,
+                         const float* gamma, const float* sums, float* dz, float* part_db, hipStream_t st);
+// out[16] += sum over G*nblk partial rows of 16
+void launch_sum_partials16(const float* part, long rows, float* out, hipStream_t st);
+
+// ---- transposed convolution support
+// D[img][Hs][Ws][16] = dz[img][y/s][x/s][:] where y, x are multiples of s inside the Ho x Wo map, else 0
+void launch_zero_stuff(const float* dz, int nimg, int Ho, int Wo, int stride, int Hs, int Ws, float* D, hipStream_t st);
+void launch_add_inplace(float* a, const float* b, long n, hipStream_t st);
+
+// ---- weight gradient of a thin convolution: x [nimg][H][W][Cpix] (Cin real channels), dz [nimg][Ho][Wo][16]
+// dW[n][c][ky][kx] += sum dz[.,oy,ox,n] * x[., oy*s - pad + ky, ox*s - pad + kx, c]   (OIHW, N = 16)
+// scratch: at least wgrad_scratch_floats(...) floats
+long wgrad_scratch_floats(int nimg, int Ho, int Cin, int KH, int KW);
+void launch_conv_wgrad(const float* x, int Cpix, int Cin, int nimg, int H, int W, const float* dz, int Ho, int Wo, int KH,
+                       int KW, int stride, int pad, float* scratch, float* dW, hipStream_t st);
+// depthwise 1x1 in front of the encoder: x0[c] = (flow[c]/std[c]) * w[c] + b[c];  dw[c] += sum dx0[c]*flow[c]/std[c], db[c] += sum dx0[c]
+void launch_dw_grad(const float* flow, const float* dx0 /*NHWC4*/, int nimg, long HW, float* scratch, float* dw, float* db,
+                    hipStream_t st);
+
+// ---- dense algebra on small matrices (row-major): C[M][N] = beta*C + op(A)*op(B) (+ bias[N] broadcast over rows)
+void launch_gemm(bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                 int ldc, float beta, const float* bias, hipStream_t st);
+void launch_colsum(const float* X, int rows, int cols, int ld, float* out /* += */, hipStream_t st);
+void launch_mish_fwd(const float* z, float* a, long n, hipStream_t st);
+void launch_mish_bwd(const float* dy, const float* z, float* dz, long n, hipStream_t st);
+// [nimg][P][16] <-> [nimg][16][P]
+void launch_nhwc_to_chw(const float* src, int nimg, int P, float* dst, hipStream_t st);
+void launch_chw_to_nhwc(const float* src, int nimg, int P, float* dst, hipStream_t st);
+
+// ---- LSTM cell (torch gate order i, f, g, o; hidden 512). pre[B][2048] = x W_ih^T + h W_hh^T + b_ih + b_hh
+// act[B][2048] (sigmoid/tanh applied), c_out = f*c_in + i*g, tanhc = tanh(c_out), h_out = o*tanhc
+void launch_lstm_fwd(const float* pre, const float* c_in, int B, float* act, float* c_out, float* tanhc, float* h_out,
+                     hipStream_t st);
+// dpre[B][2048], dc_in[B][512] from dh[B][512] (all consumers summed), dc_out[B][512] (from the next step; may be null)
+void launch_lstm_bwd(const float* dh, const float* dc_out, const float* act, const float* c_in, const float* tanhc, int B,
+                     float* dpre, float* dc_in, hipStream_t st);
+
+// ---- loss (odometry/loss.py, alpha = 1): L = mean_b sum_t (delta*|dt|^2 + khi*|dr|^2); also the gradients
+void launch_clvo_loss(const float* pred_rot, const float* pred_tr, const float* true_rot, const float* true_tr, int B, int T,
+                      float* loss /*[1]*/, float* d_rot, float* d_tr, hipStream_t st);
+
+// ---- AdamW (torch.optim.AdamW, amsgrad off) on a flat range; t = 1-based step
+void launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float wd, float eps, float beta1,
+                  float beta2, int t, hipStream_t st);
+
+}  // namespace atdn

@@ -33,6 +33,11 @@ class StateDict {
     return it->second;
   }
   bool has(const std::string& key) const { return map_.count(key) != 0; }
+  std::vector<std::string> keys() const {
+    std::vector<std::string> k;
+    for (auto& e : map_) k.push_back(e.first);
+    return k;
+  }
   size_t size() const { return map_.size(); }
 
  private:

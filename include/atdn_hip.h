@@ -21,6 +21,7 @@ extern "C" {
 typedef struct atdn_gma atdn_gma;   /* RAFTGMA flow network handle */
 typedef struct atdn_clvo atdn_clvo; /* ATDNVO pose head handle */
 typedef struct atdn_vae atdn_vae;   /* MappingVAE encoder handle (relocalisation embedding) */
+typedef struct atdn_clvo_trainer atdn_clvo_trainer; /* ATDNVO training-iteration handle */
 
 int atdn_version(void);
 const char* atdn_last_error(void);
@@ -96,6 +97,29 @@ int atdn_clvo_encode(atdn_clvo* h, const float* flow, int B, float* feat, void* 
  *   rot, tr [T,Bs,3] (Euler yxz radians, translation). */
 int atdn_clvo_step(atdn_clvo* h, const float* feat, int T, int Bs, float* state, float* rot, float* tr, void* stream);
 void atdn_clvo_destroy(atdn_clvo* h);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CLVO training iteration  —  replaces the body of train() in train_odometry.py:21-49 for one batch:
+ *   model.train(); T x model(fl[:, j]) with the LSTM state carried; CLVO_Loss(alpha = 1); loss.backward();
+ *   optimizer.step() (AdamW, train_odometry.py:99); model.reset_lstm().
+ * BatchNorm layers use per-call batch statistics and update their running averages (momentum 0.1), as torch does.
+ * Gradients sit in ONE flat device buffer (`atdn_clvo_trainer_gradients`): data-parallel training all-reduces that
+ * buffer (RCCL, averaged over ranks) between forward_backward and adamw_step — see atdn_vslam_amd/training.py.
+ * State-dict keys as in ATDNVO().state_dict().
+ * ------------------------------------------------------------------------------------------------- */
+int atdn_clvo_trainer_create(atdn_clvo_trainer** out, int H, int W, int batch, int sequence_length);
+int atdn_clvo_trainer_load(atdn_clvo_trainer* h, const char* key, const float* data, const int64_t* shape, int rank);
+int atdn_clvo_trainer_finalize(atdn_clvo_trainer* h);
+/* flows [batch, T, 2, H, W], true_rot / true_tr [batch, T, 3] (device). Returns the loss; pred_rot / pred_tr
+ * [batch, T, 3] (device) are optional. Overwrites the gradient buffer, advances the BatchNorm running statistics. */
+int atdn_clvo_trainer_forward_backward(atdn_clvo_trainer* h, const float* flows, const float* true_rot, const float* true_tr,
+                                       float* pred_rot, float* pred_tr, float* loss_out, void* stream);
+int atdn_clvo_trainer_gradients(atdn_clvo_trainer* h, float** device_ptr, long* count);
+/* torch.optim.AdamW (betas 0.9 / 0.999) on every parameter forward() uses; step is 1-based */
+int atdn_clvo_trainer_adamw_step(atdn_clvo_trainer* h, float lr, float weight_decay, float eps, int step, void* stream);
+/* copy a named tensor to the host: kind 0 parameter, 1 gradient, 2 BatchNorm running statistic; returns the count or -1 */
+long atdn_clvo_trainer_read(atdn_clvo_trainer* h, const char* key, int kind, float* host, long capacity, void* stream);
+void atdn_clvo_trainer_destroy(atdn_clvo_trainer* h);
 
 /* ---------------------------------------------------------------------------------------------------
  * MappingVAE encoder  —  replaces the embedding half of atdn_vslam/localization/network.py `MappingVAE.forward`
