@@ -160,7 +160,7 @@ void ClvoTrainer::finalize() {
   const long Pmax = (long)B * px(1);
   part_.alloc((long)T * bn_partial_blocks(Pmax) * 2 * 16 + 64);
   sums_.alloc((long)T * 2 * 16);
-  wscratch_.alloc(std::max<long>(wgrad_scratch_floats(0, 0, 16, 3, 3), 4096));
+  wscratch_.alloc(std::max(wgrad_scratch_floats(0, 0, 16, 3, 3), wgrad_scratch_floats(0, 0, 3, 7, 7)));
   loss_.alloc(4);
   flow_.alloc(nimg * 2 * px(0));
   x0_.alloc(nimg * px(0) * 4);
@@ -182,11 +182,12 @@ void ClvoTrainer::finalize() {
   }
   const long gmax = nimg * px(1) * 16;
   ga_.alloc(gmax); gb_.alloc(gmax); gc_.alloc(gmax);
-  stuffed_.alloc(nimg * px(0) * 16);
+  stuffed_.alloc(nimg * px(1) * 16);  // largest zero-stuffed gradient: a stride-2 block's output at its input size
   // small gradient scratch: 0 d_rot, 1 d_tr, 2 dh2 [TB][512], 3 dpre [TB][2048], 4 dh1 / dx [TB][512], 5 rec + dc ping-pong,
   // 6 head scratch, 7 dflat [TB][832]
   dsmall_[0].alloc(TB * 4); dsmall_[1].alloc(TB * 4); dsmall_[2].alloc(TB * 512); dsmall_[3].alloc(TB * 2048);
-  dsmall_[4].alloc(TB * 512); dsmall_[5].alloc(3L * B * 512); dsmall_[6].alloc(TB * 256); dsmall_[7].alloc(TB * 832);
+  dsmall_[4].alloc(TB * 512); dsmall_[5].alloc(3L * B * 512); dsmall_[6].alloc(TB * 256);
+  dsmall_[7].alloc(std::max<long>(TB * 832, 16 * 3 * 49));
   ready_ = true;
 }
 
@@ -397,9 +398,12 @@ float ClvoTrainer::forward_backward(const float* flows, const float* true_rot, c
     launch_add_inplace(cur, t2, (long)nimg * h * w * 16, st);
   }
   bn_bwd(stem_.bn, cur, z1_.p, Pg(1), true, cur, G(stem_.conv.b), st);                      // cur = dz1
-  launch_conv_wgrad(x0_.p, 4, 2, nimg, H, W, cur, hs_[1], ws_[1], 7, 7, 2, 3, wscratch_.p, G(stem_.conv.w), st);
-  conv_bwd_data(stem_.conv, cur, H, W, hs_[1], ws_[1], t1, 4, st);                          // t1 = dx0 (NHWC4, 2 channels)
-  launch_dw_grad(flow_.p, t1, nimg, px(0), wscratch_.p, G(dw_w_), G(dw_b_), st);
+  // stem weights and the depthwise 1x1 in front of it: one weight-gradient pass on (xn0, xn1, 1), then a combine
+  launch_prep_flow_aux(flow_.p, nimg, H, W, t1, st);                                        // t1 = auxiliary input, NHWC4
+  float* A = dsmall_[7].p;                                                                  // [16][3][49]
+  ATDN_HIP(hipMemsetAsync(A, 0, 16 * 3 * 49 * sizeof(float), st));
+  launch_conv_wgrad(t1, 4, 3, nimg, H, W, cur, hs_[1], ws_[1], 7, 7, 2, 3, wscratch_.p, A, st);
+  launch_stem_combine(A, P(stem_.conv.w), P(dw_w_), P(dw_b_), 49, G(stem_.conv.w), G(dw_w_), G(dw_b_), st);
 
   float loss = 0.f;
   ATDN_HIP(hipMemcpyAsync(&loss, loss_.p, sizeof(float), hipMemcpyDeviceToHost, st));

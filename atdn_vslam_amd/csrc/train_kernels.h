@@ -46,9 +46,12 @@ void launch_add_inplace(float* a, const float* b, long n, hipStream_t st);
 long wgrad_scratch_floats(int nimg, int Ho, int Cin, int KH, int KW);
 void launch_conv_wgrad(const float* x, int Cpix, int Cin, int nimg, int H, int W, const float* dz, int Ho, int Wo, int KH,
                        int KW, int stride, int pad, float* scratch, float* dW, hipStream_t st);
-// depthwise 1x1 in front of the encoder: x0[c] = (flow[c]/std[c]) * w[c] + b[c];  dw[c] += sum dx0[c]*flow[c]/std[c], db[c] += sum dx0[c]
-void launch_dw_grad(const float* flow, const float* dx0 /*NHWC4*/, int nimg, long HW, float* scratch, float* dw, float* db,
-                    hipStream_t st);
+// depthwise 1x1 in front of the encoder: x0[c] = xn[c]*w[c] + b[c] with xn = flow/std. Its gradients and the stem
+// conv's weight gradient all follow from A = conv_wgrad of the stem taken on the auxiliary input (xn0, xn1, 1)
+// (launch_prep_flow_aux, Cin = 3): see stem_combine_kernel. No data gradient of the stem conv is ever formed.
+void launch_prep_flow_aux(const float* flow, int nimg, int H, int W, float* out4, hipStream_t st);
+void launch_stem_combine(const float* A /*[16][3][taps]*/, const float* W1 /*[16][2][taps]*/, const float* w, const float* b,
+                         int taps, float* dW1, float* dw, float* db, hipStream_t st);
 
 // ---- dense algebra on small matrices (row-major): C[M][N] = beta*C + op(A)*op(B) (+ bias[N] broadcast over rows)
 void launch_gemm(bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,

@@ -9,12 +9,20 @@
 namespace atdn {
 
 namespace {
-__device__ __forceinline__ float mish_grad(float x) {
-  if (x > 20.0f) return 1.0f;
-  const float sp = log1pf(expf(x));
-  const float t = tanhf(sp);
-  return t + x * (1.0f - t * t) * sigmoidf_(x);
+// Mish and its derivative from ONE exponential: with n = e^x, tanh(softplus(x)) = t/(t+2), t = n(n+2).
+// (The library formula x*tanh(log1p(exp(x))) costs ~40 instructions per element and made the BatchNorm passes
+// ALU-bound at 0.9 TB/s; the two forms agree to a few ulp.)
+struct MishVal { float y, dy; };
+__device__ __forceinline__ MishVal mish_both(float x) {
+  if (x > 20.0f) return {x, 1.0f};
+  const float n = __expf(x);
+  const float t = n * (n + 2.0f);
+  const float th = t / (t + 2.0f);
+  const float sg = n / (1.0f + n);
+  return {x * th, th + x * (1.0f - th * th) * sg};
 }
+__device__ __forceinline__ float mish_fast(float x) { return mish_both(x).y; }
+__device__ __forceinline__ float mish_grad(float x) { return mish_both(x).dy; }
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 constexpr int kRedThreads = 256;
 constexpr long kPixPerBlock = 16384;  // pixels one reduction block walks over
@@ -59,7 +67,14 @@ __global__ __launch_bounds__(kRedThreads) void reduce2_kernel(long P, int nblk, 
   const int quad = threadIdx.x & 3, lane_pix = threadIdx.x >> 2;
   const long p0 = (long)blk * kPixPerBlock, p1 = min(p0 + kPixPerBlock, P);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  for (long p = p0 + lane_pix; p < p1; p += kRedThreads / 4) f((long)g * P + p, g, quad, s1, s2);
+  constexpr int kStep = kRedThreads / 4;
+  long p = p0 + lane_pix;
+  for (; p + 3 * kStep < p1; p += 4 * kStep) {   // four independent loads in flight per thread
+    typename F::Elem e0 = f.load((long)g * P + p, quad), e1 = f.load((long)g * P + p + kStep, quad),
+                     e2 = f.load((long)g * P + p + 2 * kStep, quad), e3 = f.load((long)g * P + p + 3 * kStep, quad);
+    f.acc(e0, g, quad, s1, s2); f.acc(e1, g, quad, s1, s2); f.acc(e2, g, quad, s1, s2); f.acc(e3, g, quad, s1, s2);
+  }
+  for (; p < p1; p += kStep) f.acc(f.load((long)g * P + p, quad), g, quad, s1, s2);
   __shared__ float red[2][kRedThreads][4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
@@ -74,11 +89,12 @@ __global__ __launch_bounds__(kRedThreads) void reduce2_kernel(long P, int nblk, 
 
 struct StatsFwd {
   const float4* z; int mish;
-  __device__ __forceinline__ void operator()(long pix, int, int quad, float* s1, float* s2) const {
-    const float4 v = z[pix * 4 + quad];
+  typedef float4 Elem;
+  __device__ __forceinline__ Elem load(long pix, int quad) const { return z[pix * 4 + quad]; }
+  __device__ __forceinline__ void acc(const Elem& v, int, int quad, float* s1, float* s2) const {
     const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float x = mish ? mishf_(a[e]) : a[e]; s1[e] += x; s2[e] += x * x; }
+    for (int e = 0; e < 4; ++e) { const float x = mish ? mish_fast(a[e]) : a[e]; s1[e] += x; s2[e] += x * x; }
   }
 };
 void launch_bn_stats(const float* z, int G, long P, bool mish, float* part, hipStream_t st) {
@@ -132,7 +148,7 @@ __global__ void bn_apply_kernel(const float4* __restrict__ z, long P, int mish, 
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int ch = quad * 4 + e;
-    const float x = mish ? mishf_(a[e]) : a[e];
+    const float x = mish ? mish_fast(a[e]) : a[e];
     o[e] = (x - mean[g * 16 + ch]) * rstd[g * 16 + ch] * gamma[ch] + beta[ch];
   }
   if (add) { const float4 r = add[i]; o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
@@ -149,13 +165,15 @@ void launch_bn_apply(const float* z, int G, long P, bool mish, const float* mean
 
 struct StatsBwd {
   const float4* dy; const float4* z; int mish; const float* mean; const float* rstd;
-  __device__ __forceinline__ void operator()(long pix, int g, int quad, float* s1, float* s2) const {
-    const float4 d = dy[pix * 4 + quad], v = z[pix * 4 + quad];
+  struct Elem { float4 d, v; };
+  __device__ __forceinline__ Elem load(long pix, int quad) const { return {dy[pix * 4 + quad], z[pix * 4 + quad]}; }
+  __device__ __forceinline__ void acc(const Elem& el, int g, int quad, float* s1, float* s2) const {
+    const float4 d = el.d, v = el.v;
     const float dd[4] = {d.x, d.y, d.z, d.w}, a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ch = quad * 4 + e;
-      const float x = mish ? mishf_(a[e]) : a[e];
+      const float x = mish ? mish_fast(a[e]) : a[e];
       const float xh = (x - mean[g * 16 + ch]) * rstd[g * 16 + ch];
       s1[e] += dd[e];
       s2[e] += dd[e] * xh;
@@ -212,21 +230,28 @@ __global__ __launch_bounds__(kRedThreads) void bn_bwd_apply_kernel(const float4*
     m1[e] = sums[(g * 2 + 0) * 16 + ch] * invP;
     m2[e] = sums[(g * 2 + 1) * 16 + ch] * invP;
   }
-  for (long p = p0 + lane_pix; p < p1; p += kRedThreads / 4) {
-    const long i = ((long)g * P + p) * 4 + quad;
-    const float4 d = dy[i], v = z[i];
+  auto one = [&](long i, const float4 d, const float4 v) {
     const float dd[4] = {d.x, d.y, d.z, d.w}, a[4] = {v.x, v.y, v.z, v.w};
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float x = mish ? mishf_(a[e]) : a[e];
-      const float xh = (x - mu[e]) * rs[e];
+      MishVal mv = {a[e], 1.0f};
+      if (mish) mv = mish_both(a[e]);
+      const float xh = (mv.y - mu[e]) * rs[e];
       const float da = ga[e] * rs[e] * (dd[e] - m1[e] - xh * m2[e]);
-      o[e] = mish ? da * mish_grad(a[e]) : da;
+      o[e] = da * mv.dy;
       sdb[e] += o[e];
     }
     dz[i] = make_float4(o[0], o[1], o[2], o[3]);
+  };
+  constexpr int kStep = kRedThreads / 4;
+  long p = p0 + lane_pix;
+  for (; p + 3 * kStep < p1; p += 4 * kStep) {   // eight independent loads in flight per thread
+    const long i0 = ((long)g * P + p) * 4 + quad, i1 = i0 + 4L * kStep, i2 = i0 + 8L * kStep, i3 = i0 + 12L * kStep;
+    const float4 d0 = dy[i0], v0 = z[i0], d1 = dy[i1], v1 = z[i1], d2 = dy[i2], v2 = z[i2], d3 = dy[i3], v3 = z[i3];
+    one(i0, d0, v0); one(i1, d1, v1); one(i2, d2, v2); one(i3, d3, v3);
   }
+  for (; p < p1; p += kStep) { const long i = ((long)g * P + p) * 4 + quad; one(i, dy[i], z[i]); }
   __shared__ float red[kRedThreads][4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[threadIdx.x][e] = sdb[e];
@@ -300,79 +325,114 @@ void launch_add_inplace(float* a, const float* b, long n, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------ weight gradients
 namespace {
-constexpr int WG_R = 4;                // output rows staged per step; the column count is chosen to fit LDS
-constexpr int WG_BLOCKS = 1024;       // persistent blocks; partials are [output][block]
-constexpr int WG_MAXO = 9;            // outputs per thread (3x3x16x16 = 2304 = 9 x 256)
+constexpr int WG_TW = 32;        // output columns staged per step
+constexpr int WG_BLOCKS = 1024;  // persistent blocks; partials are [output][block]
+constexpr int wg_nf4(int S, int KW) { return (3 * S + KW + 3) / 4; }   // float4 loads covering 4 output columns of one tap row
+constexpr int wg_pwpad(int S, int KW) {
+  int need = (WG_TW - 4) * S + wg_nf4(S, KW) * 4;
+  int p = ((WG_TW - 1) * S + KW + 3) / 4 * 4;
+  if (p < need) p = need;
+  if ((p / 4) % 2 == 0) p += 4;   // odd multiple of 4 dwords: the 16 channel rows of a ds_read_b128 group hit 16 distinct bank quads
+  return p;
 }
+}  // namespace
 long wgrad_scratch_floats(int, int, int Cin, int KH, int KW) { return (long)WG_BLOCKS * KH * KW * 16 * Cin; }
 
-// Thread t owns outputs o = t + 256*k (k < WG_MAXO), o = (tap*16 + n)*Cin + c: for Cin = 16 a thread keeps one (n, c)
-// pair for all taps, a wave reads 16 consecutive channels of one patch pixel (conflict-free, broadcast over n).
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, int Cpix, int Cin, int nimg, int H, int W,
-                                                         const float* __restrict__ dz, int Ho, int Wo, int KH, int KW,
-                                                         int stride, int pad, int WG_TW, float* __restrict__ scratch) {
-  extern __shared__ float lds[];
-  const int total = KH * KW * 16 * Cin;
-  const int PH = (WG_R - 1) * stride + KH, PWp = (WG_TW - 1) * stride + KW;
-  float* xs = lds;                          // [PH][PWp][Cpix]
-  float* ds = lds + PH * PWp * Cpix;        // [WG_R][WG_TW][16]
-  int off_x[WG_MAXO], n_o[WG_MAXO];
-  float acc[WG_MAXO];
+// Thread (n, c, g): output channel n, input channel c, and the kernel rows ky = g, g + GROUPS, ... with ALL kx of those
+// rows (GROUPS = 256 / (16*CIN)). The staged input patch is channel-major in LDS, xs[py][c][px], so the 3*S + KW
+// consecutive px a thread needs for 4 adjacent output columns are NF4 aligned ds_read_b128; the gradient tile is
+// ds[r][n][col] (one b128 per 4 columns): 0.2 LDS loads per FMA instead of 1.1 with a pixel-major patch.
+template <int S, int KH, int KW, int CIN, int R>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, int Cpix, int nimg, int H, int W,
+                                                         const float* __restrict__ dz, int Ho, int Wo, int pad,
+                                                         float* __restrict__ scratch) {
+  constexpr int PAIRS = 16 * CIN, GROUPS = 256 / PAIRS, NKY = (KH + GROUPS - 1) / GROUPS;
+  constexpr int PH = (R - 1) * S + KH, PWP = wg_pwpad(S, KW), NF4 = wg_nf4(S, KW);
+  __shared__ __attribute__((aligned(16))) float xs[PH * CIN * PWP];
+  __shared__ __attribute__((aligned(16))) float ds[R * 16 * WG_TW];
+  const int pair = threadIdx.x % PAIRS, g = threadIdx.x / PAIRS;
+  const bool worker = g < GROUPS;
+  const int c = pair % CIN, n = pair / CIN;
+  float acc[NKY][KW];
 #pragma unroll
-  for (int k = 0; k < WG_MAXO; ++k) {
-    const int o = threadIdx.x + 256 * k;
-    acc[k] = 0.f;
-    if (o < total) {
-      const int c = o % Cin, n = (o / Cin) & 15, tap = o / (Cin * 16);
-      const int ky = tap / KW, kx = tap - ky * KW;
-      off_x[k] = (ky * PWp + kx) * Cpix + c;
-      n_o[k] = n;
-    } else {
-      off_x[k] = -1;
-      n_o[k] = 0;
-    }
-  }
-  const int rblocks = cdiv_dev(Ho, WG_R), cblocks = cdiv_dev(Wo, WG_TW);
+  for (int i = 0; i < NKY; ++i)
+#pragma unroll
+    for (int k = 0; k < KW; ++k) acc[i][k] = 0.f;
+  const int rblocks = cdiv_dev(Ho, R), cblocks = cdiv_dev(Wo, WG_TW);
   const long items = (long)nimg * rblocks * cblocks;
   for (long it = blockIdx.x; it < items; it += gridDim.x) {
-    const int cb = (int)(it % cblocks);
+    const int cb0 = (int)(it % cblocks);
     const int rb = (int)((it / cblocks) % rblocks);
     const int img = (int)(it / ((long)cblocks * rblocks));
-    const int oy0 = rb * WG_R, ox0 = cb * WG_TW;
-    const int iy0 = oy0 * stride - pad, ix0 = ox0 * stride - pad;
+    const int oy0 = rb * R, ox0 = cb0 * WG_TW;
+    const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
     __syncthreads();
-    for (int i = threadIdx.x; i < PH * PWp * Cpix; i += 256) {
-      const int ch = i % Cpix, px = (i / Cpix) % PWp, py = i / (Cpix * PWp);
+    for (int i = threadIdx.x; i < PH * PWP; i += 256) {   // one patch pixel per thread: CIN channels, scattered by row
+      const int px = i % PWP, py = i / PWP;
       const int iy = iy0 + py, ix = ix0 + px;
-      float v = 0.f;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((long)img * H + iy) * W + ix) * Cpix + ch];
-      xs[i] = v;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const float* src = x + (((long)img * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cpix;
+#pragma unroll
+      for (int ch = 0; ch < CIN; ++ch) xs[(py * CIN + ch) * PWP + px] = ok ? src[ch] : 0.f;
     }
-    for (int i = threadIdx.x; i < WG_R * WG_TW * 16; i += 256) {
-      const int ch = i & 15, col = (i >> 4) % WG_TW, r = i / (16 * WG_TW);
+    for (int i = threadIdx.x; i < R * WG_TW; i += 256) {
+      const int col = i % WG_TW, r = i / WG_TW;
       const int oy = oy0 + r, ox = ox0 + col;
-      float v = 0.f;
-      if (oy < Ho && ox < Wo) v = dz[(((long)img * Ho + oy) * Wo + ox) * 16 + ch];
-      ds[i] = v;
+      const bool ok = oy < Ho && ox < Wo;
+      const float4* src = reinterpret_cast<const float4*>(dz + (((long)img * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0)) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = src[q];
+        ds[(r * 16 + 4 * q + 0) * WG_TW + col] = ok ? v.x : 0.f;
+        ds[(r * 16 + 4 * q + 1) * WG_TW + col] = ok ? v.y : 0.f;
+        ds[(r * 16 + 4 * q + 2) * WG_TW + col] = ok ? v.z : 0.f;
+        ds[(r * 16 + 4 * q + 3) * WG_TW + col] = ok ? v.w : 0.f;
+      }
     }
     __syncthreads();
-    for (int r = 0; r < WG_R; ++r)
-      for (int col = 0; col < WG_TW; ++col) {
-        const float* dp = ds + (r * WG_TW + col) * 16;
-        const float* xp = xs + (r * stride * PWp + col * stride) * Cpix;
+    if (worker) {
+#pragma unroll 1
+      for (int r = 0; r < R; ++r)
+#pragma unroll 2
+        for (int cb = 0; cb < WG_TW / 4; ++cb) {
+          const float4 d4 = *reinterpret_cast<const float4*>(ds + (r * 16 + n) * WG_TW + cb * 4);
+          const float d[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-        for (int k = 0; k < WG_MAXO; ++k)
-          if (off_x[k] >= 0) acc[k] += dp[n_o[k]] * xp[off_x[k]];
-      }
+          for (int i = 0; i < NKY; ++i) {
+            const int ky = g + i * GROUPS;
+            if (ky < KH) {
+              const float4* xp = reinterpret_cast<const float4*>(xs + ((r * S + ky) * CIN + c) * PWP + cb * 4 * S);
+              float xr[NF4 * 4];
+#pragma unroll
+              for (int q = 0; q < NF4; ++q) {
+                const float4 v = xp[q];
+                xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+              }
+#pragma unroll
+              for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][kx] += d[j] * xr[j * S + kx];
+            }
+          }
+        }
+    }
   }
+  if (worker) {
 #pragma unroll
-  for (int k = 0; k < WG_MAXO; ++k) {
-    const int o = threadIdx.x + 256 * k;
-    if (o < total) scratch[(long)o * gridDim.x + blockIdx.x] = acc[k];
+    for (int i = 0; i < NKY; ++i) {
+      const int ky = g + i * GROUPS;
+      if (ky < KH) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          const int o = ((ky * KW + kx) * 16 + n) * CIN + c;
+          scratch[(long)o * gridDim.x + blockIdx.x] = acc[i][kx];
+        }
+      }
+    }
   }
 }
 
-// one wave per output: sum its WG_BLOCKS partials, add into dW (OIHW)
+// one wave per output: sum its partials, add into dW (OIHW)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ scratch, int nblk, int Cin, int KH,
                                                                 int KW, float* __restrict__ dW) {
   const int total = KH * KW * 16 * Cin;
@@ -388,64 +448,74 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   }
 }
 
-void launch_conv_wgrad(const float* x, int Cpix, int Cin, int nimg, int H, int W, const float* dz, int Ho, int Wo, int KH,
-                       int KW, int stride, int pad, float* scratch, float* dW, hipStream_t st) {
-  const int total = KH * KW * 16 * Cin;
-  ATDN_CHECK(total <= 256 * WG_MAXO, "conv_wgrad: too many weights per output channel block");
-  const int PH = (WG_R - 1) * stride + KH;
-  int WG_TW = 32;
-  size_t lds = 0;
-  for (;; WG_TW /= 2) {
-    const int PWp = (WG_TW - 1) * stride + KW;
-    lds = (size_t)(PH * PWp * Cpix + WG_R * WG_TW * 16) * sizeof(float);
-    if (lds <= 48 * 1024 || WG_TW == 4) break;
-  }
-  ATDN_CHECK(lds <= 64 * 1024, "conv_wgrad: staging tile exceeds the LDS budget");
-  const long items = (long)nimg * cdiv(Ho, WG_R) * cdiv(Wo, WG_TW);
+template <int S, int KH, int KW, int CIN, int R>
+static void wgrad_launch(const float* x, int Cpix, int nimg, int H, int W, const float* dz, int Ho, int Wo, int pad,
+                         float* scratch, float* dW, hipStream_t st) {
+  const long items = (long)nimg * cdiv(Ho, R) * cdiv(Wo, WG_TW);
   const int nblk = (int)std::min<long>(items, WG_BLOCKS);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nblk), dim3(256), lds, st, x, Cpix, Cin, nimg, H, W, dz, Ho, Wo, KH, KW, stride,
-                     pad, WG_TW, scratch);
+  hipLaunchKernelGGL((conv_wgrad_kernel<S, KH, KW, CIN, R>), dim3(nblk), dim3(256), 0, st, x, Cpix, nimg, H, W, dz, Ho, Wo, pad,
+                     scratch);
   ATDN_HIP(hipGetLastError());
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(total, 4)), dim3(256), 0, st, scratch, nblk, Cin, KH, KW, dW);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(KH * KW * 16 * CIN, 4)), dim3(256), 0, st, scratch, nblk, CIN, KH, KW, dW);
   ATDN_HIP(hipGetLastError());
 }
 
-// depthwise 1x1 gradients: 4 sums (dw0, dw1, db0, db1)
-__global__ __launch_bounds__(256) void dw_grad_kernel(const float* __restrict__ flow, const float4* __restrict__ dx0, int nimg,
-                                                      long HW, float sx, float sy, float* __restrict__ scratch) {
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  const long total = (long)nimg * HW;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long img = i / HW, p = i - img * HW;
-    const float4 d = dx0[i];
-    const float* f = flow + img * 2 * HW + p;
-    s[0] += d.x * (f[0] / sx);
-    s[1] += d.y * (f[HW] / sy);
-    s[2] += d.x;
-    s[3] += d.y;
-  }
+void launch_conv_wgrad(const float* x, int Cpix, int Cin, int nimg, int H, int W, const float* dz, int Ho, int Wo, int KH,
+                       int KW, int stride, int pad, float* scratch, float* dW, hipStream_t st) {
+  ATDN_CHECK(Cpix >= Cin && Cpix % 4 == 0, "conv_wgrad: channel layout");
+  if (Cin == 16 && KH == 3 && KW == 3 && stride == 1) wgrad_launch<1, 3, 3, 16, 4>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+  else if (Cin == 16 && KH == 3 && KW == 3 && stride == 2) wgrad_launch<2, 3, 3, 16, 4>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+  else if (Cin == 16 && KH == 3 && KW == 3 && stride == 3) wgrad_launch<3, 3, 3, 16, 2>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+  else if (Cin == 16 && KH == 1 && KW == 1 && stride == 2) wgrad_launch<2, 1, 1, 16, 4>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+  else if (Cin == 3 && KH == 7 && KW == 7 && stride == 2) wgrad_launch<2, 7, 7, 3, 4>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+  else throw Error("conv_wgrad: no kernel for this convolution shape");
+}
+
+// The stem sees x0[c] = xn[c]*w[c] + b[c] (depthwise 1x1 on the normalised flow, zero padding applied AFTER it).
+// With A = weight gradient of the stem conv taken on the auxiliary input (xn0, xn1, 1): A[n][c][tap], c = 0..2,
+//   dW1[n][c][tap] += w[c]*A[n][c][tap] + b[c]*A[n][2][tap]
+//   dw[c] += sum_{n,tap} W1[n][c][tap]*A[n][c][tap],   db[c] += sum_{n,tap} W1[n][c][tap]*A[n][2][tap]
+// which is what back-propagating through the transposed stem convolution would give, without computing dx0.
+__global__ __launch_bounds__(256) void stem_combine_kernel(const float* __restrict__ A, const float* __restrict__ W1,
+                                                           const float* __restrict__ w, const float* __restrict__ b, int taps,
+                                                           float* __restrict__ dW1, float* __restrict__ dw, float* __restrict__ db) {
   __shared__ float red[256][4];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < 16 * 2 * taps; i += 256) {
+    const int tap = i % taps, c = (i / taps) & 1, n = i / (2 * taps);
+    const float a = A[((long)n * 3 + c) * taps + tap], ones = A[((long)n * 3 + 2) * taps + tap];
+    const float wv = W1[i];
+    dW1[i] += w[c] * a + b[c] * ones;
+    s[c] += wv * a;
+    s[2 + c] += wv * ones;
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[threadIdx.x][e] = s[e];
   __syncthreads();
   if (threadIdx.x < 4) {
-    float a = 0.f;
-    for (int t = 0; t < 256; ++t) a += red[t][threadIdx.x];
-    scratch[blockIdx.x * 4 + threadIdx.x] = a;
+    float acc = 0.f;
+    for (int t = 0; t < 256; ++t) acc += red[t][threadIdx.x];
+    if (threadIdx.x < 2) dw[threadIdx.x] += acc; else db[threadIdx.x - 2] += acc;
   }
 }
-__global__ void dw_grad_reduce_kernel(const float* __restrict__ scratch, int nblk, float* __restrict__ dw, float* __restrict__ db) {
-  if (threadIdx.x >= 4) return;
-  double a = 0.0;
-  for (int b = 0; b < nblk; ++b) a += (double)scratch[b * 4 + threadIdx.x];
-  if (threadIdx.x < 2) dw[threadIdx.x] += (float)a; else db[threadIdx.x - 2] += (float)a;
-}
-void launch_dw_grad(const float* flow, const float* dx0, int nimg, long HW, float* scratch, float* dw, float* db, hipStream_t st) {
-  const int nblk = 512;
-  hipLaunchKernelGGL(dw_grad_kernel, dim3(nblk), dim3(256), 0, st, flow, reinterpret_cast<const float4*>(dx0), nimg, HW,
-                     58.1837f, 17.7647f, scratch);
+void launch_stem_combine(const float* A, const float* W1, const float* w, const float* b, int taps, float* dW1, float* dw,
+                         float* db, hipStream_t st) {
+  hipLaunchKernelGGL(stem_combine_kernel, dim3(1), dim3(256), 0, st, A, W1, w, b, taps, dW1, dw, db);
   ATDN_HIP(hipGetLastError());
-  hipLaunchKernelGGL(dw_grad_reduce_kernel, dim3(1), dim3(64), 0, st, scratch, nblk, dw, db);
+}
+
+// (xn0, xn1, 1, 0) per pixel: the auxiliary stem input for the weight gradients
+__global__ void prep_flow_aux_kernel(const float* __restrict__ flow, int B, long HW, float sx, float sy, float4* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  const long img = i / HW, p = i - img * HW;
+  const float* s = flow + img * 2 * HW + p;
+  out[i] = make_float4(s[0] / sx, s[HW] / sy, 1.f, 0.f);
+}
+void launch_prep_flow_aux(const float* flow, int nimg, int H, int W, float* out4, hipStream_t st) {
+  const long n = (long)nimg * H * W;
+  hipLaunchKernelGGL(prep_flow_aux_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, flow, nimg, (long)H * W, 58.1837f,
+                     17.7647f, reinterpret_cast<float4*>(out4));
   ATDN_HIP(hipGetLastError());
 }
 
@@ -519,7 +589,7 @@ void launch_colsum(const float* X, int rows, int cols, int ld, float* out, hipSt
 
 __global__ void mish_fwd_kernel(const float* __restrict__ z, float* __restrict__ a, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] = mishf_(z[i]);
+  if (i < n) a[i] = mish_fast(z[i]);
 }
 void launch_mish_fwd(const float* z, float* a, long n, hipStream_t st) {
   hipLaunchKernelGGL(mish_fwd_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, z, a, n);

@@ -1,0 +1,62 @@
+"""Throughput of the CLVO training iteration (BASELINE config 4 shape: batch 24, sequence length 6, 376x1232 flows)
+on one GPU, or data-parallel under torch.distributed.run (one process per GPU, RCCL all-reduce of the flat gradient).
+
+    python tools/bench_train.py [--batch 24] [--seq 6] [--steps 10] [--warmup 2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from atdn_vslam_amd import synthetic as syn
+from atdn_vslam_amd.training import CLVOTrainer
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=24)
+    ap.add_argument("--seq", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    tr = CLVOTrainer(syn.to_torch(syn.make_clvo_state(seed=1)), a.batch, a.seq, device=dev, total_steps=a.steps + a.warmup)
+    r = np.random.RandomState(7 + rank)
+    flows = torch.from_numpy(syn.make_flow(a.batch * a.seq, 376, 1232, seed=50 + rank)).view(a.batch, a.seq, 2, 376, 1232).to(dev)
+    rot = torch.from_numpy(r.uniform(-0.02, 0.02, (a.batch, a.seq, 3)).astype(np.float32)).to(dev)
+    trn = torch.from_numpy(r.uniform(-0.5, 1.5, (a.batch, a.seq, 3)).astype(np.float32)).to(dev)
+    losses = []
+    for _ in range(a.warmup):
+        tr.step(flows, rot, trn)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses.append(tr.step(flows, rot, trn))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "CLVO training flow-frames/s (forward + backward + AdamW)", "value": world * a.batch * a.seq * a.steps / dt,
+                          "unit": "flow frames/s", "n_gpus": world, "ms_per_iteration": dt * 1e3 / a.steps, "batch_per_gpu": a.batch,
+                          "sequence_length": a.seq, "loss_first": losses[0], "loss_last": losses[-1]}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
