@@ -345,7 +345,8 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   // channels); N = 96 has its own 2x3-wave block. Measured (tools/microbench_conv.py, B = 8): N = 256 -> 256-wide
   // 163 us vs 64-wide 174 us; N = 192 -> 64-wide 154 us vs 128- or 256-wide 186 us.
   int bn = 64;
-  if (s.N == 96 && KH == 3) bn = 96;
+  if (s.N <= 32 && KH == 3) bn = 32;       // flow head (N = 2): 4 waves of 32 px x 32 ch, half the padding of a 64-wide block
+  else if (s.N == 96 && KH == 3) bn = 96;
   else {
     int best = cdiv(s.N, 64) * 64;
     for (int c : {128, 256})
@@ -353,6 +354,9 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   }
   // small grids: narrower blocks (more of them) until the chip is covered
   while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
+  if constexpr (KH == 3) {
+    if (bn == 32) { *bn_out = 32; launch_conv_sf6<8, 32, 4, 1, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true; }
+  }
   *bn_out = bn;
   switch (bn) {
     case 64:  launch_conv_sf6<8, 64, 2, 2, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true;  // 4 waves of 64 px x 32 ch
@@ -371,7 +375,7 @@ inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStr
   constexpr int kinds = epi_gen6<Epi>::value;
   if (kinds == 0 || !s.wfrag || s.stride != 1) return false;
   if (epi_vec4<Epi>::value && Epi::kPrefetch && (s.N % 4) != 0) return false;
-  if (s.N < 4) return false;
+  if (epi_vec4<Epi>::value && s.N < 4) return false;
   if (s.C0 % 32 != 0 || s.C1 % 32 != 0 || s.C0 <= 0 || s.ld0 % 4 != 0) return false;
   if constexpr ((kinds & 1) != 0) {
     if (s.KH == 3 && s.KW == 3) return conv_sf6_try_shape<3, 3>(s, wscale, ep, st, bn_out);

@@ -181,6 +181,7 @@ struct SfGruQ {
 struct SfFlowDelta {
   static constexpr bool kStats = false;
   static constexpr bool kPrefetch = true;
+  static constexpr int kGen6 = 1;  // conv_sf6.h (3x3), classic orientation: N = 2
   const float* bias;
   float* coords1;   // fp32 [img][pix][2]
   float* flow4;     // fp32 [img][pix][4]
