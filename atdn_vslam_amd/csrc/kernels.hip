@@ -833,7 +833,31 @@ __global__ __launch_bounds__(256) void softmax_rows_sf_kernel(const float* __res
     for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, row[i]);
   }
   mx = block_reduce<true>(mx, sm);  // (contains the barrier that publishes rowbuf)
-  const float* src = staged ? rowbuf : row;
+  if (staged) {
+    // e = exp(v - max) is computed once, kept in LDS, and every pass walks the row in float4 (conflict-free b128
+    // LDS accesses; the 2-float stride of the old normalise loop was a 2-way bank conflict on half of all LDS cycles)
+    float s = 0.f;
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      float4 v = *reinterpret_cast<const float4*>(rowbuf + i);
+      v.x = expf(v.x - mx);
+      v.y = (i + 1 < n) ? expf(v.y - mx) : 0.f;
+      v.z = (i + 2 < n) ? expf(v.z - mx) : 0.f;
+      v.w = (i + 3 < n) ? expf(v.w - mx) : 0.f;
+      *reinterpret_cast<float4*>(rowbuf + i) = v;
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    s = block_reduce<false>(s, sm);
+    for (int i = threadIdx.x * 4; i < ld; i += 1024) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n) {
+        const float4 e = *reinterpret_cast<const float4*>(rowbuf + i);   // entries >= n were written as 0 above
+        a = make_float4(e.x / s, e.y / s, e.z / s, e.w / s);
+      }
+      sf_store4(orow, 0, i, a);
+    }
+    return;
+  }
+  const float* src = row;
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) s += expf(src[i] - mx);
   s = block_reduce<false>(s, sm);
