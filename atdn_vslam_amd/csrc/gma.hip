@@ -239,7 +239,8 @@ void GmaNet::run_encoder(const EncoderWeights& E, bool instance, int nimg, hipSt
     TileChoice t = conv_dispatch<MODE>(s, ep, st);
     const int groups = cdiv(oh * ow, t.BM) * (t.BM / 32);
     ATDN_CHECK((long)nimg * groups * L.N <= psum_.n, "statistics scratch too small");
-    launch_in_finalize(psum_.p, pm2_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p, st);
+    launch_in_finalize_cnt(psum_.p, pm2_.p, nullptr, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p,
+                           reinterpret_cast<double*>(fin_.p), st);
   };
   using TapT = std::integral_constant<int, MODE_TAP>;
   using RowT = std::integral_constant<int, MODE_ROW>;
@@ -404,15 +405,17 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
     if (t.counted)
       launch_in_finalize_cnt(psum_.p, pm2_.p, pcnt_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p,
                              rstd_[slot].p, reinterpret_cast<double*>(fin_.p), st);
-    else
-      launch_in_finalize(psum_.p, pm2_.p, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p, st);
+    else  // 1-D M tiling: the valid rows of a group follow from its index (part_cnt = nullptr)
+      launch_in_finalize_cnt(psum_.p, pm2_.p, nullptr, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p,
+                             reinterpret_cast<double*>(fin_.p), st);
   };
   if (instance) {
     ConvShape s = conv_shape(E.stem, img4_.p, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
     EpiBiasStats ep{E.stem.b, R, (long)h * w * 64, 64, psum_.p, pm2_.p, 0};
     TileChoice t = conv_dispatch<MODE_ROW>(s, ep, st);
     const int groups = cdiv(h * w, t.BM) * (t.BM / 32);
-    launch_in_finalize(psum_.p, pm2_.p, nimg, groups, h * w, 64, 1e-5f, mean_[0].p, rstd_[0].p, st);
+    launch_in_finalize_cnt(psum_.p, pm2_.p, nullptr, nimg, groups, h * w, 64, 1e-5f, mean_[0].p, rstd_[0].p,
+                           reinterpret_cast<double*>(fin_.p), st);
     launch_in_apply_sf(R, X, mean_[0].p, rstd_[0].p, nullptr, nullptr, nullptr, nullptr, nimg, (long)h * w, 64, st);
   } else {
     ConvShape s = conv_shape(E.stem, img4_.p, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);

@@ -13,10 +13,10 @@ struct PyramidLevels {  // correlation pyramid of ONE batch: level l is [B*N][H_
 // n2 = number of images taken from im2 (B for pair mode; 1 in sequence mode: only the clip's last frame)
 void launch_prep_images(const float* im1, const float* im2, int B, int H, int W, float* img4, hipStream_t st, int n2);
 
-// InstanceNorm statistics from the conv epilogue's per-group partials -> mean, rstd  [nimg][C]
-void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, int groups_per_img, int HW, int C,
-                        float eps, float* mean, float* rstd, hipStream_t st);
-// same, group sizes given explicitly (part_cnt [nimg][groups]) — partials of the 2-D tiled conv kernel
+// InstanceNorm statistics from the conv epilogue's per-(32-row group) partials -> mean, rstd [nimg][C], merged with
+// Chan's formula in fp64 in two levels (8 slabs of groups per image, then one merge). part_cnt [nimg][groups] = valid
+// rows per group as the 2-D tiled conv kernels report them; nullptr for the 1-D tiled kernels (rows follow from the
+// group index).
 void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const float* part_cnt, int nimg,
                             int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, double* scratch,
                             hipStream_t st);  // scratch: nimg * 8 * C * 3 doubles

@@ -49,52 +49,6 @@ void launch_prep_images(const float* im1, const float* im2, int B, int H, int W,
 // One block per (image, 64-channel slab): lane = channel (coalesced partial reads), 16 waves stride over the
 // 32-row groups; every thread folds its groups with Chan's (count, mean, M2) merge in fp64, then the 16 partial
 // triples of a channel are merged in a fixed order through LDS (deterministic).
-__global__ __launch_bounds__(1024) void in_finalize_kernel(const float* __restrict__ ps, const float* __restrict__ pm2,
-                                                           int groups, int HW, int C, float eps,
-                                                           float* __restrict__ mean, float* __restrict__ rstd) {
-  __shared__ double s_n[16][64], s_mu[16][64], s_m2[16][64];
-  const int img = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const int ng = (HW + 31) / 32;  // groups that hold at least one valid row
-  double n = 0.0, mu = 0.0, m2 = 0.0;
-  if (c < C) {
-    const float* s = ps + (long)img * groups * C + c;
-    const float* m = pm2 + (long)img * groups * C + c;
-#pragma unroll 4
-    for (int g = wv; g < ng; g += 16) {
-      const double cnt = (double)min(32, HW - g * 32);
-      const double gmu = (double)s[(long)g * C] / cnt;
-      const double gm2 = (double)m[(long)g * C];
-      const double tot = n + cnt, d = gmu - mu;
-      mu += d * (cnt / tot);
-      m2 += gm2 + d * d * (n * cnt / tot);
-      n = tot;
-    }
-  }
-  s_n[wv][lane] = n; s_mu[wv][lane] = mu; s_m2[wv][lane] = m2;
-  __syncthreads();
-  if (wv == 0 && c < C) {
-    n = 0.0; mu = 0.0; m2 = 0.0;
-    for (int k = 0; k < 16; ++k) {
-      const double cnt = s_n[k][lane];
-      if (cnt > 0.0) {
-        const double tot = n + cnt, d = s_mu[k][lane] - mu;
-        mu += d * (cnt / tot);
-        m2 += s_m2[k][lane] + d * d * (n * cnt / tot);
-        n = tot;
-      }
-    }
-    mean[img * C + c] = (float)mu;
-    rstd[img * C + c] = (float)(1.0 / sqrt(m2 / (double)HW + (double)eps));
-  }
-}
-void launch_in_finalize(const float* part_sum, const float* part_m2, int nimg, int groups_per_img, int HW, int C,
-                        float eps, float* mean, float* rstd, hipStream_t st) {
-  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(C, 64), nimg), dim3(1024), 0, st, part_sum, part_m2,
-                     groups_per_img, HW, C, eps, mean, rstd);
-  ATDN_HIP(hipGetLastError());
-}
-
 // Two levels so that the merge of ~3700 (count, mean, M2) triples per channel is spread over the chip:
 // level 1: block (channel slab of 64, image, split z of FIN_SPLIT) folds its share of the groups (16 waves stride
 // over them, fp64 Chan merge) into one triple per channel; level 2: one thread per (image, channel) merges the
@@ -103,7 +57,7 @@ constexpr int FIN_SPLIT = 8;
 __global__ __launch_bounds__(1024) void in_finalize_cnt_kernel(const float* __restrict__ ps,
                                                                const float* __restrict__ pm2,
                                                                const float* __restrict__ pc, int groups, int C,
-                                                               double* __restrict__ part) {
+                                                               int HW, double* __restrict__ part) {
   __shared__ double s_n[16][64], s_mu[16][64], s_m2[16][64];
   const int img = blockIdx.y, z = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -113,10 +67,11 @@ __global__ __launch_bounds__(1024) void in_finalize_cnt_kernel(const float* __re
   if (c < C) {
     const float* s = ps + (long)img * groups * C + c;
     const float* m = pm2 + (long)img * groups * C + c;
-    const float* cn = pc + (long)img * groups;
+    const float* cn = pc ? pc + (long)img * groups : nullptr;
 #pragma unroll 8
     for (int g = g0 + wv; g < g1; g += 16) {
-      const double cnt = (double)cn[g];
+      // valid rows of the group: from the kernel's count, or (1-D M tiling) the rows of the image inside it
+      const double cnt = cn ? (double)cn[g] : (double)max(0, min(32, HW - g * 32));
       if (cnt > 0.0) {
         const double gmu = (double)s[(long)g * C] / cnt;
         const double tot = n + cnt, d = gmu - mu;
@@ -166,7 +121,7 @@ void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const f
                             int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, double* scratch,
                             hipStream_t st) {
   hipLaunchKernelGGL(in_finalize_cnt_kernel, dim3(cdiv(C, 64), nimg, FIN_SPLIT), dim3(1024), 0, st, part_sum, part_m2,
-                     part_cnt, groups_per_img, C, scratch);
+                     part_cnt, groups_per_img, C, HW, scratch);
   ATDN_HIP(hipGetLastError());
   hipLaunchKernelGGL(in_finalize_merge_kernel, dim3(cdiv(nimg * C, 128)), dim3(128), 0, st, scratch, nimg, HW, C, eps,
                      mean, rstd);
