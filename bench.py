@@ -132,20 +132,21 @@ def main():
     raw = torch.from_numpy(syn.make_frames(clip, H_KITTI, W_KITTI, seed=100 + rank)).to(dev)  # 376x1241, resident
     torch.cuda.synchronize()
 
-    def step(i, feats):
+    def step(i, feats, slot=None):
         s = (i * B) % (clip - B)
+        slot = i if slot is None else slot
         with torch.cuda.stream(streams[i % S]):
             frames = resize_frames(raw[s:s + B + 1])     # the reference's per-frame resize to 376x1232, on the GPU
             f, _ = pipes[i % S].features_clip(frames)    # B consecutive pairs of the clip
-            feats[i * B:(i + 1) * B] = f
+            feats[slot * B:(slot + 1) * B] = f
 
     def join():
         for st_ in streams:
             torch.cuda.current_stream().wait_stream(st_)
 
     feats = torch.empty((max(K, Wm) * B, 512), device=dev)
-    for i in range(max(Wm, S)):  # every pipeline captures its graph before timing starts
-        step(i % max(Wm, 1), feats)
+    for i in range(max(Wm, S)):  # W warm-up steps, and at least one on EVERY pipeline (graph capture) before timing
+        step(i, feats, slot=i % max(Wm, 1))
     join()
     if Wm:
         pipe.scan(feats[:B])  # warm the tail kernels too
