@@ -703,21 +703,50 @@ __global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr,
   const float wm1 = (float)(Wl - 1), hm1 = (float)(Hl - 1);
   float* w = win[lvl];
   if (threadIdx.x >= 324 - 256 && threadIdx.x < 352 - 256) vals[256 + threadIdx.x] = 0.f;  // pad channels 324..351
-  for (long p = blockIdx.x; p < npix; p += gridDim.x) {
-    const float xc = coords1[p * 2 + 0] * inv, yc = coords1[p * 2 + 1] * inv;
-    const bool sane = (fabsf(xc) < 1.0e6f) && (fabsf(yc) < 1.0e6f);
-    const int wx0 = sane ? (int)floorf(xc) - 5 : -(1 << 24), wy0 = sane ? (int)floorf(yc) - 5 : -(1 << 24);
+  // Software pipeline over the block's pixels: the window of pixel p + grid is requested (into registers) before
+  // pixel p is processed, and the coordinates of p + 2*grid before that — two dependent HBM round trips per pixel
+  // (coordinates -> window) otherwise sit fully exposed with one pixel in flight per block.
+  const long G = gridDim.x;
+  auto window_origin = [&](float cx, float cy, float& xc, float& yc, bool& sane, int& wx0, int& wy0) {
+    xc = cx * inv; yc = cy * inv;
+    sane = (fabsf(xc) < 1.0e6f) && (fabsf(yc) < 1.0e6f);
+    wx0 = sane ? (int)floorf(xc) - 5 : -(1 << 24);
+    wy0 = sane ? (int)floorf(yc) - 5 : -(1 << 24);
+  };
+  auto fetch_window = [&](long p, int wx0, int wy0, float* v, bool* ok) {
     const float* src = pyr.base[lvl] + p * ((long)Hl * Wl);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int c = lane + 64 * t;
-      if (c < LK_WIN * LK_WIN) {
-        const int wy = c / LK_WIN, wx = c - wy * LK_WIN;
-        const int y = wy0 + wy, x = wx0 + wx;
-        const bool ok = ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
-        const float v = src[ok ? (long)y * Wl + x : 0];
-        w[c] = ok ? v : 0.f;
-      }
+      const int wy = c / LK_WIN, wx = c - wy * LK_WIN;
+      const int y = wy0 + wy, x = wx0 + wx;
+      ok[t] = (c < LK_WIN * LK_WIN) & ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
+      v[t] = src[ok[t] ? (long)y * Wl + x : 0];
+    }
+  };
+  long p = blockIdx.x;
+  float xc = 0.f, yc = 0.f, nxc = 0.f, nyc = 0.f;
+  bool sane = false, nsane = false;
+  int wx0 = 0, wy0 = 0, nwx0 = 0, nwy0 = 0;
+  float cur[3], nxt[3];
+  bool okc[3], okn[3];
+  float2 cnext = make_float2(0.f, 0.f);
+  if (p < npix) {
+    window_origin(coords1[p * 2 + 0], coords1[p * 2 + 1], xc, yc, sane, wx0, wy0);
+    fetch_window(p, wx0, wy0, cur, okc);
+    if (p + G < npix) cnext = *reinterpret_cast<const float2*>(coords1 + (p + G) * 2);
+  }
+  for (; p < npix; p += G) {
+    const float2 cn = cnext;
+    if (p + 2 * G < npix) cnext = *reinterpret_cast<const float2*>(coords1 + (p + 2 * G) * 2);
+    if (p + G < npix) {
+      window_origin(cn.x, cn.y, nxc, nyc, nsane, nwx0, nwy0);
+      fetch_window(p + G, nwx0, nwy0, nxt, okn);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int c = lane + 64 * t;
+      if (c < LK_WIN * LK_WIN) w[c] = okc[t] ? cur[t] : 0.f;
     }
     if (lane < 18) {
       const bool isx = lane < 9;
@@ -730,7 +759,7 @@ __global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr,
       wgt[lvl][lane] = u - fl;
       idx[lvl][lane] = sane ? min(max((int)fl - (isx ? wx0 : wy0), 0), LK_WIN - 2) : 0;
     }
-    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes; the prefetched window stays in flight
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -756,6 +785,9 @@ __global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr,
       orow[d] = *reinterpret_cast<unsigned*>(&o);
     }
     __syncthreads();
+    xc = nxc; yc = nyc; sane = nsane; wx0 = nwx0; wy0 = nwy0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { cur[t] = nxt[t]; okc[t] = okn[t]; }
   }
 }
 void launch_lookup_sf(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
