@@ -69,6 +69,7 @@ class GmaNet {
   bool use_graph_ = true;
   EncoderWeights fnet_, cnet_;
   PackedConv convc1_, convc2_, convf1_, convf2_, convm_, to_v_, to_qk_;
+  long convf1_vw_off_ = -1;  // convf1 weights as [tap*2 + c][128] for small_convs.hip
   PackedConv gru_zr_[2], gru_q_[2], fh1_, fh2_, mask0_, mask2_;
   PackedConv gru_zr_ctx_[2], gru_q_ctx_[2];  // sf mode: context-channel (inp) slices, applied once per pair
   const float* gamma_ = nullptr;

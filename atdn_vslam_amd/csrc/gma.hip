@@ -2,6 +2,7 @@
 // (lookup -> motion encoder -> attention aggregate -> separable ConvGRU -> flow head), mask head and
 // convex upsampling.  Reference: whl:GMA/core/network.py:72-129 and the blocks it calls.
 #include "gma.h"
+#include "small_convs.h"
 #include "conv_sf.h"
 #include "epilogues_sf.h"
 
@@ -155,6 +156,14 @@ void GmaNet::finalize() {
   convc1_ = tap({u + "encoder.convc1"});
   convc2_ = tap({u + "encoder.convc2"});
   convf1_ = pack_conv(arena_, sd_, {u + "encoder.convf1"}, MODE_ROW, 4);
+  {  // the same weights as [(ky*7 + kx)*2 + c][128] for the register-tiled VALU kernel (small_convs.hip)
+    const HostTensor& w = sd_.get(u + "encoder.convf1.weight");
+    ATDN_CHECK(w.shape[0] == 128 && w.shape[1] == 2 && w.shape[2] == 7 && w.shape[3] == 7, "convf1 is 7x7, 2 -> 128");
+    convf1_vw_off_ = arena_.alloc(98 * 128);
+    for (int n = 0; n < 128; ++n)
+      for (int c = 0; c < 2; ++c)
+        for (int t = 0; t < 49; ++t) arena_.at(convf1_vw_off_)[(t * 2 + c) * 128 + n] = w.data[((long)n * 2 + c) * 49 + t];
+  }
   convf2_ = tap({u + "encoder.convf2"});
   convm_ = tap({u + "encoder.conv"});
   to_v_ = tap({u + "aggregator.to_v"}, false);
@@ -468,8 +477,13 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   conv_sf_dispatch(s, convc1_.wscale, SfBias<ACT_RELU>{convc1_.b, cor1_.p, (long)N * 256, 256}, st);
   s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
-  s = conv_shape(convf1_, flow4_.p, 4, (long)N * 4, B, H8, W8, 1, 3, 3);
-  conv_dispatch<MODE_ROW>(s, SfBias<ACT_RELU>{convf1_.b, flo1_.p, (long)N * 128, 128}, st);
+  static const bool small = !(getenv("ATDN_SMALL_CONVS") && getenv("ATDN_SMALL_CONVS")[0] == '0');
+  if (small) {
+    launch_flow_conv7(flow4_.p, B, H8, W8, arena_.dev(convf1_vw_off_), convf1_.b, flo1_.p, st);
+  } else {
+    s = conv_shape(convf1_, flow4_.p, 4, (long)N * 4, B, H8, W8, 1, 3, 3);
+    conv_dispatch<MODE_ROW>(s, SfBias<ACT_RELU>{convf1_.b, flo1_.p, (long)N * 128, 128}, st);
+  }
   s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
   s = conv_shape(convm_, corflo_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
@@ -505,9 +519,13 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
 
   s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, fh1_.wscale, SfBias<ACT_RELU>{fh1_.b, fh_.p, (long)N * 256, 256}, st);
-  s = conv_shape(fh2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
-  conv_sf_dispatch(s, fh2_.wscale,
-                   SfFlowDelta{fh2_.b, coords1_.p, flow4_.p, x_.p, XLD, (long)N * XLD, 254, W8, (long)N}, st);
+  const SfFlowDelta fd{fh2_.b, coords1_.p, flow4_.p, x_.p, XLD, (long)N * XLD, 254, W8, (long)N};
+  if (small) {
+    launch_flow_head2(fh_.p, B, H8, W8, fh2_.w, fh2_.ldw, fh2_.wscale, fd, st);
+  } else {
+    s = conv_shape(fh2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
+    conv_sf_dispatch(s, fh2_.wscale, fd, st);
+  }
   mark(ST_FLOWHEAD, st);
 }
 

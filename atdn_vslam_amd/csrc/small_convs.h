@@ -1,0 +1,17 @@
+// Dedicated kernels for the two convolutions of the GRU iteration with a degenerate GEMM shape (small_convs.hip).
+#pragma once
+#include "common.h"
+#include "epilogues_sf.h"
+
+namespace atdn {
+
+// motion encoder convf1: flow4 NHWC4 [nimg][H][W][4] (channels 0, 1) -> relu(conv7x7 + bias), sf [nimg][H*W][128].
+// wl: weights re-ordered to [(ky*7 + kx)*2 + c][128] fp32.
+void launch_flow_conv7(const float* flow4, int nimg, int H, int W, const float* wl, const float* bias, float* out_sf,
+                       hipStream_t st);
+// flow head conv2: sf [nimg][H*W][256] -> 2 channels through the SfFlowDelta epilogue. wsf: the layer's sf-packed
+// weights ([2][9*256] floats = [n][tap][chunk][32 hi | 32 lo]), wscale its accumulator scale.
+void launch_flow_head2(const float* fh_sf, int nimg, int H, int W, const float* wsf, int ldw, float wscale,
+                       const SfFlowDelta& ep, hipStream_t st);
+
+}  // namespace atdn

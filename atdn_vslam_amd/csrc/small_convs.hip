@@ -1,0 +1,169 @@
+// Two convolutions of the GRU iteration that the MFMA engines serve badly (profiles/r01_v3_kernel_stats_1stream.csv):
+//   * motion encoder convf1 (update.py:88): 7x7, 2 -> 128 channels on the flow field. K = 98: the ROW-mode fp32 MFMA
+//     kernel pads every kernel row to 32 and ran 51 us; a register-tiled fp32 VALU kernel does it in its FMA time.
+//   * flow head conv2 (update.py:12): 3x3, 256 -> 2 channels. N = 2: an MFMA block pads N to 32 (65 us); here one
+//     v_dot2_f32_f16 chain per (pixel, output) on the split-f16 operands (hi*hi + hi*lo + lo*hi, fp32 accumulate).
+#include "small_convs.h"
+#include "sf.h"
+
+namespace atdn {
+
+// ---------------------------------------------------------------------------------------------- 7x7, 2 -> 128
+// block: 8x16 output pixels x 128 channels; thread: 4 pixels (along x) x 8 channels, twice (channels c and 64 + c)
+__global__ __launch_bounds__(256) void flow_conv7_kernel(const float4* __restrict__ flow4, int H, int W,
+                                                         const float* __restrict__ wl /*[98][128]*/,
+                                                         const float* __restrict__ bias, float* __restrict__ out, long ob,
+                                                         int tiles_x, int tiles_img) {
+  __shared__ __attribute__((aligned(16))) float ws[98 * 128];
+  __shared__ float2 ps[14][24];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.x / tiles_img, tloc = blockIdx.x - img * tiles_img;
+  const int ty0 = (tloc / tiles_x) * 8, tx0 = (tloc % tiles_x) * 16;
+  for (int i = tid; i < 98 * 128 / 4; i += 256)
+    reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(wl)[i];
+  for (int i = tid; i < 14 * 22; i += 256) {
+    const int py = i / 22, px = i - py * 22;
+    const int iy = ty0 - 3 + py, ix = tx0 - 3 + px;
+    float2 v = make_float2(0.f, 0.f);
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      const float4 f = flow4[((long)img * H + iy) * W + ix];
+      v = make_float2(f.x, f.y);
+    }
+    ps[py][px] = v;
+  }
+  __syncthreads();
+  const int pg = tid & 31, cg = tid >> 5;
+  const int row = pg >> 2, xg = pg & 3;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    const int ch0 = half * 64 + cg * 8;
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+      float2 in[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) in[i] = ps[row + ky][xg * 4 + i];
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float4* wp = reinterpret_cast<const float4*>(ws + ((ky * 7 + kx) * 2 + c) * 128 + ch0);
+          const float4 w0 = wp[0], w1 = wp[1];
+          const float w8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = c ? in[j + kx].y : in[j + kx].x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] += v * w8[e];
+          }
+        }
+    }
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + ch0), b1 = *reinterpret_cast<const float4*>(bias + ch0 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int oy = ty0 + row, ox = tx0 + xg * 4 + j;
+      if (oy < H && ox < W) {
+        const long off = (long)img * ob + ((long)oy * W + ox) * 128;
+        sf_store4(out, off, ch0, make_float4(fmaxf(acc[j][0] + b0.x, 0.f), fmaxf(acc[j][1] + b0.y, 0.f),
+                                             fmaxf(acc[j][2] + b0.z, 0.f), fmaxf(acc[j][3] + b0.w, 0.f)));
+        sf_store4(out, off, ch0 + 4, make_float4(fmaxf(acc[j][4] + b1.x, 0.f), fmaxf(acc[j][5] + b1.y, 0.f),
+                                                 fmaxf(acc[j][6] + b1.z, 0.f), fmaxf(acc[j][7] + b1.w, 0.f)));
+      }
+    }
+  }
+}
+
+void launch_flow_conv7(const float* flow4, int nimg, int H, int W, const float* wl, const float* bias, float* out_sf,
+                       hipStream_t st) {
+  const int tx = cdiv(W, 16), ty = cdiv(H, 8);
+  hipLaunchKernelGGL(flow_conv7_kernel, dim3(nimg * tx * ty), dim3(256), 0, st, reinterpret_cast<const float4*>(flow4), H, W,
+                     wl, bias, out_sf, (long)H * W * 128, tx, tx * ty);
+  ATDN_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------- 3x3, 256 -> 2
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+namespace {
+constexpr int FH_RS = 2816;   // LDS bytes between patch rows: 18 pixels x 144 B rounded up to a multiple of 256 B
+__device__ __forceinline__ float dot8(const f16x8 a, const f16x8 b, float acc) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_fdot2(h2v{a[2 * k], a[2 * k + 1]}, h2v{b[2 * k], b[2 * k + 1]}, acc, false);
+  return acc;
+}
+}  // namespace
+
+// block: 8x16 pixels; thread (pixel = tid & 127, half = tid >> 7) covers 16 of the 32 channels of every chunk
+__global__ __launch_bounds__(256) void flow_head2_kernel(const float* __restrict__ src, int H, int W,
+                                                         const float* __restrict__ wsf, int ldw, float wscale,
+                                                         const SfFlowDelta ep, int tiles_x, int tiles_img) {
+  __shared__ __attribute__((aligned(256))) char patch[10 * FH_RS];
+  __shared__ __attribute__((aligned(16))) float wl[2 * 72 * 32];
+  __shared__ float red[128][2];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.x / tiles_img, tloc = blockIdx.x - img * tiles_img;
+  const int ty0 = (tloc / tiles_x) * 8, tx0 = (tloc % tiles_x) * 16;
+  for (int i = tid; i < 2 * 72 * 8; i += 256) {   // float4 index: [n][q][8 slots]
+    const int n = i / (72 * 8), rem = i - n * 72 * 8;
+    reinterpret_cast<float4*>(wl)[i] = *reinterpret_cast<const float4*>(wsf + (long)n * ldw + rem * 4);
+  }
+  const int pix = tid & 127, half = tid >> 7;
+  const int py = pix >> 4, px = pix & 15;
+  const float* simg = src + (long)img * H * W * 256;
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int chunk = 0; chunk < 8; ++chunk) {
+    __syncthreads();
+    for (int i = tid; i < 180 * 8; i += 256) {
+      const int slot = i & 7, prow = i >> 3;
+      const int ry = prow / 18, rx = prow - ry * 18;
+      const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        v = *reinterpret_cast<const float4*>(simg + ((long)iy * W + ix) * 256 + chunk * 32 + slot * 4);
+      *reinterpret_cast<float4*>(patch + ry * FH_RS + rx * 144 + slot * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const char* p = patch + (py + tap / 3) * FH_RS + (px + tap % 3) * 144 + half * 32;
+      const f16x8 h0 = *reinterpret_cast<const f16x8*>(p), h1 = *reinterpret_cast<const f16x8*>(p + 16);
+      const f16x8 l0 = *reinterpret_cast<const f16x8*>(p + 64), l1 = *reinterpret_cast<const f16x8*>(p + 80);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const char* w = reinterpret_cast<const char*>(wl) + ((n * 72 + tap * 8 + chunk) * 128) + half * 32;
+        const f16x8 wh0 = *reinterpret_cast<const f16x8*>(w), wh1 = *reinterpret_cast<const f16x8*>(w + 16);
+        const f16x8 wo0 = *reinterpret_cast<const f16x8*>(w + 64), wo1 = *reinterpret_cast<const f16x8*>(w + 80);
+        float a = n ? acc1 : acc0;
+        a = dot8(l0, wh0, a); a = dot8(l1, wh1, a);     // lo x hi
+        a = dot8(h0, wo0, a); a = dot8(h1, wo1, a);     // hi x lo
+        a = dot8(h0, wh0, a); a = dot8(h1, wh1, a);     // hi x hi
+        if (n) acc1 = a; else acc0 = a;
+      }
+    }
+  }
+  if (half == 1) { red[pix][0] = acc0; red[pix][1] = acc1; }
+  __syncthreads();
+  if (half == 0) {
+    const int oy = ty0 + py, ox = tx0 + px;
+    if (oy < H && ox < W) {
+      const int m = oy * W + ox;
+      const float v0 = (acc0 + red[pix][0]) * wscale, v1 = (acc1 + red[pix][1]) * wscale;
+      const SfFlowDelta::Aux a0 = ep.load(img, m, 0), a1 = ep.load(img, m, 1);
+      ep.apply(img, m, 0, v0, a0);
+      ep.apply(img, m, 1, v1, a1);
+    }
+  }
+}
+
+void launch_flow_head2(const float* fh_sf, int nimg, int H, int W, const float* wsf, int ldw, float wscale,
+                       const SfFlowDelta& ep, hipStream_t st) {
+  ATDN_CHECK(ldw == 9 * 256, "flow head conv2 expects 3x3 x 256 packed weights");
+  const int tx = cdiv(W, 16), ty = cdiv(H, 8);
+  hipLaunchKernelGGL(flow_head2_kernel, dim3(nimg * tx * ty), dim3(256), 0, st, fh_sf, H, W, wsf, ldw, wscale, ep, tx, tx * ty);
+  ATDN_HIP(hipGetLastError());
+}
+
+}  // namespace atdn
