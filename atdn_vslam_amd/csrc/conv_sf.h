@@ -15,7 +15,7 @@
 
 namespace atdn {
 
-template <int TM, int TN, int WGM, int WGN, class Epi>
+template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false>
 __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const float wscale, const Epi ep) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -130,8 +130,10 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (!FAST) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -195,14 +197,18 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
   }
 }
 
-template <int TM, int TN, int WGM, int WGN, class Epi>
+template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false>
 inline void launch_conv_sf(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   ConvGeom g = make_geom<MODE_TAP>(s, BM, BN);
   const int nblk = g.nimg * g.tiles_per_img * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
+  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
   ATDN_HIP(hipGetLastError());
 }
+
+// Plain-f16 arithmetic (precision mode 2) for the calling thread's sf convolutions: conv_sf_dispatch issues only the
+// hi x hi MFMA of every product while this is set (GmaNet sets it around its forward).
+bool& sf_fast_mode();
 
 // Definitions are explicitly instantiated in conv_sf_inst_*.hip
 template <class Epi>

@@ -30,7 +30,8 @@ template <class E, class = void> struct epi_vec4 : std::false_type {};
 template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bool_constant<E::kVec4> {};
 
 // ABL (diagnostic builds only, wrong results): bit0 no weight loads in the loop, bit1 no patch refresh, bit2 no LDS reads in the loop
-template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false>
+// FAST: plain-f16 arithmetic (precision mode 2): only the hi x hi MFMA of every product is issued
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = TH * TW / 32 / WM, TN = BN / 32 / WN;
@@ -164,12 +165,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (SWAP) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.hi[t][j], al[t][i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.lo[t][j], ah[t][i], acc[i][j], 0, 0, 0);
+          if constexpr (!FAST) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.hi[t][j], al[t][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.lo[t][j], ah[t][i], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.hi[t][j], ah[t][i], acc[i][j], 0, 0, 0);
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t][i], w0.hi[t][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], w0.lo[t][j], acc[i][j], 0, 0, 0);
+          if constexpr (!FAST) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t][i], w0.hi[t][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], w0.lo[t][j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], w0.hi[t][j], acc[i][j], 0, 0, 0);
         }
       }
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
   }
 }
 
-template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false>
+template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false>
 inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
   constexpr int TW = 16;
   ATDN_CHECK(s.KH == KH && s.KW == KW && s.stride == 1, "kernel shape does not match the instantiation");
@@ -330,14 +335,14 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
   ATDN_CHECK(g.w != nullptr, "missing weight copy for this kernel");
   set_groups(ep, g.tiles_x * g.tiles_y * (TH * TW / 32));
   const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
+  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW, FAST>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
   ATDN_HIP(hipGetLastError());
 }
 
 
 // Picks the block width for N output channels and launches the 8x16-pixel, fragment-major-weight kernel.
 // Returns false when this path does not serve the shape (the caller falls back to generation 4).
-template <int KH, int KW, class Epi>
+template <int KH, int KW, class Epi, bool FAST>
 inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out) {
   const int Ho = conv_out(s.H, s.KH, 1, s.padH), Wo = conv_out(s.W, s.KW, 1, s.padW);
   const long tiles = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
@@ -355,34 +360,40 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   // small grids: narrower blocks (more of them) until the chip is covered
   while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
   if constexpr (KH == 3) {
-    if (bn == 32) { *bn_out = 32; launch_conv_sf6<8, 32, 4, 1, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true; }
+    if (bn == 32) { *bn_out = 32; launch_conv_sf6<8, 32, 4, 1, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true; }
   }
   *bn_out = bn;
   switch (bn) {
-    case 64:  launch_conv_sf6<8, 64, 2, 2, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true;  // 4 waves of 64 px x 32 ch
-    case 128: launch_conv_sf6<8, 128, 1, 4, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true;
-    case 256: launch_conv_sf6<8, 256, 1, 8, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true;
+    case 64:  launch_conv_sf6<8, 64, 2, 2, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true;  // 4 waves of 64 px x 32 ch
+    case 128: launch_conv_sf6<8, 128, 1, 4, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true;
+    case 256: launch_conv_sf6<8, 256, 1, 8, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true;
     default: break;
   }
   if constexpr (KH == 3) {
-    if (bn == 96) { launch_conv_sf6<8, 96, 2, 3, KH, KW, Epi, 0, true>(s, wscale, ep, st); return true; }
+    if (bn == 96) { launch_conv_sf6<8, 96, 2, 3, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true; }
   }
   return false;
 }
 
 template <class Epi>
-inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out) {
+inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out, bool fast) {
   constexpr int kinds = epi_gen6<Epi>::value;
   if (kinds == 0 || !s.wfrag || s.stride != 1) return false;
   if (epi_vec4<Epi>::value && Epi::kPrefetch && (s.N % 4) != 0) return false;
   if (epi_vec4<Epi>::value && s.N < 4) return false;
   if (s.C0 % 32 != 0 || s.C1 % 32 != 0 || s.C0 <= 0 || s.ld0 % 4 != 0) return false;
   if constexpr ((kinds & 1) != 0) {
-    if (s.KH == 3 && s.KW == 3) return conv_sf6_try_shape<3, 3>(s, wscale, ep, st, bn_out);
+    if (s.KH == 3 && s.KW == 3)
+      return fast ? conv_sf6_try_shape<3, 3, Epi, true>(s, wscale, ep, st, bn_out)
+                  : conv_sf6_try_shape<3, 3, Epi, false>(s, wscale, ep, st, bn_out);
   }
   if constexpr ((kinds & 2) != 0) {
-    if (s.KH == 1 && s.KW == 5) return conv_sf6_try_shape<1, 5>(s, wscale, ep, st, bn_out);
-    if (s.KH == 5 && s.KW == 1) return conv_sf6_try_shape<5, 1>(s, wscale, ep, st, bn_out);
+    if (s.KH == 1 && s.KW == 5)
+      return fast ? conv_sf6_try_shape<1, 5, Epi, true>(s, wscale, ep, st, bn_out)
+                  : conv_sf6_try_shape<1, 5, Epi, false>(s, wscale, ep, st, bn_out);
+    if (s.KH == 5 && s.KW == 1)
+      return fast ? conv_sf6_try_shape<5, 1, Epi, true>(s, wscale, ep, st, bn_out)
+                  : conv_sf6_try_shape<5, 1, Epi, false>(s, wscale, ep, st, bn_out);
   }
   return false;
 }

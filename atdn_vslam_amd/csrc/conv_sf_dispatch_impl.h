@@ -25,7 +25,7 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
     static const int gen = getenv("ATDN_CONV_GEN") ? atoi(getenv("ATDN_CONV_GEN")) : 6;
     if (gen >= 6) {
       int bn = 0;
-      if (conv_sf6_try(s, wscale, ep, st, &bn)) return TileChoice{128, bn, cdiv(Wo, 16) * cdiv(Ho, 8) * 4, true};
+      if (conv_sf6_try(s, wscale, ep, st, &bn, sf_fast_mode())) return TileChoice{128, bn, cdiv(Wo, 16) * cdiv(Ho, 8) * 4, true};
     }
     static const int big_min = getenv("ATDN_BIG_TILE_MIN") ? atoi(getenv("ATDN_BIG_TILE_MIN")) : 224;
     const int tiles16 = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 16);
@@ -56,6 +56,14 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
     else if (t.BM == 128 && t.BN == 96) launch_conv_sfd<1, 3, 4, 1>(s, wscale, ep, st);
     else if (t.BM == 128 && t.BN == 32) launch_conv_sfd<1, 1, 4, 1>(s, wscale, ep, st);
     else launch_conv_sfd<1, 1, 2, 2>(s, wscale, ep, st);
+    return t;
+  }
+  if (sf_fast_mode()) {
+    if (t.BM == 128 && t.BN == 128) launch_conv_sf<2, 2, 2, 2, Epi, true>(s, wscale, ep, st);
+    else if (t.BM == 128 && t.BN == 64) launch_conv_sf<2, 1, 2, 2, Epi, true>(s, wscale, ep, st);
+    else if (t.BM == 128 && t.BN == 96) launch_conv_sf<1, 3, 4, 1, Epi, true>(s, wscale, ep, st);
+    else if (t.BM == 128 && t.BN == 32) launch_conv_sf<1, 1, 4, 1, Epi, true>(s, wscale, ep, st);
+    else launch_conv_sf<1, 1, 2, 2, Epi, true>(s, wscale, ep, st);
     return t;
   }
   if (t.BM == 128 && t.BN == 128) launch_conv_sf<2, 2, 2, 2>(s, wscale, ep, st);

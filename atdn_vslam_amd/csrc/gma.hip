@@ -34,6 +34,13 @@ ATDN_EXTERN_SF(SfAggregate) ATDN_EXTERN_SF(SfGruZR) ATDN_EXTERN_SF(SfGruQ) ATDN_
 
 namespace {
 
+// precision mode 2: the sf convolutions of this thread issue only the hi x hi MFMA while the guard lives (conv_sf.h)
+struct FastGuard {
+  bool prev;
+  explicit FastGuard(bool on) : prev(sf_fast_mode()) { sf_fast_mode() = on; }
+  ~FastGuard() { sf_fast_mode() = prev; }
+};
+
 constexpr int XLD = 384;       // GRU input x = [inp | motion(126) flow(2) | motion_global]  (update.py:130)
 constexpr int CORR_LD = 352;   // 4*81 lookup channels padded to a multiple of 32
 
@@ -104,11 +111,11 @@ void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
   for (int r = 0; r < reps; ++r) {
     Timer t;
     timer_ = &t;
-    if (precision == 1) launch_init_coords_sf(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
+    if (precision >= 1) launch_init_coords_sf(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
     else launch_init_coords(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
     ATDN_HIP(hipEventCreate(&t.start));
     ATDN_HIP(hipEventRecord(t.start, st));
-    try { if (precision == 1) run_body_sf(B, iters, st); else run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
+    try { if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, st); } else run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
     timer_ = nullptr;
     ATDN_HIP(hipStreamSynchronize(st));
     hipEvent_t prev = t.start;
@@ -124,7 +131,7 @@ void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
 }
 
 GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), maxB(max_batch), precision(precision_) {
-  ATDN_CHECK(precision == 0 || precision == 1, "precision must be 0 (fp32 MFMA) or 1 (split-f16 MFMA)");
+  ATDN_CHECK(precision >= 0 && precision <= 2, "precision must be 0 (fp32 MFMA), 1 (split-f16 MFMA) or 2 (plain f16 MFMA)");
   ATDN_CHECK(H % 8 == 0 && W % 8 == 0 && H >= 64 && W >= 64, "frame size must be a multiple of 8 (use the padder)");
   ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
@@ -146,7 +153,7 @@ GmaNet::~GmaNet() {
 void GmaNet::finalize() {
   ATDN_CHECK(!ready_, "finalize called twice");
   const std::string u = "update_block.";
-  const bool sf = precision == 1;
+  const bool sf = precision >= 1;
   auto tap = [&](const std::vector<std::string>& names, bool has_bias = true) {
     return sf ? pack_conv_sf(arena_, sd_, names, nullptr, has_bias)
               : pack_conv(arena_, sd_, names, MODE_TAP, 0, nullptr, has_bias);
@@ -583,7 +590,7 @@ void GmaNet::capture(int B, int iters) {
   hipGraph_t graph = nullptr;
   ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
   try {
-    if (precision == 1) run_body_sf(B, iters, cap_stream_); else run_body(B, iters, cap_stream_);
+    if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, cap_stream_); } else run_body(B, iters, cap_stream_);
   } catch (...) {
     (void)hipStreamEndCapture(cap_stream_, &graph);
     if (graph) (void)hipGraphDestroy(graph);
@@ -599,7 +606,7 @@ void GmaNet::capture(int B, int iters) {
 void GmaNet::forward_sequence(const float* frames, int B, int iters, const float* flow_init, float* flow_low,
                                float* flow_up, hipStream_t st) {
   ATDN_CHECK(ready_, "weights not finalized");
-  ATDN_CHECK(precision == 1, "sequence mode is built for the split-f16 pipeline");
+  ATDN_CHECK(precision >= 1, "sequence mode is built for the split-f16 pipeline");
   ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
   ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
   ATDN_CHECK(frames && flow_low && flow_up, "null tensor");
@@ -617,7 +624,7 @@ void GmaNet::launch_body(int B, int iters, hipStream_t st) {
     if (!graphs_.count(key)) capture(B, iters);
     ATDN_HIP(hipGraphLaunch(graphs_[key], st));
   } else {
-    if (precision == 1) run_body_sf(B, iters, st); else run_body(B, iters, st);
+    if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, st); } else run_body(B, iters, st);
   }
 }
 
@@ -629,7 +636,7 @@ void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const
   ATDN_CHECK(im1 && im2 && flow_low && flow_up, "null tensor");
   seq_ = false;
   launch_prep_images(im1, im2, B, H, W, img4_.p, st, B);
-  if (precision == 1) launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
+  if (precision >= 1) launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
   else launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
   launch_body(B, iters, st);
   launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
@@ -645,7 +652,7 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
   else if (k == "qk") b = &qk_; else if (k == "img4") b = &img4_;
   if (!b) return -1;
   const long n = std::min(capacity, b->n);
-  const bool is_sf = precision == 1 && (k == "fmap" || k == "net" || k == "x" || k == "attn" || k == "corrfeat" || k == "qk");
+  const bool is_sf = precision >= 1 && (k == "fmap" || k == "net" || k == "x" || k == "attn" || k == "corrfeat" || k == "qk");
   const float* src = b->p;
   if (is_sf) {  // decode the split-f16 tensor into a scratch fp32 copy first
     if (scratch_.n < b->n) { scratch_.release(); scratch_.alloc(b->n); }

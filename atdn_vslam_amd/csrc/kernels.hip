@@ -3,6 +3,11 @@
 
 namespace atdn {
 
+bool& sf_fast_mode() {
+  static thread_local bool fast = false;
+  return fast;
+}
+
 // ------------------------------------------------------------------ block reductions (deterministic)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

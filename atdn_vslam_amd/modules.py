@@ -91,7 +91,7 @@ class RAFTGMA(_NativeModule):
     """GMA optical flow; `args` is the reference's GMA_Parameters-like object (only
     `num_heads`, `position_only`, `position_and_content` are consulted)."""
 
-    PRECISIONS = {"f32": 0, "split_f16": 1}
+    PRECISIONS = {"f32": 0, "split_f16": 1, "f16": 2}
 
     def __init__(self, args=None, max_batch=1, precision=None):
         super().__init__()
@@ -163,7 +163,7 @@ class RAFTGMA(_NativeModule):
         _require_gpu(frames, "RAFTGMA.forward_sequence")
         if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[0] < 2:
             raise RuntimeError("expected frames [B+1,3,H,W] with B >= 1, got %s" % (tuple(frames.shape),))
-        if self.precision != "split_f16":
+        if self.precision not in ("split_f16", "f16"):
             return self.forward(frames[:-1], frames[1:], iters=iters, flow_init=flow_init, test_mode=True)
         B, H, W = frames.shape[0] - 1, frames.shape[2], frames.shape[3]
         with torch.cuda.device(frames.device):

@@ -98,6 +98,12 @@ def cpu_baseline(gsd, hsd, frames, budget_s=25.0):
                       % (len(timed), ITERS, sec)}
 
 
+MFMA_PER_PRODUCT = {"split_f16": 3, "f16": 1, "f32": 1}   # MFMAs the engine executes per algorithmic product
+DTYPE_LABEL = {"split_f16": "f32 via 3xf16 split MFMA (fp32 accumulate)",
+               "f16": "f16 operands, fp32 accumulate (fast mode, own tolerance)",
+               "f32": "f32 (exact fp32 MFMA)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +112,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frame pairs per step per GPU")
     ap.add_argument("--streams", type=int, default=2, help="independent clips in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f16", "f32"],
+                    help="arithmetic of the flow network; the headline is split_f16 (fp32-grade). f16 = fast mode")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,7 +132,7 @@ def main():
     hsd = syn.to_torch(syn.make_clvo_state(seed=1))
     # S pipelines on S streams: consecutive steps (clips) overlap, which fills the tails of each other's kernels
     S = max(1, args.streams)
-    pipes = [OdometryPipeline(gsd, hsd, device=dev, max_batch=B, iters=ITERS) for _ in range(S)]
+    pipes = [OdometryPipeline(gsd, hsd, device=dev, max_batch=B, iters=ITERS, precision=args.precision) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     pipe = pipes[0]
     # synthetic clip, different per rank (each rank owns its own stretch of the sequence); resized once, resident
@@ -188,7 +196,7 @@ def main():
             "metric": "frame-pairs/sec, KITTI 1241x376 odometry inference at 1/2/4/8 MI355X",
             "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 via 3xf16 split MFMA (fp32 accumulate)", "data": "synthetic",
+            "dtype": DTYPE_LABEL[args.precision], "data": "synthetic",
             "config": {"workload": "KITTI seq-03-shaped 376x1241 frames resized to 376x1232, GMA flow 12 GRU iters + "
                                    "CLVO head -> 6-DoF trajectory (BASELINE configs[1])",
                        "pairs_per_step_per_gpu": B, "streams_per_gpu": S, "gru_iters": ITERS, "parallelism": "pairs sharded x%d, one "
@@ -199,7 +207,8 @@ def main():
                          "achieved": zr_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": zr_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic("SfGruZR", B),
                          "launch_ms": zr_launch_ms, "flop_per_launch": GRU_ZR_FLOP * B,
-                         "mfma_executed_tflops": 3 * zr_tflops, "mfma_executed_frac": 3 * zr_tflops / PEAK_F16_MFMA_TFLOPS,
+                         "mfma_executed_tflops": MFMA_PER_PRODUCT[args.precision] * zr_tflops,
+                         "mfma_executed_frac": MFMA_PER_PRODUCT[args.precision] * zr_tflops / PEAK_F16_MFMA_TFLOPS,
                          "vs_f32_mfma_peak": zr_tflops / PEAK_F32_MFMA_TFLOPS},
             "forward": {"ms_per_batch_median": fwd_ms, "tflops": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12,
                         "frac_of_f32_mfma_peak": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},

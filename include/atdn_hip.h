@@ -36,9 +36,13 @@ const char* atdn_last_error(void);
  * neural_slam.py:54,198-199). max_batch: largest number of frame pairs per forward.
  * precision: ATDN_PRECISION_F32 = every GEMM on the exact-fp32 matrix core (v_mfma_f32_32x32x2_f32);
  *            ATDN_PRECISION_SPLIT_F16 = every channel-wide GEMM as three f16 MFMAs on split operands
- *            (x = hi + lo, fp32 accumulate): fp32-grade results at 5.3x the matrix rate. */
+ *            (x = hi + lo, fp32 accumulate): fp32-grade results at 5.3x the matrix rate (the default);
+ *            ATDN_PRECISION_F16 = the fast mode: the same kernels and tensors, but only the hi x hi MFMA of every
+ *            product (plain f16 operands, fp32 accumulate) — what the reference itself runs on a GPU under
+ *            `mixed_precision` autocast (utils/gma_parameters.py:11); flow within ~1e-2 px of the fp32 CPU path. */
 #define ATDN_PRECISION_F32 0
 #define ATDN_PRECISION_SPLIT_F16 1
+#define ATDN_PRECISION_F16 2
 int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch, int precision);
 
 /* One state-dict entry (load_state_dict, neural_slam.py:52). `key` as in the checkpoint, with or without the

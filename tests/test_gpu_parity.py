@@ -438,6 +438,32 @@ def test_visual_odometry_matches_neuralslam_golden(golden_dir, gsd, hsd):
     assert torch.equal(vo(frames[0]), torch.eye(4))
 
 
+def test_fast_f16_mode_within_its_stated_tolerance(golden_dir, gsd, hsd):
+    """precision="f16" (ATDN_PRECISION_F16): the same kernels issuing only the hi x hi MFMA of every product — the
+    arithmetic the reference itself uses on a GPU (mixed_precision autocast). Stated tolerance against the fp32 CPU
+    path at 376x1232 / 12 iterations: flow_low <= 0.03 px, flow_up <= 0.15 px max and <= 0.03 px mean, pose <= 2e-3
+    (measured: 8.5e-3 / 4.1e-2 / 9e-3 px). The default mode's tolerances are 150x tighter and tested above."""
+    g = np.load(os.path.join(golden_dir, "gma_c2.npz"))
+    fr = torch.from_numpy(syn.make_frames(2, 376, 1232, seed=int(g["seed_frames"]))).to(DEV)
+    net = RAFTGMA(max_batch=1, precision="f16")
+    net.load_state_dict(gsd)
+    net = net.to(DEV).eval()
+    low, up = net(fr[0:1], fr[1:2], iters=int(g["iters"]), test_mode=True)
+    lowc, upc = low.cpu(), up.cpu()
+    e_low = _maxerr(lowc[0], torch.from_numpy(g["flow_low"]))
+    d_up = (upc[0, :, ::4, ::4].double() - torch.from_numpy(g["flow_up_s4"]).double()).abs()
+    assert 1e-4 < e_low < 0.03, e_low            # really a different arithmetic, and inside its tolerance
+    assert float(d_up.max()) < 0.15 and float(d_up.mean()) < 0.03
+    head = ATDNVO()
+    head.load_state_dict(hsd)
+    head = head.to(DEV).eval()
+    rot, tr = head(up)
+    assert _maxerr(rot.cpu(), torch.from_numpy(g["rot"])) < 2e-3 and _maxerr(tr.cpu(), torch.from_numpy(g["tr"])) < 2e-3
+    # sequence mode exists for this mode too and agrees with its pair mode bit for bit
+    low_s, up_s = net.forward_sequence(fr, iters=int(g["iters"]))
+    assert torch.equal(up_s, up)
+
+
 def test_sequence_pipeline_matches_frame_by_frame(gsd, hsd):
     """OdometryPipeline.run_sequence (clip batches + one ordered scan) == VisualOdometry frame by frame."""
     from atdn_vslam_amd.pipeline import OdometryPipeline, VisualOdometry, resize_frames
