@@ -19,6 +19,7 @@ SIGNATURES = {
     "atdn_gma_finalize": (C.c_int, [_vp]),
     "atdn_gma_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "atdn_gma_forward_sequence": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "atdn_gma_forward_sequence_continued": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "atdn_gma_debug_read": (C.c_long, [_vp, C.c_char_p, _vp, C.c_long, _vp]),
     "atdn_gma_profile": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f32p, _vp]),
     "atdn_gma_workspace_bytes": (C.c_size_t, [_vp]),

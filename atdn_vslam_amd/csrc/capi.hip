@@ -148,6 +148,13 @@ int atdn_gma_forward_sequence(atdn_gma* h, const float* frames, int B, int iters
   h->net.forward_sequence(frames, B, iters, flow_init, flow_low, flow_up, (hipStream_t)stream);
   ATDN_API_END
 }
+int atdn_gma_forward_sequence_continued(atdn_gma* h, const float* frames, int B, int iters, const float* flow_init,
+                                        float* flow_low, float* flow_up, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.forward_sequence(frames, B, iters, flow_init, flow_low, flow_up, (hipStream_t)stream, true);
+  ATDN_API_END
+}
 long atdn_gma_debug_read(atdn_gma* h, const char* name, float* host, long capacity, void* stream) {
   try {
     if (!h || !name || !host) throw Error("null argument");

@@ -39,7 +39,7 @@ class GmaNet {
   // B consecutive pairs of one clip: frames NCHW [B+1,3,H,W]; pair b = (frame b, frame b+1). The feature network
   // runs once per FRAME (B+1 passes instead of 2B).
   void forward_sequence(const float* frames, int B, int iters, const float* flow_init, float* flow_low, float* flow_up,
-                        hipStream_t st);
+                        hipStream_t st, bool continued = false);
   // copy an internal tensor to host (parity tests); returns element count, or -1 for an unknown name
   long debug_read(const char* name, float* host, long capacity, hipStream_t st);
   size_t workspace_bytes() const { return ws_bytes_; }
@@ -57,11 +57,14 @@ class GmaNet {
                    int* outW);
   void iteration(int B, hipStream_t st);
   void run_body_sf(int B, int iters, hipStream_t st);
-  void run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf);
+  // first_img: index of the first image of img4_ to encode (continued sequences skip frame 0 in the feature network)
+  void run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int first_img = 0);
   void iteration_sf(int B, hipStream_t st);
   void capture(int B, int iters);
   void launch_body(int B, int iters, hipStream_t st);
-  bool seq_ = false;  // current call shares frames between consecutive pairs
+  int seq_ = 0;        // 0: pair mode; 1: sequence (B+1 frames, every frame through fnet once); 2: sequence continued
+                       //    (frame 0 is the previous call's last frame: its features are reused, fnet sees B frames)
+  int last_frame_ = -1;  // fmap_ slot of the last frame of the previous sequence call
 
   StateDict sd_;
   WeightArena arena_;

@@ -107,7 +107,7 @@ void GmaNet::mark(int stage, hipStream_t st) {
 void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
   ATDN_CHECK(ready_ && B >= 1 && B <= maxB && reps >= 1, "bad profile request");
   for (int i = 0; i < ST_COUNT; ++i) ms[i] = 0.f;
-  seq_ = false;
+  seq_ = 0;
   for (int r = 0; r < reps; ++r) {
     Timer t;
     timer_ = &t;
@@ -407,7 +407,8 @@ void GmaNet::run_body(int B, int iters, hipStream_t st) {
 // =============================================================== split-f16 pipeline (precision == 1)
 // Same op sequence; every TAP-mode GEMM runs on conv_sf_kernel and every tensor that feeds one is stored in the
 // sf format (sf.h). ROW-mode layers (7x7 stems, convf1) stay on the exact-fp32 engine and write sf directly.
-void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf) {
+void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int first_img) {
+  const float* images = img4_.p + (long)first_img * H * W * 4;
   int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
   float* X = enc_[0].p; float* R = enc_[1].p; float* Y = enc_[2].p; float* O = enc_[3].p;
   auto stats_sf = [&](const PackedConv& L, const float* src, int ld, int ih, int iw, int stride, int pad, float* dst,
@@ -426,7 +427,7 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
                              reinterpret_cast<double*>(fin_.p), st);
   };
   if (instance) {
-    ConvShape s = conv_shape(E.stem, img4_.p, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
+    ConvShape s = conv_shape(E.stem, images, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
     EpiBiasStats ep{E.stem.b, R, (long)h * w * 64, 64, psum_.p, pm2_.p, 0};
     TileChoice t = conv_dispatch<MODE_ROW>(s, ep, st);
     const int groups = cdiv(h * w, t.BM) * (t.BM / 32);
@@ -434,7 +435,7 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
                            reinterpret_cast<double*>(fin_.p), st);
     launch_in_apply_sf(R, X, mean_[0].p, rstd_[0].p, nullptr, nullptr, nullptr, nullptr, nimg, (long)h * w, 64, st);
   } else {
-    ConvShape s = conv_shape(E.stem, img4_.p, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
+    ConvShape s = conv_shape(E.stem, images, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
     conv_dispatch<MODE_ROW>(s, SfBias<ACT_RELU>{E.stem.b, X, (long)h * w * 64, 64}, st);
   }
   int c = 64;
@@ -538,10 +539,14 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
 
 void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   float* f;
-  const int nfeat = seq_ ? B + 1 : 2 * B;  // feature-network passes: one per frame in sequence mode
-  run_encoder_sf(fnet_, true, nfeat, st, &f);
+  // feature-network passes: two per pair; one per frame in sequence mode; in a continued sequence frame 0's features
+  // were already moved into fmap_ slot 0 by forward_sequence and only frames 1..B are encoded (img4_ still holds all
+  // B+1 frames: the context network needs frame 0)
+  const int nfeat = seq_ == 0 ? 2 * B : seq_ == 1 ? B + 1 : B;
+  run_encoder_sf(fnet_, true, nfeat, st, &f, seq_ == 2 ? 1 : 0);
   ConvShape s = conv_shape(fnet_.head, f, 128, (long)N * 128, nfeat, H8, W8, 1, 0, 0);
-  conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fmap_.p, (long)N * 256, 256}, st);
+  float* fdst = fmap_.p + (seq_ == 2 ? (long)N * 256 : 0);
+  conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fdst, (long)N * 256, 256}, st);
   mark(ST_FNET, st);
 
   ConvShape c;
@@ -600,19 +605,30 @@ void GmaNet::capture(int B, int iters) {
   hipGraphExec_t exec = nullptr;
   ATDN_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   (void)hipGraphDestroy(graph);
-  graphs_[{B, iters * 2 + (seq_ ? 1 : 0)}] = exec;
+  graphs_[{B, iters * 4 + seq_}] = exec;
 }
 
 void GmaNet::forward_sequence(const float* frames, int B, int iters, const float* flow_init, float* flow_low,
-                               float* flow_up, hipStream_t st) {
+                               float* flow_up, hipStream_t st, bool continued) {
   ATDN_CHECK(ready_, "weights not finalized");
   ATDN_CHECK(precision >= 1, "sequence mode is built for the split-f16 pipeline");
   ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
   ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
   ATDN_CHECK(frames && flow_low && flow_up, "null tensor");
+  const long frame = 3L * H * W;
+  if (continued) {
+    // frame 0 is the last frame of the previous sequence call on this handle: its features move to slot 0 and the
+    // feature network only sees frames 1..B (every frame of a long sequence passes through it exactly once)
+    ATDN_CHECK(last_frame_ >= 1, "continued sequence call without a previous sequence call on this handle");
+    ATDN_HIP(hipMemcpyAsync(fmap_.p, fmap_.p + (long)last_frame_ * N * 256, (size_t)N * 256 * sizeof(float),
+                            hipMemcpyDeviceToDevice, st));
+    seq_ = 2;
+  } else {
+    seq_ = 1;
+  }
   // frames 0..B-1 are the first images, frame B the last second image: img4 = [frame 0 .. frame B]
-  launch_prep_images(frames, frames + (long)B * 3 * H * W, B, H, W, img4_.p, st, 1);
-  seq_ = true;
+  launch_prep_images(frames, frames + (long)B * frame, B, H, W, img4_.p, st, 1);
+  last_frame_ = B;
   launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
   launch_body(B, iters, st);
   launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
@@ -620,7 +636,7 @@ void GmaNet::forward_sequence(const float* frames, int B, int iters, const float
 
 void GmaNet::launch_body(int B, int iters, hipStream_t st) {
   if (use_graph_) {
-    auto key = std::make_pair(B, iters * 2 + (seq_ ? 1 : 0));
+    auto key = std::make_pair(B, iters * 4 + seq_);
     if (!graphs_.count(key)) capture(B, iters);
     ATDN_HIP(hipGraphLaunch(graphs_[key], st));
   } else {
@@ -634,7 +650,7 @@ void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const
   ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
   ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
   ATDN_CHECK(im1 && im2 && flow_low && flow_up, "null tensor");
-  seq_ = false;
+  seq_ = 0;
   launch_prep_images(im1, im2, B, H, W, img4_.p, st, B);
   if (precision >= 1) launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
   else launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);

@@ -156,10 +156,13 @@ class RAFTGMA(_NativeModule):
         return flow_low, flow_up
 
     @torch.no_grad()
-    def forward_sequence(self, frames, iters=12, flow_init=None):
+    def forward_sequence(self, frames, iters=12, flow_init=None, continued=False):
         """Flow of the B consecutive pairs of a clip `frames` [B+1,3,H,W] (pair b = frames[b] -> frames[b+1]), as
         NeuralSLAM walks a sequence; each frame passes through the feature network once. Returns (flow_low, flow_up)
-        exactly as `forward(frames[:-1], frames[1:], test_mode=True)` does."""
+        exactly as `forward(frames[:-1], frames[1:], test_mode=True)` does.
+        `continued=True`: frames[0] is the frame that was frames[-1] of the previous call on this module (the next
+        clip of the same sequence); its features are reused and only frames[1:] go through the feature network.
+        Same results up to rounding (the feature network sees one image less and may pick another tile shape)."""
         _require_gpu(frames, "RAFTGMA.forward_sequence")
         if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[0] < 2:
             raise RuntimeError("expected frames [B+1,3,H,W] with B >= 1, got %s" % (tuple(frames.shape),))
@@ -176,8 +179,8 @@ class RAFTGMA(_NativeModule):
             flow_low = torch.empty((B, 2, H // 8, W // 8), dtype=torch.float32, device=frames.device)
             flow_up = torch.empty((B, 2, H, W), dtype=torch.float32, device=frames.device)
             h = self._handle(H, W, B)
-            _lib.check(_lib.lib().atdn_gma_forward_sequence(h, _ptr(fr), B, int(iters), _ptr(fi), _ptr(flow_low),
-                                                            _ptr(flow_up), _stream()))
+            fn = _lib.lib().atdn_gma_forward_sequence_continued if continued else _lib.lib().atdn_gma_forward_sequence
+            _lib.check(fn(h, _ptr(fr), B, int(iters), _ptr(fi), _ptr(flow_low), _ptr(flow_up), _stream()))
         return flow_low, flow_up
 
     def debug_read(self, name, shape, H, W):

@@ -57,11 +57,12 @@ class OdometryPipeline:
         return self.head.encode(flow), flow
 
     @torch.no_grad()
-    def features_clip(self, frames):
+    def features_clip(self, frames, continued=False):
         """frames [B+1,3,H,W]: B consecutive pairs of one clip -> (feat [B,512], flow_up [B,2,H,W]); the shared
-        frames go through the feature network once (RAFTGMA.forward_sequence)."""
+        frames go through the feature network once (RAFTGMA.forward_sequence). `continued`: frames[0] was the last
+        frame of the previous call (next clip of the same sequence) and its features are reused."""
         frames = self.padder.pad(frames)[0]
-        _, flow = self.flow_net.forward_sequence(frames, iters=self.iters)
+        _, flow = self.flow_net.forward_sequence(frames, iters=self.iters, continued=continued)
         return self.head.encode(flow), flow
 
     @torch.no_grad()
@@ -80,7 +81,7 @@ class OdometryPipeline:
             out = []
             for s in range(lo, hi, batch):
                 e = min(s + batch, hi)
-                f, _ = self.features_clip(frames[s:e + 1])
+                f, _ = self.features_clip(frames[s:e + 1], continued=(s > lo))   # consecutive clips of this shard
                 out.append(f)
             return torch.cat(out) if out else torch.zeros((0, 512), device=self.device)
 

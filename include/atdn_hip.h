@@ -65,6 +65,12 @@ int atdn_gma_forward(atdn_gma* h, const float* im1, const float* im2, int B, int
  * network runs once per frame instead of twice. Split-f16 handles only. */
 int atdn_gma_forward_sequence(atdn_gma* h, const float* frames, int B, int iters, const float* flow_init,
                               float* flow_low, float* flow_up, void* stream);
+/* The same for the NEXT clip of one sequence on this handle: frames[0] must be the frame that was frames[B] of the
+ * previous atdn_gma_forward_sequence(_continued) call; its features are reused (device-side copy) and the feature
+ * network runs on frames[1..B] only, so every frame of a long sequence passes through it exactly once. Results equal
+ * the non-continued call's up to kernel-selection rounding (the feature network sees one image less). */
+int atdn_gma_forward_sequence_continued(atdn_gma* h, const float* frames, int B, int iters, const float* flow_init,
+                                        float* flow_low, float* flow_up, void* stream);
 
 /* Copies an internal activation to a HOST buffer for parity tests ("fmap", "pyr0".."pyr3", "attn", "net",
  * "x", "corrfeat", "mask", "coords1", "flow4", "qk", "img4"). Returns the number of floats copied, -1 on error. */

@@ -438,6 +438,26 @@ def test_visual_odometry_matches_neuralslam_golden(golden_dir, gsd, hsd):
     assert torch.equal(vo(frames[0]), torch.eye(4))
 
 
+def test_continued_sequence_reuses_the_shared_frame_bit_exactly(gsd):
+    """Clip k+1 of a sequence with continued=True (features of its first frame taken from clip k) must reproduce the
+    plain sequence call (to rounding: the feature network then runs on one image less, which can select another tile
+    shape at this small size); a continued call without a predecessor is an error."""
+    fr = torch.from_numpy(syn.make_frames(7, 160, 512, seed=21)).to(DEV)
+    net = RAFTGMA(max_batch=3)
+    net.load_state_dict(gsd)
+    net = net.to(DEV).eval()
+    with pytest.raises(RuntimeError, match="previous sequence call"):
+        net.forward_sequence(fr[0:4], iters=3, continued=True)
+    a_low, a_up = net.forward_sequence(fr[0:4], iters=3)
+    b_low, b_up = net.forward_sequence(fr[3:7], iters=3, continued=True)
+    c_low, c_up = net.forward_sequence(fr[5:7], iters=3, continued=False)   # shorter clip in between resets nothing
+    ref_low, ref_up = net.forward_sequence(fr[3:7], iters=3)
+    assert _maxerr(b_up, ref_up) < 1e-4 and _maxerr(b_low, ref_low) < 2e-5
+    d_low, d_up = net.forward_sequence(fr[6:7].repeat(2, 1, 1, 1).clone(), iters=3, continued=True)  # 1-pair clip
+    e_low, e_up = net.forward_sequence(fr[6:7].repeat(2, 1, 1, 1).clone(), iters=3)
+    assert _maxerr(d_up, e_up) < 1e-4
+
+
 def test_fast_f16_mode_within_its_stated_tolerance(golden_dir, gsd, hsd):
     """precision="f16" (ATDN_PRECISION_F16): the same kernels issuing only the hi x hi MFMA of every product — the
     arithmetic the reference itself uses on a GPU (mixed_precision autocast). Stated tolerance against the fp32 CPU
