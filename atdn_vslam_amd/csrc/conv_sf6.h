@@ -218,37 +218,56 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
     return;
   }
   if constexpr (SWAP) {
-    // ---- channel-vector epilogue: lane r owns pixel pbase + r; registers 4k..4k+3 are channels nb + 8k + 4h + (0..3)
+    // ---- channel-vector epilogue. After the MFMAs lane (r, h) holds, for pixel r of a 32-pixel tile, channels
+    // 8k + 4h + (0..3) in registers 4k..4k+3. Storing from there gives every 128-byte output line 8 separate partial
+    // writes (measured: 20 us of a 170 us kernel; the same bytes as whole-line stores cost 7 us). So each tile is
+    // transposed through a wave-private LDS slab first: 4 ds_write_b128 in, 4 ds_read_b128 out, after which lane l
+    // owns pixel 8q + l/8, channels 4*(l%8)..+3 — 8 consecutive lanes cover one pixel's 32-channel group, and every
+    // load and store of the epilogue (operands of the GRU gates included) is a whole line per pixel.
+    __shared__ __attribute__((aligned(16))) float tbuf[NW][32 * LDS_LD];
+    float* tb = tbuf[wave];
+    const int trow = lane >> 3, tcol = (lane & 7) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int p = (wm * TM + i) * 32 + r;
-      const int oy = ty0 + p / TW, ox = tx0 + p % TW;
-      const bool pok = oy < g.Ho && ox < g.Wo;
-      const int m = pok ? oy * g.Wo + ox : 0;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + (wn * TN + j) * 32 + 4 * h;
+        const int nb = n0 + (wn * TN + j) * 32 + tcol;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          *reinterpret_cast<float4*>(tb + r * LDS_LD + 8 * k + 4 * h) =
+              make_float4(acc[i][j][4 * k] * g.wscale, acc[i][j][4 * k + 1] * g.wscale, acc[i][j][4 * k + 2] * g.wscale,
+                          acc[i][j][4 * k + 3] * g.wscale);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        float4 v[4];
+        int mq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = *reinterpret_cast<const float4*>(tb + (8 * q + trow) * LDS_LD + tcol);
+          const int p = (wm * TM + i) * 32 + 8 * q + trow;
+          const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+          mq[q] = (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next tile
         if constexpr (Epi::kPrefetch) {
           typename Epi::Aux4 aux[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) aux[k] = ep.load4(img, m, min(nb + 8 * k, g.N - 4));
+          for (int q = 0; q < 4; ++q) aux[q] = ep.load4(img, max(mq[q], 0), min(nb, g.N - 4));
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (pok && nb + 8 * k < g.N)
-              ep.apply4(img, m, nb + 8 * k,
-                        make_float4(acc[i][j][4 * k] * g.wscale, acc[i][j][4 * k + 1] * g.wscale,
-                                    acc[i][j][4 * k + 2] * g.wscale, acc[i][j][4 * k + 3] * g.wscale), aux[k]);
+          for (int q = 0; q < 4; ++q)
+            if (mq[q] >= 0 && nb < g.N) ep.apply4(img, mq[q], nb, v[q], aux[q]);
         } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int n = nb + 8 * k;
-            if (pok && n + 4 <= g.N) {
-              ep.store4(img, m, n, make_float4(acc[i][j][4 * k] * g.wscale, acc[i][j][4 * k + 1] * g.wscale,
-                                               acc[i][j][4 * k + 2] * g.wscale, acc[i][j][4 * k + 3] * g.wscale));
-            } else if (pok) {  // N % 4 != 0: the last run is partial, element-wise
+          for (int q = 0; q < 4; ++q) {
+            if (mq[q] < 0) continue;
+            if (nb + 4 <= g.N) {
+              ep.store4(img, mq[q], nb, v[q]);
+            } else {  // N % 4 != 0: the last run is partial, element-wise
+              const float e4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                if (n + e < g.N) ep(img, m, n + e, acc[i][j][4 * k + e] * g.wscale);
+                if (nb + e < g.N) ep(img, mq[q], nb + e, e4[e]);
             }
           }
         }
