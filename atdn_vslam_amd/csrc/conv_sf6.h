@@ -48,7 +48,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
   // 16 distinct 16-byte bank slots (pixel pitch 144 B = 9 slots, 9 odd); PW*144 alone gives 2-way conflicts
   constexpr int RS = (PW * ROWB + 255) / 256 * 256;
   constexpr bool SWAP = epi_vec4<Epi>::value;
-  __shared__ __attribute__((aligned(256))) char Pbytes[(TH + KH - 1) * RS];
+  // two patch images: chunk c+1 is written (from the registers its loads landed in) during the last tap of chunk c,
+  // so a chunk boundary costs one barrier, not two
+  constexpr int PSZ = (TH + KH - 1) * RS;
+  __shared__ __attribute__((aligned(256))) char Pbytes[2 * PSZ];
 
   const int tid = threadIdx.x;
   const int tiles_img = g.tiles_x * g.tiles_y;
@@ -91,11 +94,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
     for (int k = 0; k < NP; ++k)
       pr[k] = *reinterpret_cast<const float4*>(sp + (long)((pmeta[k] >> 12) ? (pmeta[k] >> 12) - 1 : 0) * ld + co + 4 * s);
   };
-  auto store_patch = [&]() {
+  auto store_patch = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NP; ++k)
       if (r0 + RSTEP * k < PROWS)
-        *reinterpret_cast<float4*>(Pbytes + ((pmeta[k] & 0xFFFu) << 4)) = keep_if((pmeta[k] >> 12) != 0, pr[k]);
+        *reinterpret_cast<float4*>(Pbytes + buf * PSZ + ((pmeta[k] & 0xFFFu) << 4)) = keep_if((pmeta[k] >> 12) != 0, pr[k]);
   };
 
   // ---- MFMA roles
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
     const int p = (wm * TM + i) * 32 + r;
     a_off[i] = (p / TW) * RS + (p % TW) * ROWB + 16 * h;
   }
-  const char* Pb = Pbytes;
+  const char* Pb = Pbytes;   // image of the current chunk
   // weight fragment rows (clamped: accumulators of rows >= N are never stored)
   const float* wrow[TN];
 #pragma unroll
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
   fetch_patch(0);
   load_w(w0, 0, 0);
   if (NTAP > 1) load_w(w1, 0, 1); else if (nck > 1) load_w(w1, 1, 0);
-  store_patch();
+  store_patch(0);
   __syncthreads();
   // activation fragments are software-pipelined at half-step granularity: while the 3*TM*TN MFMAs of K sub-step t
   // run, the ds_reads of the next sub-step fill the other register set (set index = t)
@@ -190,16 +193,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
         else if (more) load_w(w2, c + 1, tap + 2 - NTAP);
       }
       if (!(ABL & 4)) read_a(1, tap, 1);
+      if (!(ABL & 2) && tap + 1 == NTAP && more) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
       mfma_half(0);
       if (!(ABL & 4) && tap + 1 < NTAP) read_a(0, tap + 1, 0);
       mfma_half(1);
       w0 = w1;
       w1 = w2;
-      if (tap + 1 == NTAP && more) {  // chunk boundary: every wave is done reading the patch, then it is replaced
+      if (tap + 1 == NTAP && more) {  // chunk boundary: publish the next patch image (one barrier)
         if (!(ABL & 2)) {
-          asm volatile("s_barrier" ::: "memory");
-          store_patch();
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          Pb = Pbytes + ((c + 1) & 1) * PSZ;
         }
         if (!(ABL & 4)) read_a(0, 0, 0);
       }
