@@ -3,6 +3,7 @@
 // through the convolutional encoder, AdamW. Gradients live in one flat buffer so that data-parallel training is a
 // single all-reduce (RCCL) over it between `forward_backward` and `adamw_step`.
 #pragma once
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -66,6 +67,7 @@ class ClvoTrainer {
 
   StateDict sd_;
   bool ready_ = false;
+  bool conv16_ = !(getenv("ATDN_TRAIN_CONV16") && getenv("ATDN_TRAIN_CONV16")[0] == '0');  // 16-channel convs on the 16x16x4 MFMA kernel
   std::map<std::string, Slot> pindex_;
   std::map<std::string, long> sindex_;
   long n_params_ = 0, n_stats_ = 0;

@@ -218,6 +218,10 @@ void ClvoTrainer::pack_weights(hipStream_t st) {
 }
 
 void ClvoTrainer::conv_fwd(const ConvL& c, const float* x, int h, int w, float* z, hipStream_t st) {
+  if (c.cin == 16 && conv16_) {   // 16 -> 16 channels: the 16x16x4 fp32 MFMA kernel, weights straight from the parameters
+    launch_conv16(x, T * B, h, w, P(c.w), false, P(c.b), c.kh, c.stride, c.pad, z, st);
+    return;
+  }
   ConvShape s;
   s.src0 = x; s.ld0 = c.cpix; s.sb0 = (long)h * w * c.cpix; s.C0 = c.cpix; s.H = h; s.W = w;
   s.KH = c.kh; s.KW = c.kw; s.stride = c.stride; s.padH = c.pad; s.padW = c.pad;
@@ -236,6 +240,11 @@ void ClvoTrainer::conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w
     src = stuffed_.p;
   } else {
     ATDN_CHECK(Hs == ho && Ws == wo, "stride-1 data gradient expects same-size maps");
+  }
+  if (c.cin == 16 && ldd == 16 && conv16_) {
+    ATDN_CHECK(Hs + c.kh - 1 - 2 * c.pad == h_in && Ws + c.kw - 1 - 2 * c.pad == w_in, "data-gradient geometry");
+    launch_conv16(src, T * B, Hs, Ws, P(c.w), true, nullptr, c.kh, 1, c.kh - 1 - c.pad, dx, st);
+    return;
   }
   ConvShape s;
   s.src0 = src; s.ld0 = 16; s.sb0 = (long)Hs * Ws * 16; s.C0 = 16; s.H = Hs; s.W = Ws;

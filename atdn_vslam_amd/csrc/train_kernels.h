@@ -80,3 +80,14 @@ void launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr
                   float beta2, int t, hipStream_t st);
 
 }  // namespace atdn
+
+namespace atdn {
+// ---- 16 -> 16 channel convolution on NHWC16 maps with v_mfma_f32_16x16x4_f32 (exact fp32): the thin convolutions of
+// the CLVO encoder fill a 32x32 MFMA tile to a quarter (N = 16, K rows padded 48 -> 64); here N is exactly one
+// 16-column tile, K = KH*KW*16 needs no padding, the whole weight tensor sits in operand registers for the lifetime
+// of the block and the input is read from an LDS halo patch with one ds_read_b128 per tap and 16-pixel tile.
+// w: OIHW [16][16][K][K]; transposed = use w[c][n][K-1-ky][K-1-kx] instead (data gradient of a convolution).
+// z[img][oy][ox][n] = bias[n] + sum x[img][oy*S - pad + ky][ox*S - pad + kx][c] * w(n, c, ky, kx)
+void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int K, int S,
+                   int pad, float* z, hipStream_t st);
+}  // namespace atdn

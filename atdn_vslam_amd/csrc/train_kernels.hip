@@ -2,6 +2,8 @@
 // written for coalesced 16-byte accesses (NHWC16 maps: one float4 per thread) and deterministic reductions
 // (per-block partials + a second pass, no floating-point atomics).
 #include "train_kernels.h"
+
+#include <cstdint>
 #include "common.h"
 #include <algorithm>
 #include <cmath>
@@ -568,8 +570,61 @@ __global__ __launch_bounds__(256) void gemm_kernel(int transA, int transB, int M
       }
     }
 }
+// A not transposed and K a multiple of 8: v_mfma_f32_32x32x2_f32, one 32x32 tile of C per block, K split over the four
+// waves and summed through LDS in a fixed order. The recurrent products of the LSTMs (M = batch, K up to 2048) would
+// otherwise run on a handful of blocks. K order inside a step of 8: MFMA j holds k = kb + 4h + j in slot h = lane >> 5, so
+// every lane feeds four MFMAs from one float4 of its row.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void gemm_rows_kernel(int transB, int M, int N, int K, const float* __restrict__ A, int lda,
+                                                        const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                        float beta, const float* __restrict__ bias) {
+  __shared__ float red[4][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int steps = K / 8, per = (steps + 3) / 4;
+  const int s0 = wave * per, s1 = min(steps, s0 + per);
+  const bool mok = m0 + r < M, nok = n0 + r < N;
+  const float* arow = A + (long)(mok ? m0 + r : 0) * lda + 4 * h;
+  const float* brow = transB ? B + (long)(nok ? n0 + r : 0) * ldb + 4 * h : B + (long)(4 * h) * ldb + (nok ? n0 + r : 0);
+  f32x16_t acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int sidx = s0; sidx < s1; ++sidx) {
+    const int kb = sidx * 8;
+    float4 a = *reinterpret_cast<const float4*>(arow + kb);
+    float4 b;
+    if (transB) b = *reinterpret_cast<const float4*>(brow + kb);
+    else { const float* q = brow + (long)kb * ldb; b = make_float4(q[0], q[ldb], q[2L * ldb], q[3L * ldb]); }
+    if (!mok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!nok) b = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[wave][(i >> 2) * 8 + h * 4 + (i & 3)][r] = acc[i];   // D: row, column = lane & 31
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+    const int mm = i >> 5, nn = i & 31, m = m0 + mm, n = n0 + nn;
+    if (m < M && n < N) {
+      float v = ((red[0][mm][nn] + red[1][mm][nn]) + red[2][mm][nn]) + red[3][mm][nn];
+      if (bias) v += bias[n];
+      if (beta != 0.f) v += beta * C[(long)m * ldc + n];
+      C[(long)m * ldc + n] = v;
+    }
+  }
+}
+
 void launch_gemm(bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                  int ldc, float beta, const float* bias, hipStream_t st) {
+  const bool aligned = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0) && (!transB || ((ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)));
+  if (!transA && K % 8 == 0 && K >= 64 && aligned) {
+    hipLaunchKernelGGL(gemm_rows_kernel, dim3(cdiv(N, 32), cdiv(M, 32)), dim3(256), 0, st, transB ? 1 : 0, M, N, K, A, lda, B,
+                       ldb, C, ldc, beta, bias);
+    ATDN_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(gemm_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, st, transA ? 1 : 0, transB ? 1 : 0, M, N, K, A,
                      lda, B, ldb, C, ldc, beta, bias);
   ATDN_HIP(hipGetLastError());
@@ -724,6 +779,105 @@ void launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, wd, eps, beta1, beta2,
                      (float)bc1, (float)std::sqrt(bc2));
   ATDN_HIP(hipGetLastError());
+}
+
+}  // namespace atdn
+
+// ------------------------------------------------------------------------------------------------ thin 16x16 convolution
+namespace atdn {
+namespace {
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int c16_pitch(int S) { return S == 1 ? 16 : S == 2 ? 20 : 24; }   // floats per patch pixel: conflict-free b128 reads
+
+// K operand order: MFMA (tap, j) holds channel 4g + j in k-slot g = lane >> 4, so a lane's float4 (channels 4g..4g+3 of
+// its pixel) feeds the four MFMAs of a tap component by component.
+template <int K, int S, int TH, int TW>
+__global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x, int nimg, int H, int W,
+                                                     const float* __restrict__ w, int transposed,
+                                                     const float* __restrict__ bias, int pad, int Ho, int Wo,
+                                                     float* __restrict__ z, int tiles_x, int tiles_img, int ntiles) {
+  constexpr int PH = (TH - 1) * S + K, PW = (TW - 1) * S + K, PP = c16_pitch(S);
+  __shared__ __attribute__((aligned(16))) float patch[PH * PW * PP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // weights into operand registers once per (persistent) block: breg[tap][j] = w(n = lane & 15, c = 4*(lane >> 4) + j, tap)
+  const int n = lane & 15, g = lane >> 4;
+  float breg[K * K][4];
+#pragma unroll
+  for (int tap = 0; tap < K * K; ++tap)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * g + j;
+      breg[tap][j] = transposed ? w[((long)c * 16 + n) * K * K + (K * K - 1 - tap)] : w[((long)n * 16 + c) * K * K + tap];
+    }
+  const float bv = bias ? bias[n] : 0.f;
+  constexpr int TILES = TH * TW / 16, TPR = TW / 16;   // 16-pixel MFMA tiles of the block tile; per row
+  static_assert(TILES % 2 == 0, "two tiles per wave and trip");
+  for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
+    const int img = bt / tiles_img, tloc = bt - img * tiles_img;
+    const int oy0 = (tloc / tiles_x) * TH, ox0 = (tloc % tiles_x) * TW;
+    const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+    __syncthreads();   // everyone is done with the previous patch
+    for (int i = tid; i < PH * PW * 4; i += 256) {   // one float4 per thread and trip
+      const int q = i & 3, px = (i >> 2) % PW, py = (i >> 2) / PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        v = *reinterpret_cast<const float4*>(x + (((long)img * H + iy) * W + ix) * 16 + 4 * q);
+      *reinterpret_cast<float4*>(patch + (py * PW + px) * PP + 4 * q) = v;
+    }
+    __syncthreads();
+    for (int t = 2 * wave; t < TILES; t += 8) {   // two independent accumulation chains per wave
+      const int ty0 = t / TPR, tx0 = (t % TPR) * 16, ty1 = (t + 1) / TPR, tx1 = ((t + 1) % TPR) * 16;
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // in the A operand lane & 15 is the pixel of the row
+      const float* b0 = patch + ((ty0 * S) * PW + (tx0 + n) * S) * PP + 4 * g;
+      const float* b1 = patch + ((ty1 * S) * PW + (tx1 + n) * S) * PP + 4 * g;
+#pragma unroll
+      for (int tap = 0; tap < K * K; ++tap) {
+        const int off = ((tap / K) * PW + (tap % K)) * PP;
+        const float4 a0 = *reinterpret_cast<const float4*>(b0 + off);
+        const float4 a1 = *reinterpret_cast<const float4*>(b1 + off);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[tap][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[tap][0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[tap][1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[tap][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[tap][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, breg[tap][2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[tap][3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, breg[tap][3], acc1, 0, 0, 0);
+      }
+      // D: row (pixel) = 4*g + e, column (output channel) = lane & 15
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int oya = oy0 + ty0, oxa = ox0 + tx0 + 4 * g + e, oyb = oy0 + ty1, oxb = ox0 + tx1 + 4 * g + e;
+        if (oya < Ho && oxa < Wo) z[(((long)img * Ho + oya) * Wo + oxa) * 16 + n] = acc0[e] + bv;
+        if (oyb < Ho && oxb < Wo) z[(((long)img * Ho + oyb) * Wo + oxb) * 16 + n] = acc1[e] + bv;
+      }
+    }
+  }
+}
+
+template <int K, int S, int TH, int TW>
+void conv16_launch(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int pad,
+                   float* z, hipStream_t st) {
+  const int Ho = (H + 2 * pad - K) / S + 1, Wo = (W + 2 * pad - K) / S + 1;
+  const int tx = cdiv(Wo, TW), ty = cdiv(Ho, TH);
+  const int ntiles = nimg * tx * ty;
+  const int grid = ntiles < 256 * 3 ? ntiles : 256 * 3;   // persistent blocks: the weights are loaded into registers once
+  hipLaunchKernelGGL((conv16_kernel<K, S, TH, TW>), dim3(grid), dim3(256), 0, st, x, nimg, H, W, w, transposed ? 1 : 0, bias,
+                     pad, Ho, Wo, z, tx, tx * ty, ntiles);
+  ATDN_HIP(hipGetLastError());
+}
+}  // namespace
+
+void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int K, int S,
+                   int pad, float* z, hipStream_t st) {
+  if (K == 3 && S == 1) conv16_launch<3, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, st);
+  else if (K == 3 && S == 2) conv16_launch<3, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, st);
+  else if (K == 3 && S == 3) conv16_launch<3, 3, 2, 32>(x, nimg, H, W, w, transposed, bias, pad, z, st);
+  else if (K == 1 && S == 2) conv16_launch<1, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, st);
+  else if (K == 1 && S == 1) conv16_launch<1, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, st);
+  else throw Error("conv16: no kernel for this shape");
 }
 
 }  // namespace atdn
