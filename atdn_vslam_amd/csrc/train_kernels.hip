@@ -4,6 +4,7 @@
 #include "train_kernels.h"
 
 #include <cstdint>
+#include <cstdlib>
 #include "common.h"
 #include <algorithm>
 #include <cmath>
@@ -329,6 +330,7 @@ void launch_add_inplace(float* a, const float* b, long n, hipStream_t st) {
 namespace {
 constexpr int WG_TW = 32;        // output columns staged per step
 constexpr int WG_BLOCKS = 1024;  // persistent blocks; partials are [output][block]
+constexpr int WG_MFMA_BLOCKS = 768, WG_SLOTS = WG_MFMA_BLOCKS * 4;   // MFMA variant: one partial per wave
 constexpr int wg_nf4(int S, int KW) { return (3 * S + KW + 3) / 4; }   // float4 loads covering 4 output columns of one tap row
 constexpr int wg_pwpad(int S, int KW) {
   int need = (WG_TW - 4) * S + wg_nf4(S, KW) * 4;
@@ -338,7 +340,7 @@ constexpr int wg_pwpad(int S, int KW) {
   return p;
 }
 }  // namespace
-long wgrad_scratch_floats(int, int, int Cin, int KH, int KW) { return (long)WG_BLOCKS * KH * KW * 16 * Cin; }
+long wgrad_scratch_floats(int, int, int Cin, int KH, int KW) { return (long)WG_SLOTS * KH * KW * 16 * Cin; }
 
 // Thread (n, c, g): output channel n, input channel c, and the kernel rows ky = g, g + GROUPS, ... with ALL kx of those
 // rows (GROUPS = 256 / (16*CIN)). The staged input patch is channel-major in LDS, xs[py][c][px], so the 3*S + KW
@@ -434,6 +436,99 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   }
 }
 
+// CIN = 16 on the matrix cores: dW[n][c](tap) = sum_px dz[px][n] * x[px*S + tap][c] is a 16 x 16 x (pixels) product per tap,
+// v_mfma_f32_16x16x4_f32 with A = dz^T and B = x, both read from the channel-major LDS images with b128 loads (k-slot g of
+// MFMA j holds pixel 4g + j of a 16-pixel group). Each wave owns whole 16-pixel groups and keeps the K*K accumulator tiles;
+// its partial goes to scratch slot 4*block + wave, summed by conv_wgrad_reduce_kernel in a fixed order. The next item's
+// pixels are fetched into registers while the current one is multiplied.
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+template <int S, int K, int R>
+__global__ __launch_bounds__(256) void conv_wgrad16_mfma_kernel(const float* __restrict__ x, int nimg, int H, int W,
+                                                                const float* __restrict__ dz, int Ho, int Wo, int pad,
+                                                                float* __restrict__ scratch, int nslots) {
+  constexpr int PH = (R - 1) * S + K, PWP = wg_pwpad(S, K), NF4 = wg_nf4(S, K), DSP = WG_TW + 4;
+  constexpr int NX = PH * PWP * 4, NXF = (NX + 255) / 256, ND = R * WG_TW * 4, NDF = (ND + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float xs[PH * 16 * PWP];
+  __shared__ __attribute__((aligned(16))) float ds[R * 16 * DSP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, idx = lane & 15, g = lane >> 4;
+  wg_f32x4 acc[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) acc[t] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int rblocks = cdiv_dev(Ho, R), cblocks = cdiv_dev(Wo, WG_TW);
+  const long items = (long)nimg * rblocks * cblocks;
+  float4 fx[NXF], fd[NDF];
+  auto fetch = [&](long it) {
+    const int cb0 = (int)(it % cblocks), rb = (int)((it / cblocks) % rblocks), img = (int)(it / ((long)cblocks * rblocks));
+    const int oy0 = rb * R, ox0 = cb0 * WG_TW, iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+#pragma unroll
+    for (int f = 0; f < NXF; ++f) {
+      const int i = tid + 256 * f, q = i & 3, pix = i >> 2, px = pix % PWP, py = pix / PWP;
+      const int iy = iy0 + py, ix = ix0 + px;
+      fx[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        fx[f] = *reinterpret_cast<const float4*>(x + (((long)img * H + iy) * W + ix) * 16 + 4 * q);
+    }
+#pragma unroll
+    for (int f = 0; f < NDF; ++f) {
+      const int i = tid + 256 * f, q = i & 3, pix = i >> 2, col = pix % WG_TW, r = pix / WG_TW;
+      const int oy = oy0 + r, ox = ox0 + col;
+      fd[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < ND && oy < Ho && ox < Wo) fd[f] = *reinterpret_cast<const float4*>(dz + (((long)img * Ho + oy) * Wo + ox) * 16 + 4 * q);
+    }
+  };
+  if ((long)blockIdx.x < items) fetch(blockIdx.x);
+  for (long it = blockIdx.x; it < items; it += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < NXF; ++f) {
+      const int i = tid + 256 * f, q = i & 3, pix = i >> 2, px = pix % PWP, py = pix / PWP;
+      if (i < NX) {
+        float* d = xs + (py * 16 + 4 * q) * PWP + px;
+        d[0] = fx[f].x; d[PWP] = fx[f].y; d[2 * PWP] = fx[f].z; d[3 * PWP] = fx[f].w;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < NDF; ++f) {
+      const int i = tid + 256 * f, q = i & 3, pix = i >> 2, col = pix % WG_TW, r = pix / WG_TW;
+      if (i < ND) {
+        float* d = ds + (r * 16 + 4 * q) * DSP + col;
+        d[0] = fd[f].x; d[DSP] = fd[f].y; d[2 * DSP] = fd[f].z; d[3 * DSP] = fd[f].w;
+      }
+    }
+    __syncthreads();
+    if (it + gridDim.x < items) fetch(it + gridDim.x);
+#pragma unroll 1
+    for (int grp = wave; grp < R * (WG_TW / 16); grp += 4) {
+      const int r = grp / (WG_TW / 16), c0 = (grp % (WG_TW / 16)) * 16;
+      const float4 d4 = *reinterpret_cast<const float4*>(ds + (r * 16 + idx) * DSP + c0 + 4 * g);
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const float4* xp = reinterpret_cast<const float4*>(xs + ((r * S + ky) * 16 + idx) * PWP + (c0 + 4 * g) * S);
+        float xr[NF4 * 4];
+#pragma unroll
+        for (int q = 0; q < NF4; ++q) {
+          const float4 v = xp[q];
+          xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j], xr[j * S + kx], acc[ky * K + kx], 0, 0, 0);
+      }
+    }
+  }
+  // D: row = output channel n = 4g + e, column = input channel c = lane & 15
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = (t * 16 + 4 * g + e) * 16 + idx;
+      scratch[(long)o * nslots + blockIdx.x * 4 + wave] = acc[t][e];
+    }
+}
+
 // one wave per output: sum its partials, add into dW (OIHW)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ scratch, int nblk, int Cin, int KH,
                                                                 int KW, float* __restrict__ dW) {
@@ -462,9 +557,27 @@ static void wgrad_launch(const float* x, int Cpix, int nimg, int H, int W, const
   ATDN_HIP(hipGetLastError());
 }
 
+template <int S, int K, int R>
+static void wgrad16_mfma_launch(const float* x, int nimg, int H, int W, const float* dz, int Ho, int Wo, int pad, float* scratch,
+                                float* dW, hipStream_t st) {
+  const long items = (long)nimg * cdiv(Ho, R) * cdiv(Wo, WG_TW);
+  const int nblk = (int)std::min<long>(items, WG_MFMA_BLOCKS);
+  hipLaunchKernelGGL((conv_wgrad16_mfma_kernel<S, K, R>), dim3(nblk), dim3(256), 0, st, x, nimg, H, W, dz, Ho, Wo, pad, scratch,
+                     nblk * 4);
+  ATDN_HIP(hipGetLastError());
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(K * K * 16 * 16, 4)), dim3(256), 0, st, scratch, nblk * 4, 16, K, K, dW);
+  ATDN_HIP(hipGetLastError());
+}
+
 void launch_conv_wgrad(const float* x, int Cpix, int Cin, int nimg, int H, int W, const float* dz, int Ho, int Wo, int KH,
                        int KW, int stride, int pad, float* scratch, float* dW, hipStream_t st) {
   ATDN_CHECK(Cpix >= Cin && Cpix % 4 == 0, "conv_wgrad: channel layout");
+  static const bool mfma = !(getenv("ATDN_TRAIN_WGRAD_MFMA") && getenv("ATDN_TRAIN_WGRAD_MFMA")[0] == '0');
+  if (mfma && Cin == 16 && Cpix == 16) {
+    if (KH == 3 && KW == 3 && stride == 1) return wgrad16_mfma_launch<1, 3, 8>(x, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+    if (KH == 3 && KW == 3 && stride == 2) return wgrad16_mfma_launch<2, 3, 4>(x, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+    if (KH == 1 && KW == 1 && stride == 2) return wgrad16_mfma_launch<2, 1, 4>(x, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+  }
   if (Cin == 16 && KH == 3 && KW == 3 && stride == 1) wgrad_launch<1, 3, 3, 16, 4>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
   else if (Cin == 16 && KH == 3 && KW == 3 && stride == 2) wgrad_launch<2, 3, 3, 16, 4>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
   else if (Cin == 16 && KH == 3 && KW == 3 && stride == 3) wgrad_launch<3, 3, 3, 16, 2>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
@@ -812,20 +925,34 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
   const float bv = bias ? bias[n] : 0.f;
   constexpr int TILES = TH * TW / 16, TPR = TW / 16;   // 16-pixel MFMA tiles of the block tile; per row
   static_assert(TILES % 2 == 0, "two tiles per wave and trip");
+  // the patch of the next block tile is fetched into registers while this one is computed
+  constexpr int NV = PH * PW * 4, NF = (NV + 255) / 256;
+  float4 pre[NF];
+  auto fetch = [&](int bt) {
+    const int img = bt / tiles_img, tloc = bt - img * tiles_img;
+    const int iy0 = (tloc / tiles_x) * TH * S - pad, ix0 = (tloc % tiles_x) * TW * S - pad;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int i = tid + 256 * f;
+      const int q = i & 3, px = (i >> 2) % PW, py = (i >> 2) / PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      pre[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NV && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        pre[f] = *reinterpret_cast<const float4*>(x + (((long)img * H + iy) * W + ix) * 16 + 4 * q);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
   for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
     const int img = bt / tiles_img, tloc = bt - img * tiles_img;
     const int oy0 = (tloc / tiles_x) * TH, ox0 = (tloc % tiles_x) * TW;
-    const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
     __syncthreads();   // everyone is done with the previous patch
-    for (int i = tid; i < PH * PW * 4; i += 256) {   // one float4 per thread and trip
-      const int q = i & 3, px = (i >> 2) % PW, py = (i >> 2) / PW;
-      const int iy = iy0 + py, ix = ix0 + px;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        v = *reinterpret_cast<const float4*>(x + (((long)img * H + iy) * W + ix) * 16 + 4 * q);
-      *reinterpret_cast<float4*>(patch + (py * PW + px) * PP + 4 * q) = v;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int i = tid + 256 * f;
+      if (i < NV) *reinterpret_cast<float4*>(patch + ((i >> 2) / PW * PW + (i >> 2) % PW) * PP + 4 * (i & 3)) = pre[f];
     }
     __syncthreads();
+    if (bt + (int)gridDim.x < ntiles) fetch(bt + gridDim.x);
     for (int t = 2 * wave; t < TILES; t += 8) {   // two independent accumulation chains per wave
       const int ty0 = t / TPR, tx0 = (t % TPR) * 16, ty1 = (t + 1) / TPR, tx1 = ((t + 1) % TPR) * 16;
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
