@@ -222,6 +222,10 @@ void ClvoTrainer::conv_fwd(const ConvL& c, const float* x, int h, int w, float* 
     launch_conv16(x, T * B, h, w, P(c.w), false, P(c.b), c.kh, c.stride, c.pad, z, st);
     return;
   }
+  if (c.cin == 2 && c.cpix == 4 && c.kh == 7 && c.kw == 7 && c.stride == 2 && c.pad == 3 && conv16_) {
+    launch_stem16(x, T * B, h, w, P(c.w), P(c.b), z, st);
+    return;
+  }
   ConvShape s;
   s.src0 = x; s.ld0 = c.cpix; s.sb0 = (long)h * w * c.cpix; s.C0 = c.cpix; s.H = h; s.W = w;
   s.KH = c.kh; s.KW = c.kw; s.stride = c.stride; s.padH = c.pad; s.padW = c.pad;

@@ -88,6 +88,8 @@ namespace atdn {
 // of the block and the input is read from an LDS halo patch with one ds_read_b128 per tap and 16-pixel tile.
 // w: OIHW [16][16][K][K]; transposed = use w[c][n][K-1-ky][K-1-kx] instead (data gradient of a convolution).
 // z[img][oy][ox][n] = bias[n] + sum x[img][oy*S - pad + ky][ox*S - pad + kx][c] * w(n, c, ky, kx)
+// the 7x7 stride-2 pad-3 stem (2 -> 16 channels) on NHWC4 input, same MFMA; w: OIHW [16][2][7][7]
+void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, const float* bias, float* z, hipStream_t st);
 void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int K, int S,
                    int pad, float* z, hipStream_t st);
 }  // namespace atdn

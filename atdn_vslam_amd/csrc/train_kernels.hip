@@ -107,32 +107,48 @@ void launch_bn_stats(const float* z, int G, long P, bool mish, float* part, hipS
   ATDN_HIP(hipGetLastError());
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int G, int nblk, double invP, double unbias,
-                                   float* __restrict__ rm, float* __restrict__ rv, float* __restrict__ mean,
-                                   float* __restrict__ rstd) {
-  const int ch = threadIdx.x;
-  if (ch >= 16) return;
+// 256 threads = 16 slices x 16 channels: a slice sums every 16th partial in double, thread ch < 16 adds the slices in order
+__device__ __forceinline__ void sum_partials2(const float* __restrict__ part_g, int nblk, double (*r)[16][16], double& s1,
+                                              double& s2) {
+  const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  double a = 0.0, b = 0.0;
+  for (int k = sl; k < nblk; k += 16) {
+    a += (double)part_g[((long)k * 2 + 0) * 16 + ch];
+    b += (double)part_g[((long)k * 2 + 1) * 16 + ch];
+  }
+  __syncthreads();   // r is reused between groups
+  r[0][sl][ch] = a; r[1][sl][ch] = b;
+  __syncthreads();
+  s1 = 0.0; s2 = 0.0;
+  if (threadIdx.x < 16)
+    for (int k = 0; k < 16; ++k) { s1 += r[0][k][ch]; s2 += r[1][k][ch]; }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int G, int nblk, double invP,
+                                                          double unbias, float* __restrict__ rm, float* __restrict__ rv,
+                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ double r[2][16][16];
+  const int ch = threadIdx.x & 15;
+  const bool lead = threadIdx.x < 16;
   float m_run = rm[ch], v_run = rv[ch];
   for (int g = 0; g < G; ++g) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      s1 += (double)part[(((long)g * nblk + b) * 2 + 0) * 16 + ch];
-      s2 += (double)part[(((long)g * nblk + b) * 2 + 1) * 16 + ch];
+    double s1, s2;
+    sum_partials2(part + (long)g * nblk * 32, nblk, r, s1, s2);
+    if (lead) {
+      const double mu = s1 * invP;
+      double var = s2 * invP - mu * mu;
+      if (var < 0.0) var = 0.0;
+      mean[g * 16 + ch] = (float)mu;
+      rstd[g * 16 + ch] = (float)(1.0 / sqrt(var + 1e-5));
+      m_run = 0.9f * m_run + 0.1f * (float)mu;                 // torch: running = (1-momentum)*running + momentum*batch
+      v_run = 0.9f * v_run + 0.1f * (float)(var * unbias);
     }
-    const double mu = s1 * invP;
-    double var = s2 * invP - mu * mu;
-    if (var < 0.0) var = 0.0;
-    mean[g * 16 + ch] = (float)mu;
-    rstd[g * 16 + ch] = (float)(1.0 / sqrt(var + 1e-5));
-    m_run = 0.9f * m_run + 0.1f * (float)mu;                 // torch: running = (1-momentum)*running + momentum*batch
-    v_run = 0.9f * v_run + 0.1f * (float)(var * unbias);
   }
-  rm[ch] = m_run;
-  rv[ch] = v_run;
+  if (lead) { rm[ch] = m_run; rv[ch] = v_run; }
 }
 void launch_bn_finalize(const float* part, int G, long P, float* running_mean, float* running_var, float* mean, float* rstd,
                         hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, st, part, G, bn_partial_blocks(P), 1.0 / (double)P,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, part, G, bn_partial_blocks(P), 1.0 / (double)P,
                      P > 1 ? (double)P / (double)(P - 1) : 1.0, running_mean, running_var, mean, rstd);
   ATDN_HIP(hipGetLastError());
 }
@@ -191,27 +207,27 @@ void launch_bn_bwd_stats(const float* dy, const float* z, int G, long P, bool mi
   ATDN_HIP(hipGetLastError());
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int G, int nblk, float* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int ch = threadIdx.x;
-  if (ch >= 16) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int G, int nblk,
+                                                              float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  __shared__ double r[2][16][16];
+  const int ch = threadIdx.x & 15;
+  const bool lead = threadIdx.x < 16;
   double tg = 0.0, tb = 0.0;
   for (int g = 0; g < G; ++g) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      s1 += (double)part[(((long)g * nblk + b) * 2 + 0) * 16 + ch];
-      s2 += (double)part[(((long)g * nblk + b) * 2 + 1) * 16 + ch];
+    double s1, s2;
+    sum_partials2(part + (long)g * nblk * 32, nblk, r, s1, s2);
+    if (lead) {
+      sums[(g * 2 + 0) * 16 + ch] = (float)s1;
+      sums[(g * 2 + 1) * 16 + ch] = (float)s2;
+      tb += s1;
+      tg += s2;
     }
-    sums[(g * 2 + 0) * 16 + ch] = (float)s1;
-    sums[(g * 2 + 1) * 16 + ch] = (float)s2;
-    tb += s1;
-    tg += s2;
   }
-  dgamma[ch] += (float)tg;
-  dbeta[ch] += (float)tb;
+  if (lead) { dgamma[ch] += (float)tg; dbeta[ch] += (float)tb; }
 }
 void launch_bn_bwd_finalize(const float* part, int G, long P, float* sums, float* dgamma, float* dbeta, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, part, G, bn_partial_blocks(P), sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, part, G, bn_partial_blocks(P), sums, dgamma, dbeta);
   ATDN_HIP(hipGetLastError());
 }
 
@@ -275,15 +291,21 @@ void launch_bn_bwd_apply(const float* dy, const float* z, int G, long P, bool mi
   ATDN_HIP(hipGetLastError());
 }
 
-__global__ void sum_partials16_kernel(const float* __restrict__ part, long rows, float* __restrict__ out) {
-  const int ch = threadIdx.x;
-  if (ch >= 16) return;
+__global__ __launch_bounds__(256) void sum_partials16_kernel(const float* __restrict__ part, long rows, float* __restrict__ out) {
+  __shared__ double r[16][16];
+  const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4;
   double s = 0.0;
-  for (long r = 0; r < rows; ++r) s += (double)part[r * 16 + ch];
-  out[ch] += (float)s;
+  for (long k = sl; k < rows; k += 16) s += (double)part[k * 16 + ch];
+  r[sl][ch] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += r[k][ch];
+    out[ch] += (float)t;
+  }
 }
 void launch_sum_partials16(const float* part, long rows, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(sum_partials16_kernel, dim3(1), dim3(64), 0, st, part, rows, out);
+  hipLaunchKernelGGL(sum_partials16_kernel, dim3(1), dim3(256), 0, st, part, rows, out);
   ATDN_HIP(hipGetLastError());
 }
 
@@ -996,6 +1018,91 @@ void conv16_launch(const float* x, int nimg, int H, int W, const float* w, bool 
   ATDN_HIP(hipGetLastError());
 }
 }  // namespace
+
+// Stem of the CLVO encoder: 7x7, stride 2, pad 3, 2 -> 16 channels on NHWC4 input (channels 2, 3 unused). A patch row in
+// LDS holds (column, channel) pairs back to back, so the 14 (kx, c) products of one kernel row of one output pixel are 14
+// consecutive floats starting at 4*px: four MFMAs per kernel row (k-slot g of MFMA j = pair index 4g + j, the last two
+// pairs carry zero weights) fed by one ds_read_b128.
+namespace {
+constexpr int ST_TH = 8, ST_TW = 64, ST_PH = (ST_TH - 1) * 2 + 7, ST_PWC = (ST_TW - 1) * 2 + 8, ST_ROWP = ST_PWC * 2;
+__global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x, int nimg, int H, int W,
+                                                     const float* __restrict__ w /*[16][2][7][7]*/,
+                                                     const float* __restrict__ bias, int Ho, int Wo, float* __restrict__ z,
+                                                     int tiles_x, int tiles_img, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float patch[ST_PH * ST_ROWP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+  float breg[7][4];
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = 4 * g + j, kx = f >> 1, c = f & 1;
+      breg[ky][j] = kx < 7 ? w[(((long)n * 2 + c) * 7 + ky) * 7 + kx] : 0.f;
+    }
+  const float bv = bias ? bias[n] : 0.f;
+  constexpr int NV = ST_PH * ST_PWC, NF = (NV + 255) / 256;
+  float2 pre[NF];
+  auto fetch = [&](int bt) {
+    const int img = bt / tiles_img, tloc = bt - img * tiles_img;
+    const int iy0 = (tloc / tiles_x) * ST_TH * 2 - 3, ix0 = (tloc % tiles_x) * ST_TW * 2 - 3;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int i = tid + 256 * f, px = i % ST_PWC, py = i / ST_PWC;
+      const int iy = iy0 + py, ix = ix0 + px;
+      pre[f] = make_float2(0.f, 0.f);
+      if (i < NV && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        pre[f] = *reinterpret_cast<const float2*>(x + (((long)img * H + iy) * W + ix) * 4);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  constexpr int TILES = ST_TH * ST_TW / 16, TPR = ST_TW / 16;
+  for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
+    const int img = bt / tiles_img, tloc = bt - img * tiles_img;
+    const int oy0 = (tloc / tiles_x) * ST_TH, ox0 = (tloc % tiles_x) * ST_TW;
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int i = tid + 256 * f;
+      if (i < NV) *reinterpret_cast<float2*>(patch + (i / ST_PWC) * ST_ROWP + (i % ST_PWC) * 2) = pre[f];
+    }
+    __syncthreads();
+    if (bt + (int)gridDim.x < ntiles) fetch(bt + gridDim.x);
+    for (int t = 2 * wave; t < TILES; t += 8) {
+      const int ty0 = t / TPR, tx0 = (t % TPR) * 16, ty1 = (t + 1) / TPR, tx1 = ((t + 1) % TPR) * 16;
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const float* b0 = patch + (ty0 * 2) * ST_ROWP + 4 * (tx0 + n) + 4 * g;   // lane & 15 = pixel of the A row
+      const float* b1 = patch + (ty1 * 2) * ST_ROWP + 4 * (tx1 + n) + 4 * g;
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const float4 a0 = *reinterpret_cast<const float4*>(b0 + ky * ST_ROWP);
+        const float4 a1 = *reinterpret_cast<const float4*>(b1 + ky * ST_ROWP);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[ky][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[ky][0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[ky][1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[ky][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[ky][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, breg[ky][2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[ky][3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, breg[ky][3], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int oya = oy0 + ty0, oxa = ox0 + tx0 + 4 * g + e, oyb = oy0 + ty1, oxb = ox0 + tx1 + 4 * g + e;
+        if (oya < Ho && oxa < Wo) z[(((long)img * Ho + oya) * Wo + oxa) * 16 + n] = acc0[e] + bv;
+        if (oyb < Ho && oxb < Wo) z[(((long)img * Ho + oyb) * Wo + oxb) * 16 + n] = acc1[e] + bv;
+      }
+    }
+  }
+}
+}  // namespace
+
+void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, const float* bias, float* z, hipStream_t st) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int tx = cdiv(Wo, ST_TW), ty = cdiv(Ho, ST_TH), ntiles = nimg * tx * ty;
+  const int grid = ntiles < 256 * 4 ? ntiles : 256 * 4;
+  hipLaunchKernelGGL(stem16_kernel, dim3(grid), dim3(256), 0, st, x4, nimg, H, W, w, bias, Ho, Wo, z, tx, tx * ty, ntiles);
+  ATDN_HIP(hipGetLastError());
+}
 
 void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int K, int S,
                    int pad, float* z, hipStream_t st) {
