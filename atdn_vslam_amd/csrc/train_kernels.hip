@@ -551,6 +551,95 @@ __global__ __launch_bounds__(256) void conv_wgrad16_mfma_kernel(const float* __r
     }
 }
 
+// Weight gradient of the stem on the auxiliary input (xn0, xn1, 1): 7x7, stride 2, pad 3, NHWC4. Two column sets per kernel
+// row: set 1 = (kx, c in {0,1}) pairs, which are 16 consecutive floats of an interleaved patch row starting at 4*px; set 2 =
+// the constant channel (a validity mask after zero padding), 8 consecutive floats starting at 2*px. Same pixel-to-k-slot
+// assignment and scratch layout as conv_wgrad16_mfma_kernel.
+constexpr int SW_R = 4, SW_PH = (SW_R - 1) * 2 + 7, SW_PWC = (WG_TW - 1) * 2 + 8, SW_XP = 144, SW_MP = 80, SW_DSP = WG_TW + 4;
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x4, int nimg, int H, int W,
+                                                              const float* __restrict__ dz, int Ho, int Wo,
+                                                              float* __restrict__ scratch, int nslots) {
+  __shared__ __attribute__((aligned(16))) float xs[SW_PH * SW_XP];
+  __shared__ __attribute__((aligned(16))) float ms[SW_PH * SW_MP];
+  __shared__ __attribute__((aligned(16))) float ds[SW_R * 16 * SW_DSP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, idx = lane & 15, g = lane >> 4;
+  wg_f32x4 acc1[7], acc2[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) { acc1[t] = wg_f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = wg_f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = tid; i < SW_PH * SW_XP; i += 256) xs[i] = 0.f;   // padding columns stay zero
+  for (int i = tid; i < SW_PH * SW_MP; i += 256) ms[i] = 0.f;
+  const int rblocks = cdiv_dev(Ho, SW_R), cblocks = cdiv_dev(Wo, WG_TW);
+  const long items = (long)nimg * rblocks * cblocks;
+  constexpr int NX = SW_PH * SW_PWC, NXF = (NX + 255) / 256, ND = SW_R * WG_TW * 4, NDF = (ND + 255) / 256;
+  float4 fx[NXF], fd[NDF];
+  auto fetch = [&](long it) {
+    const int cb0 = (int)(it % cblocks), rb = (int)((it / cblocks) % rblocks), img = (int)(it / ((long)cblocks * rblocks));
+    const int oy0 = rb * SW_R, ox0 = cb0 * WG_TW, iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+#pragma unroll
+    for (int f = 0; f < NXF; ++f) {
+      const int i = tid + 256 * f, px = i % SW_PWC, py = i / SW_PWC;
+      const int iy = iy0 + py, ix = ix0 + px;
+      fx[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        fx[f] = *reinterpret_cast<const float4*>(x4 + (((long)img * H + iy) * W + ix) * 4);
+    }
+#pragma unroll
+    for (int f = 0; f < NDF; ++f) {
+      const int i = tid + 256 * f, q = i & 3, pix = i >> 2, col = pix % WG_TW, r = pix / WG_TW;
+      const int oy = oy0 + r, ox = ox0 + col;
+      fd[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < ND && oy < Ho && ox < Wo) fd[f] = *reinterpret_cast<const float4*>(dz + (((long)img * Ho + oy) * Wo + ox) * 16 + 4 * q);
+    }
+  };
+  if ((long)blockIdx.x < items) fetch(blockIdx.x);
+  for (long it = blockIdx.x; it < items; it += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < NXF; ++f) {
+      const int i = tid + 256 * f, px = i % SW_PWC, py = i / SW_PWC;
+      if (i < NX) {
+        *reinterpret_cast<float2*>(xs + py * SW_XP + 2 * px) = make_float2(fx[f].x, fx[f].y);
+        ms[py * SW_MP + px] = fx[f].z;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < NDF; ++f) {
+      const int i = tid + 256 * f, q = i & 3, pix = i >> 2, col = pix % WG_TW, r = pix / WG_TW;
+      if (i < ND) {
+        float* d = ds + (r * 16 + 4 * q) * SW_DSP + col;
+        d[0] = fd[f].x; d[SW_DSP] = fd[f].y; d[2 * SW_DSP] = fd[f].z; d[3 * SW_DSP] = fd[f].w;
+      }
+    }
+    __syncthreads();
+    if (it + gridDim.x < items) fetch(it + gridDim.x);
+#pragma unroll 1
+    for (int grp = wave; grp < SW_R * (WG_TW / 16); grp += 4) {
+      const int r = grp / (WG_TW / 16), c0 = (grp % (WG_TW / 16)) * 16;
+      const float4 d4 = *reinterpret_cast<const float4*>(ds + (r * 16 + idx) * SW_DSP + c0 + 4 * g);
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const float* xr = xs + (r * 2 + ky) * SW_XP + 4 * (c0 + 4 * g) + idx;   // pixel 4g + j: + 4j
+        const float* mr = ms + (r * 2 + ky) * SW_MP + 2 * (c0 + 4 * g) + idx;   //              + 2j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc1[ky] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j], xr[4 * j], acc1[ky], 0, 0, 0);
+          acc2[ky] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j], mr[2 * j], acc2[ky], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D: row n = 4g + e; set 1 column idx = 2*kx + c, set 2 column idx = kx
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = 4 * g + e, slot = blockIdx.x * 4 + wave;
+      if ((idx >> 1) < 7) scratch[(long)(((ky * 7 + (idx >> 1)) * 16 + n) * 3 + (idx & 1)) * nslots + slot] = acc1[ky][e];
+      if (idx < 7) scratch[(long)(((ky * 7 + idx) * 16 + n) * 3 + 2) * nslots + slot] = acc2[ky][e];
+    }
+}
+
 // one wave per output: sum its partials, add into dW (OIHW)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ scratch, int nblk, int Cin, int KH,
                                                                 int KW, float* __restrict__ dW) {
@@ -599,6 +688,15 @@ void launch_conv_wgrad(const float* x, int Cpix, int Cin, int nimg, int H, int W
     if (KH == 3 && KW == 3 && stride == 1) return wgrad16_mfma_launch<1, 3, 8>(x, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
     if (KH == 3 && KW == 3 && stride == 2) return wgrad16_mfma_launch<2, 3, 4>(x, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
     if (KH == 1 && KW == 1 && stride == 2) return wgrad16_mfma_launch<2, 1, 4>(x, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
+  }
+  if (mfma && Cin == 3 && Cpix == 4 && KH == 7 && KW == 7 && stride == 2 && pad == 3) {
+    const long items = (long)nimg * cdiv(Ho, SW_R) * cdiv(Wo, WG_TW);
+    const int nblk = (int)std::min<long>(items, WG_MFMA_BLOCKS);
+    hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nblk), dim3(256), 0, st, x, nimg, H, W, dz, Ho, Wo, scratch, nblk * 4);
+    ATDN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(49 * 16 * 3, 4)), dim3(256), 0, st, scratch, nblk * 4, 3, 7, 7, dW);
+    ATDN_HIP(hipGetLastError());
+    return;
   }
   if (Cin == 16 && KH == 3 && KW == 3 && stride == 1) wgrad_launch<1, 3, 3, 16, 4>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
   else if (Cin == 16 && KH == 3 && KW == 3 && stride == 2) wgrad_launch<2, 3, 3, 16, 4>(x, Cpix, nimg, H, W, dz, Ho, Wo, pad, scratch, dW, st);
