@@ -57,7 +57,8 @@ class ClvoTrainer {
 
   void pack_weights(hipStream_t st);
   void conv_fwd(const ConvL& c, const float* x, int h, int w, float* z, hipStream_t st);
-  void conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w_in, int ho, int wo, float* dx, int ldd, hipStream_t st);
+  void conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w_in, int ho, int wo, float* dx, int ldd, hipStream_t st,
+                     bool accumulate = false);
   void bn_fwd(const BnL& bn, const float* z, long P, bool mish, const float* add, float* y, hipStream_t st);
   // dy -> dz (through BN and the activation); adds dgamma/dbeta; bias gradient of the producing conv into db (optional)
   void bn_bwd(const BnL& bn, const float* dy, const float* z, long P, bool mish, float* dz, float* db, hipStream_t st);

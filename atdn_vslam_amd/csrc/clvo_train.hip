@@ -235,7 +235,11 @@ void ClvoTrainer::conv_fwd(const ConvL& c, const float* x, int h, int w, float* 
 }
 
 void ClvoTrainer::conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w_in, int ho, int wo, float* dx, int ldd,
-                                hipStream_t st) {
+                                hipStream_t st, bool accumulate) {
+  if (c.cin == 16 && ldd == 16 && conv16_ && c.stride == 2) {   // no zero-stuffed map: parity classes of the output
+    launch_tconv16_s2(dz, T * B, ho, wo, P(c.w), c.kh, c.pad, h_in, w_in, accumulate, dx, st);
+    return;
+  }
   const int Hs = h_in - c.kh + 1 + 2 * c.pad, Ws = w_in - c.kw + 1 + 2 * c.pad;
   const float* src = dz;
   if (c.stride > 1) {
@@ -247,7 +251,7 @@ void ClvoTrainer::conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w
   }
   if (c.cin == 16 && ldd == 16 && conv16_) {
     ATDN_CHECK(Hs + c.kh - 1 - 2 * c.pad == h_in && Ws + c.kw - 1 - 2 * c.pad == w_in, "data-gradient geometry");
-    launch_conv16(src, T * B, Hs, Ws, P(c.w), true, nullptr, c.kh, 1, c.kh - 1 - c.pad, dx, st);
+    launch_conv16(src, T * B, Hs, Ws, P(c.w), true, nullptr, c.kh, 1, c.kh - 1 - c.pad, dx, st, accumulate);
     return;
   }
   ConvShape s;
@@ -255,6 +259,7 @@ void ClvoTrainer::conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w
   s.KH = c.kh; s.KW = c.kw; s.stride = 1; s.padH = c.kh - 1 - c.pad; s.padW = c.kw - 1 - c.pad;
   s.w = packed_.p + c.bwd_off; s.ldw = c.kh * round_up(c.kw * 16, 32); s.N = c.cin; s.nimg = T * B;
   ATDN_CHECK(conv_out(Hs, c.kh, 1, s.padH) == h_in && conv_out(Ws, c.kw, 1, s.padW) == w_in, "data-gradient geometry");
+  ATDN_CHECK(!accumulate, "conv_bwd_data: accumulation needs the 16-channel kernels");
   conv_dispatch<MODE_ROW>(s, EpiBias<ACT_NONE>{nullptr, dx, (long)h_in * w_in * ldd, ldd, 1.f}, st);
 }
 
@@ -407,8 +412,13 @@ float ClvoTrainer::forward_backward(const float* flows, const float* true_rot, c
     conv_bwd_data(r.b.conv, cur, h, w, oh, ow, t1, 16, st);                                 // t1 = dua
     bn_bwd(r.a.bn, t1, A.za.p, Pg(k + 1), true, t1, G(r.a.conv.b), st);                     // t1 = dza
     launch_conv_wgrad(xin, 16, 16, nimg, h, w, t1, h, w, 3, 3, 1, 1, wscratch_.p, G(r.a.conv.w), st);
-    conv_bwd_data(r.a.conv, t1, h, w, h, w, cur, 16, st);                                   // cur = dx through conv a
-    launch_add_inplace(cur, t2, (long)nimg * h * w * 16, st);
+    if (conv16_) {
+      conv_bwd_data(r.a.conv, t1, h, w, h, w, t2, 16, st, true);                            // t2 += dx through conv a
+      std::swap(cur, t2);
+    } else {
+      conv_bwd_data(r.a.conv, t1, h, w, h, w, cur, 16, st);                                 // cur = dx through conv a
+      launch_add_inplace(cur, t2, (long)nimg * h * w * 16, st);
+    }
   }
   bn_bwd(stem_.bn, cur, z1_.p, Pg(1), true, cur, G(stem_.conv.b), st);                      // cur = dz1
   // stem weights and the depthwise 1x1 in front of it: one weight-gradient pass on (xn0, xn1, 1), then a combine

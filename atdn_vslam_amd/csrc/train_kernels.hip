@@ -1028,7 +1028,8 @@ template <int K, int S, int TH, int TW>
 __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x, int nimg, int H, int W,
                                                      const float* __restrict__ w, int transposed,
                                                      const float* __restrict__ bias, int pad, int Ho, int Wo,
-                                                     float* __restrict__ z, int tiles_x, int tiles_img, int ntiles) {
+                                                     float* __restrict__ z, int tiles_x, int tiles_img, int ntiles,
+                                                     int accumulate) {
   constexpr int PH = (TH - 1) * S + K, PW = (TW - 1) * S + K, PP = c16_pitch(S);
   __shared__ __attribute__((aligned(16))) float patch[PH * PW * PP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1097,8 +1098,10 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int oya = oy0 + ty0, oxa = ox0 + tx0 + 4 * g + e, oyb = oy0 + ty1, oxb = ox0 + tx1 + 4 * g + e;
-        if (oya < Ho && oxa < Wo) z[(((long)img * Ho + oya) * Wo + oxa) * 16 + n] = acc0[e] + bv;
-        if (oyb < Ho && oxb < Wo) z[(((long)img * Ho + oyb) * Wo + oxb) * 16 + n] = acc1[e] + bv;
+        float* pa = z + (((long)img * Ho + oya) * Wo + oxa) * 16 + n;
+        float* pb = z + (((long)img * Ho + oyb) * Wo + oxb) * 16 + n;
+        if (oya < Ho && oxa < Wo) *pa = acc0[e] + bv + (accumulate ? *pa : 0.f);
+        if (oyb < Ho && oxb < Wo) *pb = acc1[e] + bv + (accumulate ? *pb : 0.f);
       }
     }
   }
@@ -1106,13 +1109,13 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
 
 template <int K, int S, int TH, int TW>
 void conv16_launch(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int pad,
-                   float* z, hipStream_t st) {
+                   float* z, bool accumulate, hipStream_t st) {
   const int Ho = (H + 2 * pad - K) / S + 1, Wo = (W + 2 * pad - K) / S + 1;
   const int tx = cdiv(Wo, TW), ty = cdiv(Ho, TH);
   const int ntiles = nimg * tx * ty;
   const int grid = ntiles < 256 * 3 ? ntiles : 256 * 3;   // persistent blocks: the weights are loaded into registers once
   hipLaunchKernelGGL((conv16_kernel<K, S, TH, TW>), dim3(grid), dim3(256), 0, st, x, nimg, H, W, w, transposed ? 1 : 0, bias,
-                     pad, Ho, Wo, z, tx, tx * ty, ntiles);
+                     pad, Ho, Wo, z, tx, tx * ty, ntiles, accumulate ? 1 : 0);
   ATDN_HIP(hipGetLastError());
 }
 }  // namespace
@@ -1202,13 +1205,112 @@ void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, cons
   ATDN_HIP(hipGetLastError());
 }
 
+// Data gradient of a stride-2 16 -> 16 convolution without the zero-stuffed map: dx[y][x][c] = sum over the taps whose
+// source (y + PAD - ky)/2, (x + PAD - kx)/2 is integral. Output pixels of one row and one column parity share their tap
+// list (1, 2, 2 or 4 taps for 3x3), and 16 of them read 16 consecutive dz columns, so each parity class is a small
+// stride-1 convolution on the dz patch. Wave w owns rows 2w and 2w+1 of the 8 x 64 tile (every class once).
+namespace {
+template <int K, int PAD>
+__global__ __launch_bounds__(256) void tconv16_s2_kernel(const float* __restrict__ dz, int nimg, int Ho, int Wo,
+                                                         const float* __restrict__ w, int H, int W, int accumulate,
+                                                         float* __restrict__ dx, int tiles_x, int tiles_img, int ntiles) {
+  constexpr int TH = 8, TW = 64, PH = TH / 2 + 2, PW = TW / 2 + 2;
+  __shared__ __attribute__((aligned(16))) float patch[PH * PW * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, idx = lane & 15, g = lane >> 4;
+  float breg[K * K][4];   // contraction over n: slot g of MFMA j = output channel 4g + j; column = input channel idx
+#pragma unroll
+  for (int tap = 0; tap < K * K; ++tap)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) breg[tap][j] = w[((long)(4 * g + j) * 16 + idx) * K * K + tap];
+  constexpr int NV = PH * PW * 4, NF = (NV + 255) / 256;
+  float4 pre[NF];
+  auto fetch = [&](int bt) {
+    const int img = bt / tiles_img, tloc = bt - img * tiles_img;
+    const int oyb = (tloc / tiles_x) * (TH / 2) - 1, oxb = (tloc % tiles_x) * (TW / 2) - 1;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int i = tid + 256 * f, q = i & 3, pc = (i >> 2) % PW, pr = (i >> 2) / PW;
+      const int oy = oyb + pr, ox = oxb + pc;
+      pre[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NV && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo)
+        pre[f] = *reinterpret_cast<const float4*>(dz + (((long)img * Ho + oy) * Wo + ox) * 16 + 4 * q);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
+    const int img = bt / tiles_img, tloc = bt - img * tiles_img;
+    const int y0 = (tloc / tiles_x) * TH, x0 = (tloc % tiles_x) * TW;
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int i = tid + 256 * f;
+      if (i < NV) *reinterpret_cast<float4*>(patch + (i >> 2) * 16 + 4 * (i & 3)) = pre[f];
+    }
+    __syncthreads();
+    if (bt + (int)gridDim.x < ntiles) fetch(bt + gridDim.x);
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      const int ly = 2 * wave + py, y = y0 + ly;
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          if ((py + PAD - ky) & 1) continue;
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            if ((px + PAD - kx) & 1) continue;
+            // (ly + PAD - ky)/2 and (px + PAD - kx)/2 are exact; the patch starts one dz row / column before the tile
+            const float* b = patch + ((((ly + PAD - ky) >> 1) + 1) * PW + idx + ((px + PAD - kx) >> 1) + 1) * 16 + 4 * g;
+            const float4 a0 = *reinterpret_cast<const float4*>(b);
+            const float4 a1 = *reinterpret_cast<const float4*>(b + 16 * 16);
+            const int tap = ky * K + kx;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[tap][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[tap][0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[tap][1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[tap][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[tap][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, breg[tap][2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[tap][3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, breg[tap][3], acc1, 0, 0, 0);
+          }
+        }
+        if (y < H) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int xa = x0 + 2 * (4 * g + e) + px, xb = xa + 32;
+            float* pa = dx + (((long)img * H + y) * W + xa) * 16 + idx;
+            if (xa < W) *pa = acc0[e] + (accumulate ? *pa : 0.f);
+            if (xb < W) pa[32 * 16] = acc1[e] + (accumulate ? pa[32 * 16] : 0.f);
+          }
+        }
+      }
+    }
+  }
+}
+}  // namespace
+
+void launch_tconv16_s2(const float* dz, int nimg, int Ho, int Wo, const float* w, int K, int pad, int H, int W, bool accumulate,
+                       float* dx, hipStream_t st) {
+  const int tx = cdiv(W, 64), ty = cdiv(H, 8), ntiles = nimg * tx * ty;
+  const int grid = ntiles < 256 * 4 ? ntiles : 256 * 4;
+  if (K == 3 && pad == 1)
+    hipLaunchKernelGGL((tconv16_s2_kernel<3, 1>), dim3(grid), dim3(256), 0, st, dz, nimg, Ho, Wo, w, H, W, accumulate ? 1 : 0, dx,
+                       tx, tx * ty, ntiles);
+  else if (K == 1 && pad == 0)
+    hipLaunchKernelGGL((tconv16_s2_kernel<1, 0>), dim3(grid), dim3(256), 0, st, dz, nimg, Ho, Wo, w, H, W, accumulate ? 1 : 0, dx,
+                       tx, tx * ty, ntiles);
+  else throw Error("tconv16_s2: no kernel for this shape");
+  ATDN_HIP(hipGetLastError());
+}
+
 void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int K, int S,
-                   int pad, float* z, hipStream_t st) {
-  if (K == 3 && S == 1) conv16_launch<3, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, st);
-  else if (K == 3 && S == 2) conv16_launch<3, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, st);
-  else if (K == 3 && S == 3) conv16_launch<3, 3, 2, 32>(x, nimg, H, W, w, transposed, bias, pad, z, st);
-  else if (K == 1 && S == 2) conv16_launch<1, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, st);
-  else if (K == 1 && S == 1) conv16_launch<1, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, st);
+                   int pad, float* z, hipStream_t st, bool accumulate) {
+  if (K == 3 && S == 1) conv16_launch<3, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
+  else if (K == 3 && S == 2) conv16_launch<3, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
+  else if (K == 3 && S == 3) conv16_launch<3, 3, 2, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
+  else if (K == 1 && S == 2) conv16_launch<1, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
+  else if (K == 1 && S == 1) conv16_launch<1, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
   else throw Error("conv16: no kernel for this shape");
 }
 
