@@ -80,6 +80,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
       if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) off = (unsigned)(iy * g.W + ix) + 1u;
     }
     pmeta[k] = (off << 12) | (unsigned)((py * RS + px * ROWB + 16 * s) >> 4);
+    // a row past the patch repeats this thread's first row (same data to the same address): the refresh stays
+    // branch-free, so the whole chunk body is one scheduling region
+    if (prow >= PROWS) pmeta[k] = pmeta[0];
   }
   const float* s0 = g.src0 + (long)img * g.sb0;
   const float* s1 = g.src1 ? g.src1 + (long)img * g.sb1 : nullptr;
@@ -97,8 +100,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
   auto store_patch = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NP; ++k)
-      if (r0 + RSTEP * k < PROWS)
-        *reinterpret_cast<float4*>(Pbytes + buf * PSZ + ((pmeta[k] & 0xFFFu) << 4)) = keep_if((pmeta[k] >> 12) != 0, pr[k]);
+      *reinterpret_cast<float4*>(Pbytes + buf * PSZ + ((pmeta[k] & 0xFFFu) << 4)) = keep_if((pmeta[k] >> 12) != 0, pr[k]);
   };
 
   // ---- MFMA roles
@@ -127,32 +129,39 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
     else
       wrow[j] = g.w + (long)min(n0 + (wn * TN + j) * 32 + r, g.N - 1) * g.ldw + 4 * h;
 
-  // weight fragments of the current step and of the next two (requested two steps ahead of use)
-  struct WFrag { f16x8 hi[2][TN], lo[2][TN]; };
-  WFrag w0, w1, w2;
-  auto load_w = [&](WFrag& f, int c, int tap) {
-    const int q = tap * nck + c;  // packed K order is [tap][channel chunk]
+  // Weight fragments live in a ring of R half-step slots (half-step = one 16-wide K sub-step of one tap). R divides
+  // the 2*NTAP half-steps of a chunk, so every slot index is a compile-time constant: no register rotation (copying
+  // w1 = w2 made the compiler wait for a load right after issuing it) and the load for half-step hs + R - 1 goes
+  // into the slot half-step hs - 1 just released. The chunk body is branch-free (the prefetches of the last chunk
+  // are clamped to valid, unused data), i.e. one scheduling region, and sched_group_barrier pins the interleave:
+  // one LDS read or global load behind every MFMA, reads for the NEXT half-step first.
+  constexpr int NH = 2 * NTAP;
+  constexpr int R = (NH % 5 == 0) ? 5 : (NH % 6 == 0) ? 6 : 4;
+  static_assert(NH % R == 0 && NH >= R, "ring size must divide the half-steps of a chunk");
+  struct HFrag { f16x8 hi[TN], lo[TN]; };
+  HFrag wr[R];
+  auto load_wh = [&](HFrag& f, int c, int hs) {
+    const int q = (hs >> 1) * nck + c;  // packed K order is [tap][channel chunk]
+    const int t = hs & 1;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if constexpr (FRAGW) {
-          f.hi[t][j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512);
-          f.lo[t][j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512 + 256);
-        } else {
-          f.hi[t][j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t);
-          f.lo[t][j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t + 16);
-        }
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (FRAGW) {
+        f.hi[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512);
+        f.lo[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512 + 256);
+      } else {
+        f.hi[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t);
+        f.lo[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t + 16);
       }
+    }
   };
 
   fetch_patch(0);
-  load_w(w0, 0, 0);
-  if (NTAP > 1) load_w(w1, 0, 1); else if (nck > 1) load_w(w1, 1, 0);
+#pragma unroll
+  for (int hs = 0; hs < R - 1; ++hs) load_wh(wr[hs], 0, hs);
+  if (ABL & 1) load_wh(wr[R - 1], 0, R - 1);
   store_patch(0);
   __syncthreads();
-  // activation fragments are software-pipelined at half-step granularity: while the 3*TM*TN MFMAs of K sub-step t
-  // run, the ds_reads of the next sub-step fill the other register set (set index = t)
+  // activation fragments: two register sets, the ds_reads of half-step hs + 1 are issued among the MFMAs of hs
   f16x8 ah[2][TM], al[2][TM];
   auto read_a = [&](int set, int tap, int t) {
     const char* arow = Pb + (tap / KW) * RS + (tap % KW) * ROWB;
@@ -162,51 +171,64 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
       al[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t + 64);
     }
   };
-  auto mfma_half = [&](int t) {
+  auto mfma_half = [&](int set, const HFrag& w) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (SWAP) {
           if constexpr (!FAST) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.hi[t][j], al[t][i], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.lo[t][j], ah[t][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[j], al[set][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo[j], ah[set][i], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0.hi[t][j], ah[t][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[j], ah[set][i], acc[i][j], 0, 0, 0);
         } else {
           if constexpr (!FAST) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t][i], w0.hi[t][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], w0.lo[t][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][i], w.hi[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][i], w.lo[j], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][i], w0.hi[t][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][i], w.hi[j], acc[i][j], 0, 0, 0);
         }
       }
   };
+  constexpr int NMF = (FAST ? 1 : 3) * TM * TN;   // MFMAs per half-step
   read_a(0, 0, 0);
   for (int c = 0; c < nck; ++c) {
-    const bool more = c + 1 < nck;
+    const int cn = min(c + 1, nck - 1);   // clamped: the prefetches of the last chunk fetch valid, unused data
 #pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap) {
-      if (!(ABL & 2) && tap == 0 && more) fetch_patch(c + 1);  // lands during this chunk's taps
+    for (int hs = 0; hs < NH; ++hs) {
+      // every half-step is its own scheduling region: without this fence the interleave solver moves the LDS reads
+      // of half-step hs + 1 to just before their consumers
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ABL & 2) && hs == 0) fetch_patch(cn);  // lands during this chunk's taps
       if (!(ABL & 1)) {
-        if (tap + 2 < NTAP) load_w(w2, c, tap + 2);
-        else if (more) load_w(w2, c + 1, tap + 2 - NTAP);
+        const int nhs = hs + R - 1;
+        if (nhs < NH) load_wh(wr[nhs % R], c, nhs); else load_wh(wr[nhs % R], cn, nhs - NH);
       }
-      if (!(ABL & 4)) read_a(1, tap, 1);
-      if (!(ABL & 2) && tap + 1 == NTAP && more) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
-      mfma_half(0);
-      if (!(ABL & 4) && tap + 1 < NTAP) read_a(0, tap + 1, 0);
-      mfma_half(1);
-      w0 = w1;
-      w1 = w2;
-      if (tap + 1 == NTAP && more) {  // chunk boundary: publish the next patch image (one barrier)
-        if (!(ABL & 2)) {
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          Pb = Pbytes + ((c + 1) & 1) * PSZ;
+      if (!(ABL & 4) && hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1, (hs + 1) & 1);
+      if (!(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
+      mfma_half(hs & 1, wr[hs % R]);
+      // interleave: one memory instruction behind each MFMA — LDS reads first (they feed the next half-step), then
+      // the global loads, then the patch image writes
+      {
+        constexpr int nds = 2 * TM;
+        const int nvm = 2 * TN + (hs == 0 ? NP : 0);
+        const int ndw = (hs == NH - 2) ? NP : 0;
+#pragma unroll
+        for (int k = 0; k < NMF; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (hs + 1 < NH && k < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          else if (k - ((hs + 1 < NH) ? nds : 0) < nvm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          else if (k - ((hs + 1 < NH) ? nds : 0) - nvm < ndw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
-        if (!(ABL & 4)) read_a(0, 0, 0);
       }
     }
+    // chunk boundary: publish the next patch image (one barrier)
+    if (!(ABL & 2)) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      Pb = Pbytes + ((c + 1) & 1) * PSZ;
+    }
+    if (!(ABL & 4)) read_a(0, 0, 0);
   }
 
   if constexpr ((ABL & 8) != 0) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
@@ -227,8 +249,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
     // transposed through a wave-private LDS slab first: 4 ds_write_b128 in, 4 ds_read_b128 out, after which lane l
     // owns pixel 8q + l/8, channels 4*(l%8)..+3 — 8 consecutive lanes cover one pixel's 32-channel group, and every
     // load and store of the epilogue (operands of the GRU gates included) is a whole line per pixel.
-    __shared__ __attribute__((aligned(16))) float tbuf[NW][32 * LDS_LD];
-    float* tb = tbuf[wave];
+    // The slabs reuse the patch images (dead after the main loop; one barrier before the first write), so a block's
+    // LDS footprint is the two patch images only and narrower blocks fit several to a CU: one block's epilogue then
+    // overlaps another block's main loop.
+    static_assert(NW * 32 * LDS_LD * 4 <= 2 * PSZ, "transpose slabs must fit in the patch images");
+    __syncthreads();
+    float* tb = reinterpret_cast<float*>(Pbytes) + wave * (32 * LDS_LD);
     const int trow = lane >> 3, tcol = (lane & 7) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
