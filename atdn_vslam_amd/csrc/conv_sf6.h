@@ -388,10 +388,12 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
 }
 
 
-// Picks the block width for N output channels and launches the 8x16-pixel, fragment-major-weight kernel.
-// Returns false when this path does not serve the shape (the caller falls back to generation 4).
+// Picks the block shape for N output channels and launches the fragment-major-weight kernel: 8x16-pixel tiles, or
+// 12x16 for the 64- and 96-wide blocks (3 MFMA row tiles per wave: less halo, fewer tile seams; measured
+// 7-10 % faster on the encoder shapes and on N = 192) when the taller tiles pad the image no worse and still
+// cover the chip. Returns false when this path does not serve the shape (the caller falls back to generation 4).
 template <int KH, int KW, class Epi, bool FAST>
-inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out) {
+inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out, int* th_out) {
   const int Ho = conv_out(s.H, s.KH, 1, s.padH), Wo = conv_out(s.W, s.KW, 1, s.padW);
   const long tiles = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
   // block width: the one of {256, 128, 64} that pads N least (ties: the widest, it shares the patch among more
@@ -407,8 +409,19 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   }
   // small grids: narrower blocks (more of them) until the chip is covered
   while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
+  *th_out = 8;
   if constexpr (KH == 3) {
     if (bn == 32) { *bn_out = 32; launch_conv_sf6<8, 32, 4, 1, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true; }
+    static const bool tall_ok = !(getenv("ATDN_NO_TALL_TILES") && getenv("ATDN_NO_TALL_TILES")[0] == '1');
+    const long tiles12 = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
+    const bool tall = tall_ok && (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 &&
+                      tiles12 * cdiv(s.N, bn) >= 512;
+    if (tall) {
+      *bn_out = bn; *th_out = 12;
+      if (bn == 64) launch_conv_sf6<12, 64, 2, 2, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st);
+      else launch_conv_sf6<12, 96, 2, 3, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st);
+      return true;
+    }
   }
   *bn_out = bn;
   switch (bn) {
@@ -424,7 +437,7 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
 }
 
 template <class Epi>
-inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out, bool fast) {
+inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out, int* th_out, bool fast) {
   constexpr int kinds = epi_gen6<Epi>::value;
   if (kinds == 0 || !s.wfrag || s.stride != 1) return false;
   if (epi_vec4<Epi>::value && Epi::kPrefetch && (s.N % 4) != 0) return false;
@@ -432,16 +445,16 @@ inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStr
   if (s.C0 % 32 != 0 || s.C1 % 32 != 0 || s.C0 <= 0 || s.ld0 % 4 != 0) return false;
   if constexpr ((kinds & 1) != 0) {
     if (s.KH == 3 && s.KW == 3)
-      return fast ? conv_sf6_try_shape<3, 3, Epi, true>(s, wscale, ep, st, bn_out)
-                  : conv_sf6_try_shape<3, 3, Epi, false>(s, wscale, ep, st, bn_out);
+      return fast ? conv_sf6_try_shape<3, 3, Epi, true>(s, wscale, ep, st, bn_out, th_out)
+                  : conv_sf6_try_shape<3, 3, Epi, false>(s, wscale, ep, st, bn_out, th_out);
   }
   if constexpr ((kinds & 2) != 0) {
     if (s.KH == 1 && s.KW == 5)
-      return fast ? conv_sf6_try_shape<1, 5, Epi, true>(s, wscale, ep, st, bn_out)
-                  : conv_sf6_try_shape<1, 5, Epi, false>(s, wscale, ep, st, bn_out);
+      return fast ? conv_sf6_try_shape<1, 5, Epi, true>(s, wscale, ep, st, bn_out, th_out)
+                  : conv_sf6_try_shape<1, 5, Epi, false>(s, wscale, ep, st, bn_out, th_out);
     if (s.KH == 5 && s.KW == 1)
-      return fast ? conv_sf6_try_shape<5, 1, Epi, true>(s, wscale, ep, st, bn_out)
-                  : conv_sf6_try_shape<5, 1, Epi, false>(s, wscale, ep, st, bn_out);
+      return fast ? conv_sf6_try_shape<5, 1, Epi, true>(s, wscale, ep, st, bn_out, th_out)
+                  : conv_sf6_try_shape<5, 1, Epi, false>(s, wscale, ep, st, bn_out, th_out);
   }
   return false;
 }

@@ -24,8 +24,8 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
     // of the epilogues that opt in (kGen6); everything else, and ATDN_CONV_GEN=4, stays on generation 4
     static const int gen = getenv("ATDN_CONV_GEN") ? atoi(getenv("ATDN_CONV_GEN")) : 6;
     if (gen >= 6) {
-      int bn = 0;
-      if (conv_sf6_try(s, wscale, ep, st, &bn, sf_fast_mode())) return TileChoice{128, bn, cdiv(Wo, 16) * cdiv(Ho, 8) * 4, true};
+      int bn = 0, th = 8;
+      if (conv_sf6_try(s, wscale, ep, st, &bn, &th, sf_fast_mode())) return TileChoice{th * 16, bn, cdiv(Wo, 16) * cdiv(Ho, th) * (th / 2), true};
     }
     static const int big_min = getenv("ATDN_BIG_TILE_MIN") ? atoi(getenv("ATDN_BIG_TILE_MIN")) : 224;
     const int tiles16 = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 16);

@@ -74,6 +74,59 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
   }
 }
 
+// Thin-layer variant of the ladder (encoder shapes: few chunks per tile, so prologue/epilogue weigh more): the
+// 64-channel 2x2-wave block at tile heights 8 and 12 and its ablations. us_out[8].
+extern "C" int atdn_microbench_conv_thin(int nimg, int H, int W, int C, int N, int reps, float* us_out) {
+  try {
+    hipStream_t st = nullptr;
+    const long npix = (long)nimg * H * W;
+    float *x, *wf, *y, *bias;
+    const int K = 9 * C;
+    ATDN_CHECK(C % 32 == 0 && N % 32 == 0, "microbench shapes are multiples of 32");
+    ATDN_HIP(hipMalloc(&x, npix * C * 4)); ATDN_HIP(hipMalloc(&wf, (long)N * K * 4));
+    ATDN_HIP(hipMalloc(&y, npix * N * 4)); ATDN_HIP(hipMalloc(&bias, N * 4));
+    std::vector<unsigned short> hx((size_t)npix * C * 2), hw((size_t)N * K * 2);
+    unsigned v = 12345u;
+    for (auto& e : hx) { v = v * 1664525u + 1013904223u; e = (unsigned short)(0x3000 + ((v >> 16) & 0x0FFF) + ((v >> 31) << 15)); }
+    for (auto& e : hw) { v = v * 1664525u + 1013904223u; e = (unsigned short)(0x3000 + ((v >> 16) & 0x0FFF) + ((v >> 31) << 15)); }
+    ATDN_HIP(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    ATDN_HIP(hipMemcpy(wf, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    ATDN_HIP(hipMemset(bias, 0, N * 4));
+    ConvShape s;
+    s.src0 = x; s.ld0 = C; s.sb0 = (long)H * W * C; s.C0 = C; s.H = H; s.W = W;
+    s.KH = 3; s.KW = 3; s.stride = 1; s.padH = 1; s.padW = 1;
+    s.w = wf; s.wfrag = wf; s.ldw = K; s.N = N; s.nimg = nimg;
+    using E = SfBias<ACT_RELU>;
+    E ep{bias, y, (long)H * W * N, N};
+    auto time_it = [&](auto&& go) {
+      hipEvent_t a, b;
+      ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
+      for (int i = 0; i < 2 * reps; ++i) go();
+      ATDN_HIP(hipEventRecord(a, st));
+      for (int i = 0; i < reps; ++i) go();
+      ATDN_HIP(hipEventRecord(b, st));
+      ATDN_HIP(hipEventSynchronize(b));
+      float ms = 0.f;
+      ATDN_HIP(hipEventElapsedTime(&ms, a, b));
+      (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+      return ms * 1000.f / reps;
+    };
+    us_out[0] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
+    us_out[1] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
+    us_out[2] = time_it([&]() { launch_conv_sf6<16, 64, 4, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
+    us_out[3] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 8, true>(s, 1.f, ep, st); });
+    us_out[4] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 9, true>(s, 1.f, ep, st); });
+    us_out[5] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 13, true>(s, 1.f, ep, st); });
+    us_out[6] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 15, true>(s, 1.f, ep, st); });
+    us_out[7] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 8, true>(s, 1.f, ep, st); });
+    (void)hipFree(x); (void)hipFree(wf); (void)hipFree(y); (void)hipFree(bias);
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  }
+}
+
 // ---- MFMA ceilings under DVFS: the split-f16 product pattern (3 MFMAs per operand pair) on random or zero data,
 // operands held in registers or re-read from a conflict-free LDS image every step, for both f16 MFMA shapes.
 namespace atdn {
