@@ -31,8 +31,11 @@ template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bo
 
 // ABL (diagnostic builds only, wrong results): bit0 no weight loads in the loop, bit1 no patch refresh, bit2 no LDS reads in the loop
 // FAST: plain-f16 arithmetic (precision mode 2): only the hi x hi MFMA of every product is issued
-template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
+// NIMG: patch images in LDS. 2 = a chunk boundary costs one barrier (deep pipeline, one or two blocks per CU); 1 = half the
+// LDS and two barriers per boundary, for thin layers (few chunks per tile): four blocks per CU overlap each other's
+// prologue, epilogue and barriers instead
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2>
+__global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2) ? 4 : 1)) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = TH * TW / 32 / WM, TN = BN / 32 / WN;
   static_assert(TM * WM * 32 == TH * TW && TN * WN * 32 == BN, "wave grid must tile the block");
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
   // two patch images: chunk c+1 is written (from the registers its loads landed in) during the last tap of chunk c,
   // so a chunk boundary costs one barrier, not two
   constexpr int PSZ = (TH + KH - 1) * RS;
-  __shared__ __attribute__((aligned(256))) char Pbytes[2 * PSZ];
+  static_assert(NIMG == 1 || NIMG == 2, "one or two patch images");
+  __shared__ __attribute__((aligned(256))) char Pbytes[NIMG * PSZ];
 
   const int tid = threadIdx.x;
   const int tiles_img = g.tiles_x * g.tiles_y;
@@ -136,7 +140,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
   // are clamped to valid, unused data), i.e. one scheduling region, and sched_group_barrier pins the interleave:
   // one LDS read or global load behind every MFMA, reads for the NEXT half-step first.
   constexpr int NH = 2 * NTAP;
-  constexpr int R = (NH % 5 == 0) ? 5 : (NH % 6 == 0) ? 6 : 4;
+  // (the high-occupancy single-image variant keeps the ring short: its budget is 128 registers per lane)
+  constexpr int R = (NIMG == 1 && NH % 3 == 0) ? 3 : (NH % 5 == 0) ? 5 : (NH % 6 == 0) ? 6 : 4;
   static_assert(NH % R == 0 && NH >= R, "ring size must divide the half-steps of a chunk");
   struct HFrag { f16x8 hi[TN], lo[TN]; };
   HFrag wr[R];
@@ -206,14 +211,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
         if (nhs < NH) load_wh(wr[nhs % R], c, nhs); else load_wh(wr[nhs % R], cn, nhs - NH);
       }
       if (!(ABL & 4) && hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1, (hs + 1) & 1);
-      if (!(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
+      if (NIMG == 2 && !(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
       mfma_half(hs & 1, wr[hs % R]);
       // interleave: one memory instruction behind each MFMA — LDS reads first (they feed the next half-step), then
       // the global loads, then the patch image writes
       {
         constexpr int nds = 2 * TM;
         const int nvm = 2 * TN + (hs == 0 ? NP : 0);
-        const int ndw = (hs == NH - 2) ? NP : 0;
+        const int ndw = (NIMG == 2 && hs == NH - 2) ? NP : 0;
 #pragma unroll
         for (int k = 0; k < NMF; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -226,7 +231,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
     // chunk boundary: publish the next patch image (one barrier)
     if (!(ABL & 2)) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      Pb = Pbytes + ((c + 1) & 1) * PSZ;
+      if constexpr (NIMG == 2) {
+        Pb = Pbytes + ((c + 1) & 1) * PSZ;
+      } else if (c + 1 < nck) {   // single image: every wave is done reading it; rewrite in place and publish
+        store_patch(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
     }
     if (!(ABL & 4)) read_a(0, 0, 0);
   }
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
     // The slabs reuse the patch images (dead after the main loop; one barrier before the first write), so a block's
     // LDS footprint is the two patch images only and narrower blocks fit several to a CU: one block's epilogue then
     // overlaps another block's main loop.
-    static_assert(NW * 32 * LDS_LD * 4 <= 2 * PSZ, "transpose slabs must fit in the patch images");
+    static_assert(NW * 32 * LDS_LD * 4 <= NIMG * PSZ, "transpose slabs must fit in the patch images");
     __syncthreads();
     float* tb = reinterpret_cast<float*>(Pbytes) + wave * (32 * LDS_LD);
     const int trow = lane >> 3, tcol = (lane & 7) * 4;
@@ -261,6 +271,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nb = n0 + (wn * TN + j) * 32 + tcol;
+        const float4 bj = ep.bias4(max(min(nb, g.N - 4), 0));   // this lane's 4 channels: one load per channel run
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           *reinterpret_cast<float4*>(tb + r * LDS_LD + 8 * k + 4 * h) =
@@ -285,13 +296,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
           for (int q = 0; q < 4; ++q) aux[q] = ep.load4(img, max(mq[q], 0), min(nb, g.N - 4));
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (mq[q] >= 0 && nb < g.N) ep.apply4(img, mq[q], nb, v[q], aux[q]);
+            if (mq[q] >= 0 && nb < g.N) ep.apply4(img, mq[q], nb, v[q], aux[q], bj);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             if (mq[q] < 0) continue;
             if (nb + 4 <= g.N) {
-              ep.store4(img, mq[q], nb, v[q]);
+              ep.store4(img, mq[q], nb, v[q], bj);
             } else {  // N % 4 != 0: the last run is partial, element-wise
               const float e4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_sf6_kernel(const Conv2Geom 
   }
 }
 
-template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false>
+template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2>
 inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
   constexpr int TW = 16;
   ATDN_CHECK(s.KH == KH && s.KW == KW && s.stride == 1, "kernel shape does not match the instantiation");
@@ -383,7 +394,7 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
   ATDN_CHECK(g.w != nullptr, "missing weight copy for this kernel");
   set_groups(ep, g.tiles_x * g.tiles_y * (TH * TW / 32));
   const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW, FAST>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
+  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW, FAST, NIMG>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
   ATDN_HIP(hipGetLastError());
 }
 

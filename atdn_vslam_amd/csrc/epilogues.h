@@ -23,8 +23,12 @@ struct EpiBias {
   // channel-vector form (conv_sf6.h): channels n..n+3 of pixel m; 3x3 halo kernels only
   static constexpr bool kVec4 = true;
   static constexpr int kGen6 = 1;
-  __device__ __forceinline__ void store4(int img, int m, int n, float4 a) const {
-    if (bias) { a.x += bias[n]; a.y += bias[n + 1]; a.z += bias[n + 2]; a.w += bias[n + 3]; }
+  // bias of channels n..n+3, fetched once per channel run by the kernel (see SfBias)
+  __device__ __forceinline__ float4 bias4(int n) const {
+    return bias ? make_float4(bias[n], bias[n + 1], bias[n + 2], bias[n + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void store4(int img, int m, int n, float4 a, float4 b) const {
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     if (ACT == ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
     float* d = dst + (long)img * ob + (long)m * ld + n;
     if ((ld & 3) == 0 && (ob & 3) == 0) {

@@ -22,8 +22,13 @@ struct SfBias {
   // channel-vector form (conv_sf6.h): channels n..n+3 of pixel m
   static constexpr bool kVec4 = true;
   static constexpr int kGen6 = 1;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
-  __device__ __forceinline__ void store4(int img, int m, int n, float4 a) const {
-    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + n); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+  // bias of channels n..n+3, fetched ONCE per channel run by the kernel (a load inside store4 sits between the
+  // stores of consecutive pixels and its wait, vmcnt(0), also waits for those stores)
+  __device__ __forceinline__ float4 bias4(int n) const {
+    return bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void store4(int img, int m, int n, float4 a, float4 b) const {
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     if (ACT == ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
     sf_store4(dst, (long)img * ob + (long)m * ld, n, a);
   }
@@ -46,8 +51,8 @@ struct SfBiasReluAddRelu {
   static constexpr int kGen6 = 1;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
   struct Aux4 { float4 r; };
   __device__ __forceinline__ Aux4 load4(int img, int m, int n) const { return {sf_load4(res, (long)img * rb + (long)m * ldr, n)}; }
-  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x) const {
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+  __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b) const {
     float4 o;
     o.x = fmaxf(x.r.x + fmaxf(a.x + b.x, 0.f), 0.f);
     o.y = fmaxf(x.r.y + fmaxf(a.y + b.y, 0.f), 0.f);
@@ -129,8 +134,8 @@ struct SfGruZR {
     return {sf_load4(h, (long)img * ob + (long)m * 128, n & 127),
             *reinterpret_cast<const float4*>(pre + (long)img * pb + (long)m * 256 + n)};
   }
-  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x) const {
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+  __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b) const {
     float4 v;
     v.x = sigmoidf_((a.x + x.p.x) + b.x);
     v.y = sigmoidf_((a.y + x.p.y) + b.y);
@@ -167,8 +172,8 @@ struct SfGruQ {
     const long o = (long)img * ob + (long)m * 128;
     return {sf_load4(h, o, n), *reinterpret_cast<const float4*>(z + o + n), *reinterpret_cast<const float4*>(pre + o + n)};
   }
-  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x) const {
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+  __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b) const {
     float4 o;
     o.x = (1.f - x.z.x) * x.h.x + x.z.x * tanhf((a.x + x.p.x) + b.x);
     o.y = (1.f - x.z.y) * x.h.y + x.z.y * tanhf((a.y + x.p.y) + b.y);

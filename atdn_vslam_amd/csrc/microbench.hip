@@ -75,7 +75,7 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
 }
 
 // Thin-layer variant of the ladder (encoder shapes: few chunks per tile, so prologue/epilogue weigh more): the
-// 64-channel 2x2-wave block at tile heights 8 and 12 and its ablations. us_out[8].
+// 64-channel 2x2-wave block at tile heights 8 and 12, its ablations, and the single-patch-image variants. us_out[10].
 extern "C" int atdn_microbench_conv_thin(int nimg, int H, int W, int C, int N, int reps, float* us_out) {
   try {
     hipStream_t st = nullptr;
@@ -114,6 +114,8 @@ extern "C" int atdn_microbench_conv_thin(int nimg, int H, int W, int C, int N, i
     us_out[0] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
     us_out[1] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
     us_out[2] = time_it([&]() { launch_conv_sf6<16, 64, 4, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
+    us_out[8] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 0, true, false, 1>(s, 1.f, ep, st); });
+    us_out[9] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true, false, 1>(s, 1.f, ep, st); });
     us_out[3] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 8, true>(s, 1.f, ep, st); });
     us_out[4] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 9, true>(s, 1.f, ep, st); });
     us_out[5] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 13, true>(s, 1.f, ep, st); });

@@ -7,9 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 from atdn_vslam_amd import _lib
 L = C.CDLL(_lib.LIB_PATH)
-out = (C.c_float * 8)()
+out = (C.c_float * 10)()
 names = ["8x16 px x 64 ch (2x2 waves)", "12x16 px x 64 ch (2x2 waves)", "16x16 px x 64 ch (4x2 waves)", "  8x16 minus epilogue",
-         "  ... minus weight loads", "  ... minus LDS reads", "  ... minus patch refresh (bare MFMA)", "  12x16 minus epilogue"]
+         "  ... minus weight loads", "  ... minus LDS reads", "  ... minus patch refresh (bare MFMA)", "  12x16 minus epilogue",
+         "8x16 px x 64 ch, one patch image", "12x16 px x 64 ch, one patch image"]
 for (nimg, H, W, Cc, N) in ((8, 188, 616, 64, 64), (8, 94, 308, 96, 96), (8, 47, 154, 128, 128), (8, 47, 154, 256, 192)):
     torch.cuda.synchronize()
     rc = L.atdn_microbench_conv_thin(nimg, H, W, Cc, N, 30, out)
