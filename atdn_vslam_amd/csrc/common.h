@@ -1,5 +1,6 @@
 // Shared host/device helpers for libatdn_hip (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -37,6 +38,10 @@ struct Error : std::runtime_error {
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// epilogues that take their per-column constants as an argument (struct Col, col(n), store_c)
+template <class E, class = void> struct epi_bias_arg : std::false_type {};
+template <class E> struct epi_bias_arg<E, std::void_t<typename E::Col>> : std::true_type {};
 
 // Bijective XCD-aware remap of a 1-D block id: blocks that land on the same XCD
 // (observed round-robin: id % 8) receive a contiguous range of logical ids, so

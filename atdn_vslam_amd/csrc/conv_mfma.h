@@ -235,6 +235,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
             const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (m < HoWo) ep.apply(img, m, n, acc[i][j][e], aux[e]);
           }
+        } else if constexpr (epi_bias_arg<Epi>::value) {
+          const typename Epi::Col cn = ep.col(n);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < HoWo) ep.store_c(img, m, n, acc[i][j][e], cn);
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {

@@ -364,6 +364,11 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
 #pragma unroll
           for (int e = 0; e < 16; ++e)
             if (mm[e] >= 0) ep.apply(img, mm[e], n, acc[i][j][e] * g.wscale, aux[e]);
+        } else if constexpr (epi_bias_arg<Epi>::value) {
+          const typename Epi::Col cn = ep.col(n);
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (mm[e] >= 0) ep.store_c(img, mm[e], n, acc[i][j][e] * g.wscale, cn);
         } else {
 #pragma unroll
           for (int e = 0; e < 16; ++e)

@@ -1,6 +1,7 @@
 // Fused epilogues of the implicit-GEMM engine: called once per valid output
 // element as ep(img, pix, n, acc). All tensors NHWC; `ob` = per-image stride.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace atdn {
@@ -15,8 +16,12 @@ struct EpiBias {
   const float* bias;  // may be null
   float* dst; long ob; int ld;
   float scale;        // applied after bias (mask head: 0.25), 1 otherwise
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    float v = a + (bias ? bias[n] : 0.f);
+  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const { store_c(img, m, n, a, col(n)); }
+  // element form with the per-column constants passed in (fetched once per output column by the kernel, see SfBias)
+  struct Col { float b; };
+  __device__ __forceinline__ Col col(int n) const { return {bias ? bias[n] : 0.f}; }
+  __device__ __forceinline__ void store_c(int img, int m, int n, float a, Col c) const {
+    float v = a + c.b;
     if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
     dst[(long)img * ob + (long)m * ld + n] = v * scale;
   }
@@ -194,8 +199,11 @@ struct EpiMishBN {
   static constexpr bool kPrefetch = false;
   const float* bias; const float* sc; const float* sh;
   float* dst; long ob; int ld;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    dst[(long)img * ob + (long)m * ld + n] = mishf_(a + bias[n]) * sc[n] + sh[n];
+  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const { store_c(img, m, n, a, col(n)); }
+  struct Col { float b, sc, sh; };
+  __device__ __forceinline__ Col col(int n) const { return {bias[n], sc[n], sh[n]}; }
+  __device__ __forceinline__ void store_c(int img, int m, int n, float a, Col c) const {
+    dst[(long)img * ob + (long)m * ld + n] = mishf_(a + c.b) * c.sc + c.sh;
   }
 };
 

@@ -14,8 +14,13 @@ struct SfBias {
   static constexpr bool kPrefetch = false;
   const float* bias;  // may be null
   float* dst; long ob; int ld;
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    float v = a + (bias ? bias[n] : 0.f);
+  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const { store_c(img, m, n, a, col(n)); }
+  // element form with the per-column constants passed in: kernels fetch col(n) once per output column instead of
+  // once per element (a load between the stores of consecutive rows makes each row wait for the previous row's stores)
+  struct Col { float b; };
+  __device__ __forceinline__ Col col(int n) const { return {bias ? bias[n] : 0.f}; }
+  __device__ __forceinline__ void store_c(int img, int m, int n, float a, Col c) const {
+    float v = a + c.b;
     if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
     sf_store(dst, (long)img * ob + (long)m * ld, n, v);
   }
