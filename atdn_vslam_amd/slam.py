@@ -9,9 +9,10 @@ replaced by the HIP modules of this package:
 * relocalization mode (`neural_slam.py:355-399`): MappingVAE embedding of the query, nearest keyframe embedding,
   flow-based refinement against that keyframe's stored frame.
 
-Not on this path: training the MappingVAE at the end of odometry (`__create_map`, 50 epochs of AdamW on stock
-PyTorch). `end_odometry()` persists the keyframe poses like the reference and then needs trained weights
-(`mapping_weights=` or `<keyframes_path>/MappingVAE_weights.pth`) to enter relocalization.
+`end_odometry()` persists the keyframe poses like the reference and then creates the map: with trained weights at hand
+(`mapping_weights=` or `<keyframes_path>/MappingVAE_weights.pth`) it loads them, otherwise it trains the MappingVAE on
+the keyframes (`mapping.create_map`, the reference's `__create_map`: 50 epochs of AdamW on stock PyTorch, a one-off per
+mapping run) — then every keyframe is embedded on the HIP path and the state machine enters relocalization.
 """
 import copy
 import glob
@@ -68,14 +69,16 @@ class NeuralSLAM:
 
     args: object with `.device` and `.keyframes_path` (the reference's `Arguments`).
     odometry_weights / flow_weights / mapping_weights: checkpoint path or state dict. `flow_weights` defaults to the
-    path the reference's `GMA_Parameters` names.
+    path the reference's `GMA_Parameters` names. `map_options`: keyword arguments for `mapping.create_map` when
+    `end_odometry()` has to train the map itself.
     """
 
     FLOW_CHECKPOINT = "atdn_vslam/checkpoints/gma-kitti.pth"  # utils/gma_parameters.py
 
     def __init__(self, args, odometry_weights=None, start_mode=None, flow_weights=None, mapping_weights=None,
-                 precision=None):
+                 precision=None, map_options=None):
         self._args = args
+        self._map_options = dict(map_options or {})   # keyword arguments of mapping.create_map (e.g. num_epochs)
         self._base = args.keyframes_path
         self._device = torch.device(args.device if getattr(args, "device", None) not in (None, "cpu") else "cuda:0")
         self._flow_net = RAFTGMA(max_batch=1, precision=precision)
@@ -127,10 +130,11 @@ class NeuralSLAM:
             if mapping_weights is None and os.path.exists(default):
                 mapping_weights = default
             if mapping_weights is None:
-                raise RuntimeError(
-                    "keyframe poses saved; training the MappingVAE (neural_slam.py:286-352, stock PyTorch) is not part "
-                    "of the MI355X path: train it on %s, then call end_odometry(mapping_weights=...) or start with "
-                    "start_mode='relocalization'" % self._base)
+                # map creation (neural_slam.py:305-352): the auto-encoder is trained on the keyframes with stock
+                # PyTorch, as in the reference; the embedding it yields runs on the HIP path again
+                from .mapping import create_map
+                create_map(self._base, device=self._device, **self._map_options)
+                mapping_weights = default
             self._set_mapping_net(mapping_weights)
             for kf in self._keyframes:
                 kf.embedding = self._embed(torch.load(kf.rgb_file_name))

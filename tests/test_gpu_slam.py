@@ -85,8 +85,9 @@ def test_neuralslam_odometry_mode_matches_reference(golden_dir, gsd, hsd, tmp_pa
     first = torch.load(os.path.join(kf, "rgb", "000000.pth"))
     assert first.dtype == torch.uint8 and tuple(first.shape) == (3, 376, 1232)
     assert torch.equal(slam[0].pose, torch.eye(4)) and slam.get_keyframe(0).rgb_file_name.endswith("000000.pth")
-    # no trained MappingVAE: poses are persisted, the state machine stops in "mapping" with a clear error
-    with pytest.raises(RuntimeError, match="MappingVAE"):
+    # no trained MappingVAE and fewer keyframes than one training batch: poses are persisted, map creation refuses
+    # (the reference divides by zero there), the state machine stays in "mapping"
+    with pytest.raises(RuntimeError, match="at least 16 keyframes"):
         slam.end_odometry()
     assert slam.mode() == "mapping"
     saved = torch.load(os.path.join(kf, "poses.pth"))
@@ -119,3 +120,43 @@ def test_neuralslam_relocalization_matches_reference(golden_dir, gsd, hsd, vsd, 
         assert int(torch.argmin(dist)) == int(np.argmin(g[name + "_distances"]))
         np.testing.assert_allclose(init.numpy(), g[name + "_initial"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(refined.numpy(), g[name + "_refined"], rtol=0, atol=5e-5)
+
+
+def test_neuralslam_creates_its_map_and_relocalizes(gsd, hsd, tmp_path):
+    """BASELINE config 5 end to end: a keyframe directory as odometry leaves it, `start_mode="mapping"` -> the
+    MappingVAE is trained on the keyframes (stock PyTorch, two epochs here), every keyframe is embedded on the HIP
+    path and queries relocalise. The HIP embedding of the trained weights must agree with the torch module that was
+    trained."""
+    from atdn_vslam_amd import mapping
+    from atdn_vslam_amd.slam import NeuralSLAM
+    frames = torch.from_numpy(syn.make_frames(16, 376, 1232, seed=77))
+    kf = os.path.join(str(tmp_path), "kf")
+    os.makedirs(os.path.join(kf, "rgb"))
+    poses = torch.eye(4).flatten()[:12].repeat(16, 1)
+    poses[:, 3] = torch.arange(16, dtype=torch.float32)       # x translation = keyframe index
+    for i in range(16):
+        torch.save(frames[i].byte(), os.path.join(kf, "rgb", "%06d.pth" % i))
+    torch.save(poses, os.path.join(kf, "poses.pth"))
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))   # mapping_loss.pth goes to the working directory, as in the reference
+    try:
+        torch.manual_seed(11)
+        slam = NeuralSLAM(_Args(kf), odometry_weights=hsd, flow_weights=gsd, start_mode="mapping",
+                          map_options={"num_epochs": 2, "miopen": False})
+    finally:
+        os.chdir(cwd)
+    assert slam.mode() == "relocalization" and len(slam) == 16
+    assert os.path.exists(os.path.join(kf, "MappingVAE_weights.pth"))
+    assert list(torch.load(os.path.join(str(tmp_path), "mapping_loss.pth")).shape) == [2]
+    # the torch module with the trained weights, eval mode, against the HIP embedding stored on the keyframes
+    net = mapping.MappingVAENet()
+    net.load_state_dict(torch.load(os.path.join(kf, "MappingVAE_weights.pth")))
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        mu = net(frames[5:6].byte().float().to(DEV))[0]
+    emb = slam[5].embedding
+    scale = float(mu.abs().max())
+    assert float((emb.to(DEV) - mu).abs().max()) < 2e-3 * max(scale, 1.0)
+    init, refined, dist = slam(frames[5].byte().float())
+    assert int(torch.argmin(dist)) == 5 and float(dist[5]) < 1e-3 * max(scale, 1.0)
+    assert torch.equal(init, slam[5].pose) and float(init[0, 3]) == 5.0
