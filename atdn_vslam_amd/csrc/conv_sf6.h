@@ -423,6 +423,8 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
     for (int c : {128, 256})
       if (cdiv(s.N, c) * c <= best) { best = cdiv(s.N, c) * c; bn = c; }
   }
+  static const int cap = getenv("ATDN_SF6_MAX_BN") ? atoi(getenv("ATDN_SF6_MAX_BN")) : 256;   // diagnostic: widest block
+  while (bn > cap && bn > 64 && bn != 96) bn /= 2;
   // small grids: narrower blocks (more of them) until the chip is covered
   while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
   *th_out = 8;

@@ -1,4 +1,4 @@
-"""Prints the per-stage error of the HIP path against the CPU oracle (run on the GPU box).
+"""Test infrastructure (may use oracle/): prints the per-stage error of the HIP path against the CPU oracle (run on the GPU box).
 Used to calibrate the tolerances stated in tests/test_gpu_parity.py and DESIGN.md."""
 import os
 import sys
@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repository root
 sys.path.insert(0, ROOT)
 from atdn_vslam_amd import synthetic as syn  # noqa: E402
 from atdn_vslam_amd.modules import ATDNVO, RAFTGMA  # noqa: E402

@@ -4,7 +4,7 @@ size-independent properties at full KITTI size.
 
 Stated tolerances of the fp32-MFMA path: flow_low <= 2e-4 px, flow_up <= 1e-3 px
 (flows of up to ~75 px), pose <= 1e-5; intermediate activations <= 1e-4 absolute (values of O(1)-O(25)).
-Measured (tools/parity_report.py, MI355X): flow_up 1.6e-4 px max / 1.2e-5 mean at 376x1232 after 12
+Measured (tests/parity_report.py, MI355X): flow_up 1.6e-4 px max / 1.2e-5 mean at 376x1232 after 12
 iterations, against 8.8e-5 px between 1- and 8-thread runs of the CPU path itself."""
 import ctypes as C
 import os
