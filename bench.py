@@ -236,7 +236,7 @@ def main():
                        "peak_GBps": PEAK_HBM_GBS},
             "stages_ms_per_forward": {k: round(v, 4) for k, v in st.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(gsd, hsd, resize_frames(raw[:6]))
         print(json.dumps(out))
     if world > 1:
