@@ -22,8 +22,12 @@ class ClvoNet {
   int H, W, maxB;
 
  private:
-  struct ConvBN { PackedConv conv; long sc_off = -1, sh_off = -1; const float* sc = nullptr; const float* sh = nullptr; };
-  struct Res { ConvBN a, b; PackedConv skip; long sc_off = -1, sh_off = -1; const float* sc = nullptr; const float* sh = nullptr; };
+  // raw_*: the layer's OIHW weights and bias as the state dict holds them, for the 16x16x4 MFMA kernels (conv16)
+  struct ConvBN { PackedConv conv; long sc_off = -1, sh_off = -1; const float* sc = nullptr; const float* sh = nullptr;
+                  long raw_w_off = -1, raw_b_off = -1; const float* raw_w = nullptr; const float* raw_b = nullptr; };
+  struct Res { ConvBN a, b; PackedConv skip; long sc_off = -1, sh_off = -1; const float* sc = nullptr; const float* sh = nullptr;
+               long skip_w_off = -1, skip_b_off = -1; const float* skip_w = nullptr; const float* skip_b = nullptr; };
+  bool conv16_ = true;   // ATDN_CLVO_CONV16=0: the 32x32x2 implicit-GEMM engine (earlier path, kept for comparison)
   ConvBN pack_convbn(const std::string& p);
 
   StateDict sd_;

@@ -1,6 +1,8 @@
 // CLVO pose head on MI355X. Reference: atdn_vslam/odometry/network.py:63-73,122-146;
 // layers/conv.py:36-37,83-90; layers/linear.py:35-42; utils/normalizations.py:8-10.
 #include "clvo.h"
+#include "train_kernels.h"
+#include <cstdlib>
 
 namespace atdn {
 
@@ -35,6 +37,8 @@ ClvoNet::ConvBN ClvoNet::pack_convbn(const std::string& p) {
   std::vector<float> sc(a.scale.begin(), a.scale.end()), sh(a.shift.begin(), a.shift.end());
   c.sc_off = pack_vector(arena_, sc);
   c.sh_off = pack_vector(arena_, sh);
+  c.raw_w_off = pack_vector(arena_, sd_.get(p + ".conv.weight").data);
+  c.raw_b_off = pack_vector(arena_, sd_.get(p + ".conv.bias").data);
   return c;
 }
 
@@ -59,6 +63,8 @@ void ClvoNet::finalize() {
     res_[i].a = pack_convbn(p + ".conv.0");
     res_[i].b = pack_convbn(p + ".conv.1");
     res_[i].skip = pack_conv(arena_, sd_, {p + ".skip_layer"}, MODE_ROW, 16);
+    res_[i].skip_w_off = pack_vector(arena_, sd_.get(p + ".skip_layer.weight").data);
+    res_[i].skip_b_off = pack_vector(arena_, sd_.get(p + ".skip_layer.bias").data);
     ChannelAffine a = bn_affine(sd_, p + ".out_block.1");
     std::vector<float> sc(a.scale.begin(), a.scale.end()), sh(a.shift.begin(), a.shift.end());
     res_[i].sc_off = pack_vector(arena_, sc);
@@ -84,9 +90,16 @@ void ClvoNet::finalize() {
     L[2] = pack_linear(p + ".2.weight", "");
   }
   arena_.upload();
-  auto fix = [&](ConvBN& c) { resolve(arena_, c.conv); c.sc = arena_.dev(c.sc_off); c.sh = arena_.dev(c.sh_off); };
+  auto fix = [&](ConvBN& c) {
+    resolve(arena_, c.conv); c.sc = arena_.dev(c.sc_off); c.sh = arena_.dev(c.sh_off);
+    c.raw_w = arena_.dev(c.raw_w_off); c.raw_b = arena_.dev(c.raw_b_off);
+  };
   fix(stem_); fix(last_);
-  for (auto& r : res_) { fix(r.a); fix(r.b); resolve(arena_, r.skip); r.sc = arena_.dev(r.sc_off); r.sh = arena_.dev(r.sh_off); }
+  for (auto& r : res_) {
+    fix(r.a); fix(r.b); resolve(arena_, r.skip); r.sc = arena_.dev(r.sc_off); r.sh = arena_.dev(r.sh_off);
+    r.skip_w = arena_.dev(r.skip_w_off); r.skip_b = arena_.dev(r.skip_b_off);
+  }
+  conv16_ = !(getenv("ATDN_CLVO_CONV16") && getenv("ATDN_CLVO_CONV16")[0] == '0');
   for (Lin* l : {&fc_, &lstm1_ih_, &lstm1_hh_, &lstm_lin_, &lstm2_ih_, &lstm2_hh_, &rot_[0], &rot_[1], &rot_[2],
                  &tr_[0], &tr_[1], &tr_[2]}) {
     l->w = arena_.dev(l->w_off);
@@ -116,6 +129,27 @@ void ClvoNet::encode(const float* flow, int B, float* feat, hipStream_t st) {
   };
   int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
   float* x = bufA_.p; float* t = bufB_.p;
+  if (conv16_) {
+    // every layer after the depthwise 1x1 is 16 channels wide: the 16x16x4 fp32 MFMA kernels (train_kernels.hip) hold
+    // the whole weight tensor in operand registers and their N tile is exactly 16 columns — a 32x32x2 tile is a quarter
+    // full on these layers. Eval-mode BatchNorm/Mish (and the residual tail) are fused into the store.
+    Conv16Tail ts; ts.sc = stem_.sc; ts.sh = stem_.sh;
+    launch_stem16(in4_.p, B, H, W, stem_.raw_w, stem_.raw_b, x, st, &ts);
+    for (int i = 0; i < 4; ++i) {
+      const Res& r = res_[i];
+      const int oh = conv_out(h, 3, 2, 1), ow = conv_out(w, 3, 2, 1);
+      Conv16Tail ta; ta.sc = r.a.sc; ta.sh = r.a.sh;
+      launch_conv16_eval(x, B, h, w, r.a.raw_w, r.a.raw_b, 3, 1, 1, ta, t, st);
+      launch_conv16(x, B, h, w, r.skip_w, false, r.skip_b, 1, 2, 0, bufS_.p, st);
+      Conv16Tail tb; tb.sc = r.b.sc; tb.sh = r.b.sh; tb.skip = bufS_.p; tb.sc2 = r.sc; tb.sh2 = r.sh;
+      launch_conv16_eval(t, B, h, w, r.b.raw_w, r.b.raw_b, 3, 2, 1, tb, x, st);   // x is dead after the skip conv
+      h = oh; w = ow;
+    }
+    Conv16Tail tl; tl.sc = last_.sc; tl.sh = last_.sh;
+    launch_conv16_eval(x, B, h, w, last_.raw_w, last_.raw_b, 3, 3, 0, tl, flat_.p, st);
+    launch_linear(fc_.w, flat_.p, 832, 832, nullptr, nullptr, 0, 0, fc_.b, nullptr, 1, feat, 512, 512, B, st);
+    return;
+  }
   conv_dispatch<MODE_ROW>(shape(stem_.conv, in4_.p, H, W, 2, 3),
                           EpiMishBN{stem_.conv.b, stem_.sc, stem_.sh, x, (long)h * w * 16, 16}, st);
   for (int i = 0; i < 4; ++i) {

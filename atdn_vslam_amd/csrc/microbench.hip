@@ -56,6 +56,7 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
     us_out[0] = ATDN_MB_SF6(256, 1, 8, 0);
     us_out[1] = ATDN_MB_SF6(128, 1, 4, 0);
     us_out[2] = ATDN_MB_SF6(64, 2, 2, 0);
+    if (getenv("ATDN_MB_WIDE_WAVE")) us_out[1] = ATDN_MB_SF6(256, 1, 4, 0);   // diagnostic: 128 px x 64 ch per wave, one wave per SIMD
     us_out[3] = ATDN_MB_SF6(256, 1, 8, 8);    // no epilogue
     us_out[4] = ATDN_MB_SF6(256, 1, 8, 9);    // ... and no weight loads in the loop
     us_out[5] = ATDN_MB_SF6(256, 1, 8, 13);   // ... and no LDS reads in the loop

@@ -89,11 +89,21 @@ namespace atdn {
 // w: OIHW [16][16][K][K]; transposed = use w[c][n][K-1-ky][K-1-kx] instead (data gradient of a convolution).
 // z[img][oy][ox][n] = bias[n] + sum x[img][oy*S - pad + ky][ox*S - pad + kx][c] * w(n, c, ky, kx)
 // the 7x7 stride-2 pad-3 stem (2 -> 16 channels) on NHWC4 input, same MFMA; w: OIHW [16][2][7][7]
-void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, const float* bias, float* z, hipStream_t st);
+// eval-mode tail fused into the store (inference head): BN(Mish(.)) with the folded affine sc/sh, and with `skip`
+// ([nimg][Ho][Wo][16]) the ResidualConv tail BN2(Mish(BN1(Mish(.)) + skip))
+struct Conv16Tail {
+  const float* sc = nullptr; const float* sh = nullptr;
+  const float* skip = nullptr; const float* sc2 = nullptr; const float* sh2 = nullptr;
+};
+void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, const float* bias, float* z, hipStream_t st,
+                   const Conv16Tail* tail = nullptr);
 // data gradient of a stride-2 16 -> 16 convolution (w OIHW, K = 3 pad 1 or K = 1 pad 0): dx [nimg][H][W][16] from
 // dz [nimg][Ho][Wo][16]; accumulate: dx += instead of dx =
 void launch_tconv16_s2(const float* dz, int nimg, int Ho, int Wo, const float* w, int K, int pad, int H, int W, bool accumulate,
                        float* dx, hipStream_t st);
 void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int K, int S,
                    int pad, float* z, hipStream_t st, bool accumulate = false);   // accumulate: z += instead of z =
+// the same convolution with an eval-mode tail: K = 3 with S = 1 or 3 (Conv blocks), K = 3, S = 2 with tail.skip (ResidualConv)
+void launch_conv16_eval(const float* x, int nimg, int H, int W, const float* w, const float* bias, int K, int S, int pad,
+                        const Conv16Tail& tail, float* z, hipStream_t st);
 }  // namespace atdn

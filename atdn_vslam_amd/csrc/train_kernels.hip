@@ -1022,14 +1022,33 @@ namespace {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int c16_pitch(int S) { return S == 1 ? 16 : S == 2 ? 20 : 24; }   // floats per patch pixel: conflict-free b128 reads
 
+// Eval-mode tail of a CLVO block fused into the store (inference head, clvo.hip): TAIL 0 = none (z = acc + bias: the
+// training forward, whose BatchNorm needs batch statistics first), 1 = BN(Mish(.)) with the folded affine, 2 = the
+// ResidualConv tail BN2(Mish(BN1(Mish(.)) + skip)). Per-channel constants live in registers (channel = lane & 15).
+struct C16Consts { float sc, sh, sc2, sh2; };
+template <int TAIL>
+__device__ __forceinline__ C16Consts c16_consts(const Conv16Tail& t, int n) {
+  C16Consts c{1.f, 0.f, 1.f, 0.f};
+  if constexpr (TAIL >= 1) { c.sc = t.sc[n]; c.sh = t.sh[n]; }
+  if constexpr (TAIL == 2) { c.sc2 = t.sc2[n]; c.sh2 = t.sh2[n]; }
+  return c;
+}
+template <int TAIL>
+__device__ __forceinline__ float c16_tail(float v, const C16Consts& c, const float* skip, long o) {
+  if constexpr (TAIL == 0) return v;
+  const float y = mishf_(v) * c.sc + c.sh;
+  if constexpr (TAIL == 1) return y;
+  return mishf_(y + skip[o]) * c.sc2 + c.sh2;
+}
+
 // K operand order: MFMA (tap, j) holds channel 4g + j in k-slot g = lane >> 4, so a lane's float4 (channels 4g..4g+3 of
 // its pixel) feeds the four MFMAs of a tap component by component.
-template <int K, int S, int TH, int TW>
+template <int K, int S, int TH, int TW, int TAIL = 0>
 __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x, int nimg, int H, int W,
                                                      const float* __restrict__ w, int transposed,
                                                      const float* __restrict__ bias, int pad, int Ho, int Wo,
                                                      float* __restrict__ z, int tiles_x, int tiles_img, int ntiles,
-                                                     int accumulate) {
+                                                     int accumulate, const Conv16Tail tail) {
   constexpr int PH = (TH - 1) * S + K, PW = (TW - 1) * S + K, PP = c16_pitch(S);
   __shared__ __attribute__((aligned(16))) float patch[PH * PW * PP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1044,6 +1063,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
       breg[tap][j] = transposed ? w[((long)c * 16 + n) * K * K + (K * K - 1 - tap)] : w[((long)n * 16 + c) * K * K + tap];
     }
   const float bv = bias ? bias[n] : 0.f;
+  const C16Consts cc = c16_consts<TAIL>(tail, n);
   constexpr int TILES = TH * TW / 16, TPR = TW / 16;   // 16-pixel MFMA tiles of the block tile; per row
   static_assert(TILES % 2 == 0, "two tiles per wave and trip");
   // the patch of the next block tile is fetched into registers while this one is computed
@@ -1098,24 +1118,30 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int oya = oy0 + ty0, oxa = ox0 + tx0 + 4 * g + e, oyb = oy0 + ty1, oxb = ox0 + tx1 + 4 * g + e;
-        float* pa = z + (((long)img * Ho + oya) * Wo + oxa) * 16 + n;
-        float* pb = z + (((long)img * Ho + oyb) * Wo + oxb) * 16 + n;
-        if (oya < Ho && oxa < Wo) *pa = acc0[e] + bv + (accumulate ? *pa : 0.f);
-        if (oyb < Ho && oxb < Wo) *pb = acc1[e] + bv + (accumulate ? *pb : 0.f);
+        const long oa = (((long)img * Ho + oya) * Wo + oxa) * 16 + n, ob = (((long)img * Ho + oyb) * Wo + oxb) * 16 + n;
+        float* pa = z + oa;
+        float* pb = z + ob;
+        if constexpr (TAIL == 0) {
+          if (oya < Ho && oxa < Wo) *pa = acc0[e] + bv + (accumulate ? *pa : 0.f);
+          if (oyb < Ho && oxb < Wo) *pb = acc1[e] + bv + (accumulate ? *pb : 0.f);
+        } else {
+          if (oya < Ho && oxa < Wo) *pa = c16_tail<TAIL>(acc0[e] + bv, cc, tail.skip, oa);
+          if (oyb < Ho && oxb < Wo) *pb = c16_tail<TAIL>(acc1[e] + bv, cc, tail.skip, ob);
+        }
       }
     }
   }
 }
 
-template <int K, int S, int TH, int TW>
+template <int K, int S, int TH, int TW, int TAIL = 0>
 void conv16_launch(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int pad,
-                   float* z, bool accumulate, hipStream_t st) {
+                   float* z, bool accumulate, hipStream_t st, const Conv16Tail& tail = Conv16Tail{}) {
   const int Ho = (H + 2 * pad - K) / S + 1, Wo = (W + 2 * pad - K) / S + 1;
   const int tx = cdiv(Wo, TW), ty = cdiv(Ho, TH);
   const int ntiles = nimg * tx * ty;
   const int grid = ntiles < 256 * 3 ? ntiles : 256 * 3;   // persistent blocks: the weights are loaded into registers once
-  hipLaunchKernelGGL((conv16_kernel<K, S, TH, TW>), dim3(grid), dim3(256), 0, st, x, nimg, H, W, w, transposed ? 1 : 0, bias,
-                     pad, Ho, Wo, z, tx, tx * ty, ntiles, accumulate ? 1 : 0);
+  hipLaunchKernelGGL((conv16_kernel<K, S, TH, TW, TAIL>), dim3(grid), dim3(256), 0, st, x, nimg, H, W, w, transposed ? 1 : 0, bias,
+                     pad, Ho, Wo, z, tx, tx * ty, ntiles, accumulate ? 1 : 0, tail);
   ATDN_HIP(hipGetLastError());
 }
 }  // namespace
@@ -1126,10 +1152,11 @@ void conv16_launch(const float* x, int nimg, int H, int W, const float* w, bool 
 // pairs carry zero weights) fed by one ds_read_b128.
 namespace {
 constexpr int ST_TH = 8, ST_TW = 64, ST_PH = (ST_TH - 1) * 2 + 7, ST_PWC = (ST_TW - 1) * 2 + 8, ST_ROWP = ST_PWC * 2;
+template <int TAIL>
 __global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x, int nimg, int H, int W,
                                                      const float* __restrict__ w /*[16][2][7][7]*/,
                                                      const float* __restrict__ bias, int Ho, int Wo, float* __restrict__ z,
-                                                     int tiles_x, int tiles_img, int ntiles) {
+                                                     int tiles_x, int tiles_img, int ntiles, const Conv16Tail tail) {
   __shared__ __attribute__((aligned(16))) float patch[ST_PH * ST_ROWP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
   float breg[7][4];
@@ -1141,6 +1168,7 @@ __global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x
       breg[ky][j] = kx < 7 ? w[(((long)n * 2 + c) * 7 + ky) * 7 + kx] : 0.f;
     }
   const float bv = bias ? bias[n] : 0.f;
+  const C16Consts cc = c16_consts<TAIL>(tail, n);
   constexpr int NV = ST_PH * ST_PWC, NF = (NV + 255) / 256;
   float2 pre[NF];
   auto fetch = [&](int bt) {
@@ -1189,19 +1217,26 @@ __global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int oya = oy0 + ty0, oxa = ox0 + tx0 + 4 * g + e, oyb = oy0 + ty1, oxb = ox0 + tx1 + 4 * g + e;
-        if (oya < Ho && oxa < Wo) z[(((long)img * Ho + oya) * Wo + oxa) * 16 + n] = acc0[e] + bv;
-        if (oyb < Ho && oxb < Wo) z[(((long)img * Ho + oyb) * Wo + oxb) * 16 + n] = acc1[e] + bv;
+        if (oya < Ho && oxa < Wo) z[(((long)img * Ho + oya) * Wo + oxa) * 16 + n] = c16_tail<TAIL>(acc0[e] + bv, cc, nullptr, 0);
+        if (oyb < Ho && oxb < Wo) z[(((long)img * Ho + oyb) * Wo + oxb) * 16 + n] = c16_tail<TAIL>(acc1[e] + bv, cc, nullptr, 0);
       }
     }
   }
 }
 }  // namespace
 
-void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, const float* bias, float* z, hipStream_t st) {
+void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, const float* bias, float* z, hipStream_t st,
+                   const Conv16Tail* tail) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int tx = cdiv(Wo, ST_TW), ty = cdiv(Ho, ST_TH), ntiles = nimg * tx * ty;
   const int grid = ntiles < 256 * 4 ? ntiles : 256 * 4;
-  hipLaunchKernelGGL(stem16_kernel, dim3(grid), dim3(256), 0, st, x4, nimg, H, W, w, bias, Ho, Wo, z, tx, tx * ty, ntiles);
+  if (tail) {
+    ATDN_CHECK(tail->sc && tail->sh && !tail->skip, "stem tail is BN(Mish(.))");
+    hipLaunchKernelGGL(stem16_kernel<1>, dim3(grid), dim3(256), 0, st, x4, nimg, H, W, w, bias, Ho, Wo, z, tx, tx * ty, ntiles, *tail);
+  } else {
+    hipLaunchKernelGGL(stem16_kernel<0>, dim3(grid), dim3(256), 0, st, x4, nimg, H, W, w, bias, Ho, Wo, z, tx, tx * ty, ntiles,
+                       Conv16Tail{});
+  }
   ATDN_HIP(hipGetLastError());
 }
 
@@ -1312,6 +1347,17 @@ void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool 
   else if (K == 1 && S == 2) conv16_launch<1, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
   else if (K == 1 && S == 1) conv16_launch<1, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
   else throw Error("conv16: no kernel for this shape");
+}
+
+void launch_conv16_eval(const float* x, int nimg, int H, int W, const float* w, const float* bias, int K, int S, int pad,
+                        const Conv16Tail& tail, float* z, hipStream_t st) {
+  ATDN_CHECK(tail.sc && tail.sh, "eval tail needs the folded BatchNorm affine");
+  const bool res = tail.skip != nullptr;
+  ATDN_CHECK(!res || (tail.sc2 && tail.sh2), "residual tail needs the second affine");
+  if (K == 3 && S == 1 && !res) conv16_launch<3, 1, 8, 64, 1>(x, nimg, H, W, w, false, bias, pad, z, false, st, tail);
+  else if (K == 3 && S == 2 && res) conv16_launch<3, 2, 4, 32, 2>(x, nimg, H, W, w, false, bias, pad, z, false, st, tail);
+  else if (K == 3 && S == 3 && !res) conv16_launch<3, 3, 2, 32, 1>(x, nimg, H, W, w, false, bias, pad, z, false, st, tail);
+  else throw Error("conv16_eval: no kernel for this shape");
 }
 
 }  // namespace atdn
