@@ -188,6 +188,8 @@ def main():
         step(i, feats)
         ev[i + 1].record(streams[i % S])
     join()
+    torch.cuda.current_stream().synchronize()
+    t_tail = time.perf_counter()   # sequence tail: all-gather + ordered LSTM scan over all N*K*B features + rel2abs
     allf = gather_features(feats[:K * B], world * K * B) if world > 1 else feats[:K * B]
     rot, tr = pipe.scan(allf)
     poses = transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
@@ -195,6 +197,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    tail_ms = (time.perf_counter() - t_tail) * 1e3
     assert tuple(poses.shape) == (world * K * B + 1, 4, 4) and bool(torch.isfinite(poses).all())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -235,6 +238,8 @@ def main():
             "lookup": {"ms_per_launch": lookup_ms, "achieved_GBps": LOOKUP_BYTES * B / (lookup_ms * 1e-3) / 1e9,
                        "peak_GBps": PEAK_HBM_GBS},
             "stages_ms_per_forward": {k: round(v, 4) for k, v in st.items()},
+            # inside the timed region, after the K steps: grows with N (every rank scans all N*K*B features in order)
+            "sequence_tail_ms": round(tail_ms, 3),
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(gsd, hsd, resize_frames(raw[:6]))
