@@ -15,7 +15,12 @@
 
 namespace atdn {
 
-template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false>
+// PF: chunks of global loads in flight ahead of the one being multiplied. The register sets form a ring whose slot is a
+// compile-time constant (the chunk loop is unrolled PF times): rotating one register set by copying makes the compiler
+// wait (vmcnt(0)) for every outstanding load at the top of each iteration, i.e. no depth at all. PF = 3 is for operands
+// streamed once from HBM (attention x V: 16 KB of the attention matrix per block and chunk; at PF = 1 a CU has ~28 KB
+// in flight, half of what hides an HBM miss at full rate).
+template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false, int PF = 1>
 __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const float wscale, const Epi ep) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -60,12 +65,12 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
   const float* s0 = g.src0 + (long)img * g.sb0;
   const float* s1 = g.src1 ? g.src1 + (long)img * g.sb1 : nullptr;
 
-  float4 ra[RA], rb[RB];
-  bool aok[RA];  // applied at LDS-store time (see conv_mfma.h)
+  float4 ra[PF][RA], rb[PF][RB];
+  bool aok[PF][RA];  // applied at LDS-store time (see conv_mfma.h)
   int ky = 0, kx = 0, cc = 0;
   const int ctot = g.C0 + g.C1;
 
-  auto fetch = [&](int q) __attribute__((always_inline)) {
+  auto fetch = [&](int q, int slot) __attribute__((always_inline)) {
     const float* sp;
     int ld, co;
     if (cc < g.C0) { sp = s0; ld = g.ld0; co = cc; } else { sp = s1; ld = g.ld1; co = cc - g.C0; }
@@ -74,15 +79,15 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
       const int iy = iy0[i] + ky, ix = ix0[i] + kx;
       const bool ok = ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
       const float4 v = *reinterpret_cast<const float4*>(sp + (long)(ok ? iy * g.W + ix : 0) * ld + co + 4 * s);
-      ra[i] = v;
-      aok[i] = ok;
+      ra[slot][i] = v;
+      aok[slot][i] = ok;
     }
     cc += 32;
     if (cc == ctot) { cc = 0; if (++kx == g.KW) { kx = 0; ++ky; } }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(wrow[j] + q * 32);
-      rb[j] = v;
+      rb[slot][j] = v;
     }
   };
 
@@ -102,17 +107,27 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
   const char* b_rd = reinterpret_cast<const char*>(Bs + (wn * TN * 32 + r) * LDS_LD) + 16 * h;
   constexpr int ROWB = LDS_LD * 4;
 
-  fetch(0);
-  for (int q = 0; q < g.nchunks; ++q) {
+  // The chunk loop is branch-free: look-ahead fetches past the end are clamped (valid, unused data) and the trip
+  // count is rounded up to a multiple of PF with the surplus chunks stored to LDS as zeros, so the waits the compiler
+  // places before a slot's LDS stores are exact counts of the younger loads, never a drain.
+  const int last = g.nchunks - 1;
+#pragma unroll
+  for (int d = 0; d < PF; ++d) fetch(min(d, last), d);
+  const int nq = (g.nchunks + PF - 1) / PF * PF;
+  for (int q0 = 0; q0 < nq; q0 += PF) {
+#pragma unroll
+   for (int d = 0; d < PF; ++d) {
+    const int q = q0 + d;
+    const bool live = PF == 1 || q <= last;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RA; ++i)
-      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDS_LD + 4 * s) = keep_if(aok[i], ra[i]);
+      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDS_LD + 4 * s) = keep_if(aok[d][i] && live, ra[d][i]);
 #pragma unroll
     for (int j = 0; j < RB; ++j)
-      *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = keep_if(wok[j], rb[j]);
+      *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = keep_if(wok[j], rb[d][j]);
     __syncthreads();
-    if (q + 1 < g.nchunks) fetch(q + 1);
+    fetch(min(q + PF, last), d);   // into the slot just drained
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -137,6 +152,7 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+   }
   }
 
 #pragma unroll
@@ -204,12 +220,12 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
   }
 }
 
-template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false>
+template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false, int PF = 1>
 inline void launch_conv_sf(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   ConvGeom g = make_geom<MODE_TAP>(s, BM, BN);
   const int nblk = g.nimg * g.tiles_per_img * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
+  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST, PF>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
   ATDN_HIP(hipGetLastError());
 }
 
