@@ -78,7 +78,15 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
     for (int i = 0; i < RA; ++i) {
       const int iy = iy0[i] + ky, ix = ix0[i] + kx;
       const bool ok = ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
-      const float4 v = *reinterpret_cast<const float4*>(sp + (long)(ok ? iy * g.W + ix : 0) * ld + co + 4 * s);
+      const float* ap = sp + (long)(ok ? iy * g.W + ix : 0) * ld + co + 4 * s;
+      float4 v;
+      if constexpr (PF > 1) {   // streamed-once operand: non-temporal, so the stream does not evict the shared operand from L2
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(ap));
+        v = make_float4(t.x, t.y, t.z, t.w);
+      } else {
+        v = *reinterpret_cast<const float4*>(ap);
+      }
       ra[slot][i] = v;
       aok[slot][i] = ok;
     }
