@@ -42,6 +42,8 @@ class ClvoNet {
 
   DeviceBuf in4_, bufA_, bufB_, bufS_, flat_, gates_, x2_;
   DeviceBuf pre_, hseq_, x2seq_;  // scan scratch, grown on demand: [T*Bs][2048], [(T+1)*Bs][512], [T*Bs][512]
+  DeviceBuf hseq2_;               // [(T+1)*Bs][512]: the h2 sequence of the pipelined scan
+  bool pipe_ = true;              // ATDN_LSTM_PIPE=0: two scans of one launch per step each (earlier path)
   void ensure_scan(long rows, int Bs);
 };
 

@@ -25,7 +25,7 @@ ClvoNet::ClvoNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) 
 }
 
 ClvoNet::~ClvoNet() {
-  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &gates_, &x2_, &pre_, &hseq_, &x2seq_}) b->release();
+  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &gates_, &x2_, &pre_, &hseq_, &x2seq_, &hseq2_}) b->release();
   arena_.release();
 }
 
@@ -100,6 +100,7 @@ void ClvoNet::finalize() {
     r.skip_w = arena_.dev(r.skip_w_off); r.skip_b = arena_.dev(r.skip_b_off);
   }
   conv16_ = !(getenv("ATDN_CLVO_CONV16") && getenv("ATDN_CLVO_CONV16")[0] == '0');
+  pipe_ = !(getenv("ATDN_LSTM_PIPE") && getenv("ATDN_LSTM_PIPE")[0] == '0');
   for (Lin* l : {&fc_, &lstm1_ih_, &lstm1_hh_, &lstm_lin_, &lstm2_ih_, &lstm2_hh_, &rot_[0], &rot_[1], &rot_[2],
                  &tr_[0], &tr_[1], &tr_[2]}) {
     l->w = arena_.dev(l->w_off);
@@ -173,6 +174,7 @@ void ClvoNet::ensure_scan(long rows, int Bs) {
   if (pre_.n < rows * 2048) { pre_.release(); pre_.alloc(rows * 2048); }
   if (hseq_.n < (rows + Bs) * 512) { hseq_.release(); hseq_.alloc((rows + Bs) * 512); }
   if (x2seq_.n < rows * 512) { x2seq_.release(); x2seq_.alloc(rows * 512); }
+  if (hseq2_.n < (rows + Bs) * 512) { hseq2_.release(); hseq2_.alloc((rows + Bs) * 512); }
 }
 
 // The recurrence of odometry/network.py:137-140 restructured so that only what is truly sequential stays in the
@@ -199,13 +201,35 @@ void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, f
     ATDN_HIP(hipMemcpyAsync(h, hseq_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
   };
   gemm(feat, lstm1_ih_, pre_.p, 2048);
+  const MlpHead R{rot_[0].w, rot_[0].b, rot_[1].w, rot_[1].b, rot_[2].w};
+  const MlpHead Tt{tr_[0].w, tr_[0].b, tr_[1].w, tr_[1].b, tr_[2].w};
+  if (pipe_) {
+    // lstm1 (step s), lstm_linear (step s - 1) and lstm2 with its input projection (step s - 2) share ONE launch per
+    // step: T + 2 dependent launches instead of 2T + 2 (the scan is bound by the launch rate)
+    ATDN_HIP(hipMemcpyAsync(hseq_.p, h1, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ATDN_HIP(hipMemcpyAsync(hseq2_.p, h2, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+    for (int sidx = 0; sidx < T + 2; ++sidx) {
+      LstmPipeArgs a{};
+      a.Hd = 512; a.B = Bs;
+      a.do1 = sidx < T; a.do_lin = sidx >= 1 && sidx <= T; a.do2 = sidx >= 2;
+      const int t1 = sidx < T ? sidx : 0, tl = a.do_lin ? sidx - 1 : 0, t2 = a.do2 ? sidx - 2 : 0;
+      a.pre1 = pre_.p + (long)t1 * Bs * 2048; a.Whh1 = lstm1_hh_.w; a.bhh1 = lstm1_hh_.b;
+      a.h1_in = hseq_.p + t1 * sb; a.c1 = c1; a.h1_out = hseq_.p + (t1 + 1) * sb;
+      a.Wlin = lstm_lin_.w; a.blin = lstm_lin_.b; a.lin_in = hseq_.p + (tl + 1) * sb; a.lin_out = x2seq_.p + tl * sb;
+      a.Wih2 = lstm2_ih_.w; a.bih2 = lstm2_ih_.b; a.Whh2 = lstm2_hh_.w; a.bhh2 = lstm2_hh_.b;
+      a.x2_in = x2seq_.p + t2 * sb; a.h2_in = hseq2_.p + t2 * sb; a.c2 = c2; a.h2_out = hseq2_.p + (t2 + 1) * sb;
+      launch_lstm_pipe(a, st);
+    }
+    ATDN_HIP(hipMemcpyAsync(h1, hseq_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ATDN_HIP(hipMemcpyAsync(h2, hseq2_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+    launch_mlp_heads(hseq2_.p + sb, (int)rows, R, Tt, rot, tr, st);
+    return;
+  }
   scan(lstm1_hh_, h1, c1);
   launch_linear(lstm_lin_.w, hseq_.p + sb, 512, 512, nullptr, nullptr, 0, 0, lstm_lin_.b, nullptr, 1, x2seq_.p, 512, 512,
                 (int)rows, st);
   gemm(x2seq_.p, lstm2_ih_, pre_.p, 2048);
   scan(lstm2_hh_, h2, c2);
-  const MlpHead R{rot_[0].w, rot_[0].b, rot_[1].w, rot_[1].b, rot_[2].w};
-  const MlpHead Tt{tr_[0].w, tr_[0].b, tr_[1].w, tr_[1].b, tr_[2].w};
   launch_mlp_heads(hseq_.p + sb, (int)rows, R, Tt, rot, tr, st);
 }
 

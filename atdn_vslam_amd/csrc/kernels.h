@@ -60,6 +60,16 @@ void launch_lstm_cell(const float* gates, float* c, float* h, int B, int Hd, hip
 // pointwise cell update (gate order i,f,g,o). One wave per hidden unit; h_out must not alias h_in.
 void launch_lstm_rec(const float* pre, const float* Whh, const float* bhh, const float* h_in, float* c, float* h_out,
                      int B, int Hd, hipStream_t st);
+// One time step of the recurrent tail as a three-stage pipeline (see lstm_pipe_kernel): stage 1 = lstm1 cell on
+// pre1 (= W_ih1 x + b_ih1, batched beforehand) and h1_in; stage 2 = lin_out = Mish(Wlin lin_in + blin); stage 3 = lstm2
+// cell on x2_in and h2_in with its input projection inline. Stages with do_* == 0 are skipped (pipeline fill / drain).
+struct LstmPipeArgs {
+  int Hd, B, do1, do_lin, do2;
+  const float *pre1, *Whh1, *bhh1, *h1_in; float *c1, *h1_out;
+  const float *Wlin, *blin, *lin_in; float* lin_out;
+  const float *Wih2, *bih2, *Whh2, *bhh2, *x2_in, *h2_in; float *c2, *h2_out;
+};
+void launch_lstm_pipe(const LstmPipeArgs& a, hipStream_t st);
 // both regressors (512 -> 128 -> 64 -> 3, Mish, last layer no bias): out rot [B][3], tr [B][3]
 struct MlpHead { const float *w0, *b0, *w1, *b1, *w2; };
 void launch_mlp_heads(const float* h2, int B, MlpHead rot, MlpHead tr, float* rot_out, float* tr_out, hipStream_t st);

@@ -494,6 +494,73 @@ void launch_lstm_rec(const float* pre, const float* Whh, const float* bhh, const
   ATDN_HIP(hipGetLastError());
 }
 
+// ---- the whole recurrent tail as a three-stage software pipeline, ONE launch per time step (the scan is bound by the
+// launch rate, ~5.5 us per dependent launch): launch s runs lstm1 for step s (blocks [0,G)), lstm_linear + Mish for step
+// s - 1 and lstm2 — input projection included — for step s - 2; every stage reads what the previous launch wrote.
+// One block per hidden unit with one wave per gate (4.6 k waves per launch: the 13 MB of weights stream from L2 in ~3 us).
+__global__ __launch_bounds__(256) void lstm_pipe_kernel(const LstmPipeArgs a) {
+  // blocks [0,Hd): lstm1, one block per hidden unit, wave g = gate g; [Hd, Hd + Hd/4): lstm_linear, one wave per output;
+  // [Hd + Hd/4, 2Hd + Hd/4): lstm2 likewise (each wave: its gate row of W_ih2 and of W_hh2)
+  __shared__ float gate[4];
+  const int Hd = a.Hd, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto dot = [&](const float* __restrict__ wrow, const float* __restrict__ x) {
+    float acc = 0.f;
+    for (int k = lane; k < Hd / 4; k += 64) {
+      const float4 w = reinterpret_cast<const float4*>(wrow)[k];
+      const float4 v = reinterpret_cast<const float4*>(x)[k];
+      acc += w.x * v.x + w.y * v.y + w.z * v.z + w.w * v.w;
+    }
+    return wave_sum(acc);
+  };
+  int blk = blockIdx.x;
+  if (blk < Hd) {
+    if (!a.do1) return;
+    const int j = blk;
+    for (int b = 0; b < a.B; ++b) {
+      const float acc = dot(a.Whh1 + ((long)wv * Hd + j) * Hd, a.h1_in + (long)b * Hd);
+      if (lane == 0) gate[wv] = a.pre1[(long)b * 4 * Hd + wv * Hd + j] + (acc + a.bhh1[wv * Hd + j]);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float cn = sigmoidf_(gate[1]) * a.c1[(long)b * Hd + j] + sigmoidf_(gate[0]) * tanhf(gate[2]);
+        a.c1[(long)b * Hd + j] = cn;
+        a.h1_out[(long)b * Hd + j] = sigmoidf_(gate[3]) * tanhf(cn);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  blk -= Hd;
+  if (blk < Hd / 4) {
+    if (!a.do_lin) return;
+    const int j = blk * 4 + wv;
+    for (int b = 0; b < a.B; ++b) {
+      const float acc = dot(a.Wlin + (long)j * Hd, a.lin_in + (long)b * Hd);
+      if (lane == 0) a.lin_out[(long)b * Hd + j] = mishf_(acc + a.blin[j]);
+    }
+    return;
+  }
+  blk -= Hd / 4;
+  if (!a.do2) return;
+  const int j = blk;
+  for (int b = 0; b < a.B; ++b) {
+    const float ax = dot(a.Wih2 + ((long)wv * Hd + j) * Hd, a.x2_in + (long)b * Hd);
+    const float ah = dot(a.Whh2 + ((long)wv * Hd + j) * Hd, a.h2_in + (long)b * Hd);
+    if (lane == 0) gate[wv] = (ax + a.bih2[wv * Hd + j]) + (ah + a.bhh2[wv * Hd + j]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float cn = sigmoidf_(gate[1]) * a.c2[(long)b * Hd + j] + sigmoidf_(gate[0]) * tanhf(gate[2]);
+      a.c2[(long)b * Hd + j] = cn;
+      a.h2_out[(long)b * Hd + j] = sigmoidf_(gate[3]) * tanhf(cn);
+    }
+    __syncthreads();
+  }
+}
+void launch_lstm_pipe(const LstmPipeArgs& a, hipStream_t st) {
+  ATDN_CHECK(a.Hd % 16 == 0 && a.B >= 1, "lstm_pipe: bad arguments");
+  hipLaunchKernelGGL(lstm_pipe_kernel, dim3(2 * a.Hd + a.Hd / 4), dim3(256), 0, st, a);
+  ATDN_HIP(hipGetLastError());
+}
+
 // block = one batch row; waves 0-1 run the rotation head, waves 2-3 the translation head
 __global__ __launch_bounds__(256) void mlp_heads_kernel(const float* __restrict__ h2, MlpHead rot, MlpHead tr,
                                                         float* __restrict__ rot_out, float* __restrict__ tr_out) {
