@@ -403,6 +403,27 @@ def test_clvo_head_matches_golden_and_oracle(golden_dir, hsd):
         assert _maxerr(rot_seq[t].cpu(), torch.from_numpy(g["rot%d" % t])) < 1e-5
 
 
+def test_clvo_head_kernel_generations_agree(hsd, monkeypatch):
+    """The 16x16x4 encoder kernels and the one-launch-per-step recurrent pipeline against the paths they replaced
+    (32x32x2 implicit-GEMM engine, two scans), which stay selectable: same features, same poses over a sequence."""
+    fl = torch.from_numpy(syn.make_flow(5, 376, 1232, seed=16)).to(DEV)
+
+    def run():
+        head = ATDNVO()
+        head.load_state_dict(hsd)
+        head = head.to(DEV).eval()
+        feats = head.encode(fl)
+        rot, tr, _ = head.scan(feats[:, None, :])
+        return feats.cpu(), rot.cpu(), tr.cpu()
+
+    new = run()
+    monkeypatch.setenv("ATDN_CLVO_CONV16", "0")
+    monkeypatch.setenv("ATDN_LSTM_PIPE", "0")
+    old = run()
+    assert _maxerr(new[0], old[0]) < 1e-5
+    assert _maxerr(new[1], old[1]) < 1e-6 and _maxerr(new[2], old[2]) < 1e-5
+
+
 def test_clvo_head_rejects_unsupported_size(hsd):
     head = ATDNVO()
     head.load_state_dict(hsd)
