@@ -53,8 +53,12 @@ struct EpiBiasStats {
   float* part_sum; float* part_m2; int groups_per_img;
   float* part_cnt = nullptr;  // valid rows per group (only the 2-D tiled kernel writes it)
   static constexpr int kGen6 = 1;  // conv_sf6.h, classic (pixel-major) orientation
-  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    dst[(long)img * ob + (long)m * ld + n] = a + bias[n];
+  __device__ __forceinline__ void operator()(int img, int m, int n, float a) const { store_c(img, m, n, a, col(n)); }
+  // per-column constant passed in (see SfBias): one bias load per output column, not one between every two stores
+  struct Col { float b; };
+  __device__ __forceinline__ Col col(int n) const { return {bias[n]}; }
+  __device__ __forceinline__ void store_c(int img, int m, int n, float a, Col c) const {
+    dst[(long)img * ob + (long)m * ld + n] = a + c.b;
   }
 };
 
