@@ -26,6 +26,8 @@ namespace atdn {
 // which kernel shapes an epilogue is instantiated for on this path (bit 0: 3x3, bit 1: 1x5 and 5x1)
 template <class E, class = void> struct epi_gen6 : std::integral_constant<int, 0> {};
 template <class E> struct epi_gen6<E, std::void_t<decltype(E::kGen6)>> : std::integral_constant<int, E::kGen6> {};
+template <class E, class = void> struct EpiAux4 { struct type {}; };
+template <class E> struct EpiAux4<E, std::void_t<typename E::Aux4>> { using type = typename E::Aux4; };
 template <class E, class = void> struct epi_vec4 : std::false_type {};
 template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bool_constant<E::kVec4> {};
 
@@ -266,6 +268,27 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
     __syncthreads();
     float* tb = reinterpret_cast<float*>(Pbytes) + wave * (32 * LDS_LD);
     const int trow = lane >> 3, tcol = (lane & 7) * 4;
+    // pixel index of row 8q + trow of tile row i (-1: outside the image)
+    auto tile_pixel = [&](int i, int q) {
+      const int p = (wm * TM + i) * 32 + 8 * q + trow;
+      const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+      return (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
+    };
+    // Epilogues with operand loads (GRU gates, residual adds) are software-pipelined over the wave's tiles: the
+    // operands of tile t + 1 are requested BEFORE the stores of tile t are issued. vmcnt retires in order, so a load
+    // issued after a store can only be waited for together with that store; this way the wait before tile t + 1's
+    // arithmetic counts the younger stores and loads and never drains them.
+    struct NoAux {};
+    using AuxT = typename std::conditional<Epi::kPrefetch, typename EpiAux4<Epi>::type, NoAux>::type;
+    // (only while the operands of a tile fit 32 registers per lane: the q gate's three operand vectors would take the
+    // 128-wide block from three to two resident blocks per CU)
+    constexpr bool PIPE = Epi::kPrefetch && sizeof(AuxT) <= 2 * sizeof(float4);
+    AuxT aux_next[PIPE ? 4 : 1];
+    if constexpr (PIPE) {
+      const int nb0 = n0 + (wn * TN) * 32 + tcol;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) aux_next[q] = ep.load4(img, max(tile_pixel(0, q), 0), min(nb0, g.N - 4));
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -284,16 +307,26 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           v[q] = *reinterpret_cast<const float4*>(tb + (8 * q + trow) * LDS_LD + tcol);
-          const int p = (wm * TM + i) * 32 + 8 * q + trow;
-          const int oy = ty0 + p / TW, ox = tx0 + p % TW;
-          mq[q] = (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
+          mq[q] = tile_pixel(i, q);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next tile
         if constexpr (Epi::kPrefetch) {
-          typename Epi::Aux4 aux[4];
+          AuxT aux[4];
+          if constexpr (PIPE) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) aux[q] = ep.load4(img, max(mq[q], 0), min(nb, g.N - 4));
+            for (int q = 0; q < 4; ++q) aux[q] = aux_next[q];
+            // next tile of this wave: (i, j + 1) or (i + 1, 0)
+            const int jn = (j + 1 < TN) ? j + 1 : 0, in = (j + 1 < TN) ? i : i + 1;
+            if (in < TM) {
+              const int nbn = n0 + (wn * TN + jn) * 32 + tcol;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) aux_next[q] = ep.load4(img, max(tile_pixel(in, q), 0), min(nbn, g.N - 4));
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) aux[q] = ep.load4(img, max(mq[q], 0), min(nb, g.N - 4));
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (mq[q] >= 0 && nb < g.N) ep.apply4(img, mq[q], nb, v[q], aux[q], bj);
