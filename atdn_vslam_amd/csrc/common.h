@@ -42,6 +42,9 @@ inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 // epilogues that take their per-column constants as an argument (struct Col, col(n), store_c)
 template <class E, class = void> struct epi_bias_arg : std::false_type {};
 template <class E> struct epi_bias_arg<E, std::void_t<typename E::Col>> : std::true_type {};
+// its Col type (an empty struct for epilogues without one)
+template <class E, class = void> struct EpiCol { struct type {}; };
+template <class E> struct EpiCol<E, std::void_t<typename E::Col>> { using type = typename E::Col; };
 
 // Bijective XCD-aware remap of a 1-D block id: blocks that land on the same XCD
 // (observed round-robin: id % 8) receive a contiguous range of logical ids, so

@@ -188,6 +188,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
   }
 
   // ---- epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  // per-column constants once per wave, before any store (a load issued after a store waits for that store too)
+  typename EpiCol<Epi>::type colj[TN];
+  float biasj[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = min(n0 + (wn * TN + j) * 32 + r, g.N - 1);
+    biasj[j] = 0.f;
+    if constexpr (Epi::kStats) biasj[j] = ep.bias[n];
+    if constexpr (epi_bias_arg<Epi>::value) colj[j] = ep.col(n);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int mbase = pix0 + (wm * TM + i) * 32;
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
       const bool nok = n < g.N;
       if constexpr (Epi::kStats) {
         // per-column (sum, M2) of this 32-row group for instance norm, combined across the two lane halves
-        const float bias = nok ? ep.bias[n] : 0.f;
+        const float bias = nok ? biasj[j] : 0.f;
         float v[16];
         float sum = 0.f;
         int cnt = 0;
@@ -236,11 +246,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGeom g, const 
             if (m < HoWo) ep.apply(img, m, n, acc[i][j][e], aux[e]);
           }
         } else if constexpr (epi_bias_arg<Epi>::value) {
-          const typename Epi::Col cn = ep.col(n);
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < HoWo) ep.store_c(img, m, n, acc[i][j][e], cn);
+            if (m < HoWo) ep.store_c(img, m, n, acc[i][j][e], colj[j]);
           }
         } else {
 #pragma unroll

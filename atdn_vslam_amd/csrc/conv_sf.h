@@ -163,6 +163,16 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
    }
   }
 
+  // per-column constants once per wave, before any store (a load issued after a store waits for that store too)
+  typename EpiCol<Epi>::type colj[TN];
+  float biasj[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = min(n0 + (wn * TN + j) * 32 + r, g.N - 1);
+    biasj[j] = 0.f;
+    if constexpr (Epi::kStats) biasj[j] = ep.bias[n];
+    if constexpr (epi_bias_arg<Epi>::value) colj[j] = ep.col(n);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int mbase = pix0 + (wm * TM + i) * 32;
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
       const int n = n0 + (wn * TN + j) * 32 + r;
       const bool nok = n < g.N;
       if constexpr (Epi::kStats) {
-        const float bias = nok ? ep.bias[n] : 0.f;
+        const float bias = nok ? biasj[j] : 0.f;
         float v[16];
         float sum = 0.f;
         int cnt = 0;
@@ -210,11 +220,10 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
             if (m < HoWo) ep.apply(img, m, n, acc[i][j][e] * wscale, aux[e]);
           }
         } else if constexpr (epi_bias_arg<Epi>::value) {
-          const typename Epi::Col cn = ep.col(n);
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < HoWo) ep.store_c(img, m, n, acc[i][j][e] * wscale, cn);
+            if (m < HoWo) ep.store_c(img, m, n, acc[i][j][e] * wscale, colj[j]);
           }
         } else {
 #pragma unroll

@@ -349,6 +349,16 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
     return;
   }
   // ---- epilogue (as conv_sf2.h, TM x TN tiles per wave)
+  // per-column constants once per wave, before any store (a load issued after a store waits for that store too)
+  typename EpiCol<Epi>::type colj[TN];
+  float biasj[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = min(n0 + (wn * TN + j) * 32 + r, g.N - 1);
+    biasj[j] = 0.f;
+    if constexpr (Epi::kStats) biasj[j] = ep.bias[n];
+    if constexpr (epi_bias_arg<Epi>::value) colj[j] = ep.col(n);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int pbase = (wm * TM + i) * 32;
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
         mm[e] = (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
       }
       if constexpr (Epi::kStats) {
-        const float bias = nok ? ep.bias[n] : 0.f;
+        const float bias = nok ? biasj[j] : 0.f;
         float v[16];
         float sum = 0.f;
         int cnt = 0;
@@ -398,10 +408,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
           for (int e = 0; e < 16; ++e)
             if (mm[e] >= 0) ep.apply(img, mm[e], n, acc[i][j][e] * g.wscale, aux[e]);
         } else if constexpr (epi_bias_arg<Epi>::value) {
-          const typename Epi::Col cn = ep.col(n);
 #pragma unroll
           for (int e = 0; e < 16; ++e)
-            if (mm[e] >= 0) ep.store_c(img, mm[e], n, acc[i][j][e] * g.wscale, cn);
+            if (mm[e] >= 0) ep.store_c(img, mm[e], n, acc[i][j][e] * g.wscale, colj[j]);
         } else {
 #pragma unroll
           for (int e = 0; e < 16; ++e)
