@@ -114,18 +114,36 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const float* __restrict
   const int py = pix >> 4, px = pix & 15;
   const float* simg = src + (long)img * H * W * 256;
   float acc0 = 0.f, acc1 = 0.f;
-  for (int chunk = 0; chunk < 8; ++chunk) {
-    __syncthreads();
-    for (int i = tid; i < 180 * 8; i += 256) {
-      const int slot = i & 7, prow = i >> 3;
+  // the patch of chunk c + 1 is fetched into registers while chunk c is multiplied (180 pixels x 8 slots = 1440
+  // 16-byte pieces, 6 per thread)
+  constexpr int NPF = (180 * 8 + 255) / 256;
+  float4 pre[NPF];
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int i = tid + 256 * k;
+      const int slot = i & 7, prow = min(i >> 3, 179);
       const int ry = prow / 18, rx = prow - ry * 18;
       const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        v = *reinterpret_cast<const float4*>(simg + ((long)iy * W + ix) * 256 + chunk * 32 + slot * 4);
-      *reinterpret_cast<float4*>(patch + ry * FH_RS + rx * 144 + slot * 16) = v;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const float4 v = *reinterpret_cast<const float4*>(simg + ((long)(ok ? iy : 0) * W + (ok ? ix : 0)) * 256 + chunk * 32 + slot * 4);
+      pre[k] = keep_if(ok, v);
+    }
+  };
+  fetch(0);
+  for (int chunk = 0; chunk < 8; ++chunk) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int i = tid + 256 * k;
+      if (i < 180 * 8) {
+        const int slot = i & 7, prow = i >> 3;
+        const int ry = prow / 18, rx = prow - ry * 18;
+        *reinterpret_cast<float4*>(patch + ry * FH_RS + rx * 144 + slot * 16) = pre[k];
+      }
     }
     __syncthreads();
+    if (chunk + 1 < 8) fetch(chunk + 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const char* p = patch + (py + tap / 3) * FH_RS + (px + tap % 3) * 144 + half * 32;
