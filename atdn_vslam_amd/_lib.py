@@ -70,6 +70,9 @@ def lib():
             raise RuntimeError(
                 "%s is missing: the HIP extension has not been built (python -m atdn_vslam_amd.build). "
                 "There is no CPU fallback for the product path." % LIB_PATH)
+        # PyTorch-ROCm ships its own HIP runtime: it must be the one already mapped when this library (linked against
+        # libamdhip64 by soname) is loaded, or the process ends up with two runtimes and the second one finds no device
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
