@@ -274,6 +274,9 @@ struct ConvShape {  // what the caller describes; ConvGeom is derived from it
   const float* wfrag = nullptr;  // fragment-major sf copy of w (weights.h pack_fragment_major), optional
   int N = 0;
   int nimg = 1;
+  // optional (generation-6 halo kernels with a statistics epilogue only): src0 is the RAW fp32 output of an
+  // InstanceNorm'ed layer and these are its per-(image, channel) mean / reciprocal std: the loader normalises + ReLUs
+  const float* in_mean = nullptr; const float* in_rstd = nullptr;
 };
 
 inline int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }

@@ -23,6 +23,9 @@ struct Conv2Geom {
   int nimg, ntile_n;
   const float* w; int ldw; int N;
   float wscale;
+  // normalise-on-load (conv_sf6.h NORM): src0 is RAW fp32 [pix][C0] and the patch loader applies
+  // relu((x - in_mean[img][c]) * in_rstd[img][c]) before splitting to sf (InstanceNorm + ReLU of the producer)
+  const float* in_mean; const float* in_rstd;
 };
 
 // patch pixels an TH x TW output tile needs for the supported filters (3x3, 1x5, 5x1): 8x16 -> 192, 16x16 -> 324

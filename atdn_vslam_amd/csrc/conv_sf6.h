@@ -36,7 +36,12 @@ template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bo
 // NIMG: patch images in LDS. 2 = a chunk boundary costs one barrier (deep pipeline, one or two blocks per CU); 1 = half the
 // LDS and two barriers per boundary, for thin layers (few chunks per tile): four blocks per CU overlap each other's
 // prologue, epilogue and barriers instead
-template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2>
+// NORM: normalise-on-load. src0 holds the RAW fp32 output of an InstanceNorm'ed conv (same addressing: 128 bytes per
+// pixel and 32-channel chunk); the patch loader applies relu((x - mean) * rstd) per (image, channel), splits to hi | lo and
+// writes the sf chunk image itself, one patch row per half-step over the last NP half-steps of a chunk — the separate
+// normalisation pass between the two convs of a residual block (read 4 B + write 4 B per element) disappears.
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2,
+          bool NORM = false>
 __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2) ? 4 : 1)) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = TH * TW / 32 / WM, TN = BN / 32 / WN;
@@ -108,6 +113,24 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
     for (int k = 0; k < NP; ++k)
       *reinterpret_cast<float4*>(Pbytes + buf * PSZ + ((pmeta[k] & 0xFFFu) << 4)) = keep_if((pmeta[k] >> 12) != 0, pr[k]);
   };
+  // NORM: per-channel constants of the chunk being fetched (this thread's 4 channels), and the store of ONE patch row
+  float4 nmu = make_float4(0.f, 0.f, 0.f, 0.f), nrs = make_float4(1.f, 1.f, 1.f, 1.f);
+  auto fetch_norm = [&](int c) {
+    nmu = *reinterpret_cast<const float4*>(g.in_mean + (long)img * g.C0 + (c << 5) + 4 * s);
+    nrs = *reinterpret_cast<const float4*>(g.in_rstd + (long)img * g.C0 + (c << 5) + 4 * s);
+  };
+  auto store_row_norm = [&](int buf, int k, float4 mu, float4 rs) {
+    const bool ok = (pmeta[k] >> 12) != 0;
+    float4 v = pr[k];
+    v.x = fmaxf((v.x - mu.x) * rs.x, 0.f); v.y = fmaxf((v.y - mu.y) * rs.y, 0.f);
+    v.z = fmaxf((v.z - mu.z) * rs.z, 0.f); v.w = fmaxf((v.w - mu.w) * rs.w, 0.f);
+    v = keep_if(ok, v);
+    const SfPair a = sf_split(v.x), b = sf_split(v.y), d = sf_split(v.z), e = sf_split(v.w);
+    // the 16-byte slot field addresses slot s of the pixel: its 128-byte chunk starts s slots earlier
+    char* px = Pbytes + buf * PSZ + (((pmeta[k] & 0xFFFu) - (unsigned)s) << 4);
+    *reinterpret_cast<f16x4*>(px + 8 * s) = f16x4{a.hi, b.hi, d.hi, e.hi};
+    *reinterpret_cast<f16x4*>(px + 64 + 8 * s) = f16x4{a.lo, b.lo, d.lo, e.lo};
+  };
 
   // ---- MFMA roles
   const int wm = wave / WN, wn = wave % WN;
@@ -163,10 +186,16 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
   };
 
   fetch_patch(0);
+  if constexpr (NORM) fetch_norm(0);
 #pragma unroll
   for (int hs = 0; hs < R - 1; ++hs) load_wh(wr[hs], 0, hs);
   if (ABL & 1) load_wh(wr[R - 1], 0, R - 1);
-  store_patch(0);
+  if constexpr (NORM) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) store_row_norm(0, k, nmu, nrs);
+  } else {
+    store_patch(0);
+  }
   __syncthreads();
   // activation fragments: two register sets, the ds_reads of half-step hs + 1 are issued among the MFMAs of hs
   f16x8 ah[2][TM], al[2][TM];
@@ -207,20 +236,25 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
       // every half-step is its own scheduling region: without this fence the interleave solver moves the LDS reads
       // of half-step hs + 1 to just before their consumers
       __builtin_amdgcn_sched_barrier(0);
-      if (!(ABL & 2) && hs == 0) fetch_patch(cn);  // lands during this chunk's taps
+      if (!(ABL & 2) && hs == 0) { fetch_patch(cn); if constexpr (NORM) fetch_norm(cn); }  // lands during this chunk's taps
       if (!(ABL & 1)) {
         const int nhs = hs + R - 1;
         if (nhs < NH) load_wh(wr[nhs % R], c, nhs); else load_wh(wr[nhs % R], cn, nhs - NH);
       }
       if (!(ABL & 4) && hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1, (hs + 1) & 1);
-      if (NIMG == 2 && !(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
+      if constexpr (NORM) {   // one patch row per half-step: the conversion arithmetic spreads over NP half-steps
+        static_assert(!NORM || (NIMG == 2 && NH - 1 - NP >= 1), "normalise-on-load needs two patch images and NP < NH - 1");
+        if (hs >= NH - 1 - NP && hs <= NH - 2) store_row_norm((c + 1) & 1, hs - (NH - 1 - NP), nmu, nrs);
+      } else {
+        if (NIMG == 2 && !(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
+      }
       mfma_half(hs & 1, wr[hs % R]);
       // interleave: one memory instruction behind each MFMA — LDS reads first (they feed the next half-step), then
       // the global loads, then the patch image writes
       {
         constexpr int nds = 2 * TM;
         const int nvm = 2 * TN + (hs == 0 ? NP : 0);
-        const int ndw = (NIMG == 2 && hs == NH - 2) ? NP : 0;
+        const int ndw = NORM ? ((hs >= NH - 1 - NP && hs <= NH - 2) ? 2 : 0) : ((NIMG == 2 && hs == NH - 2) ? NP : 0);
 #pragma unroll
         for (int k = 0; k < NMF; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -421,7 +455,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
   }
 }
 
-template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2>
+template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2,
+          bool NORM = false>
 inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
   constexpr int TW = 16;
   ATDN_CHECK(s.KH == KH && s.KW == KW && s.stride == 1, "kernel shape does not match the instantiation");
@@ -438,10 +473,13 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
   g.tiles_x = cdiv(g.Wo, TW); g.tiles_y = cdiv(g.Ho, TH);
   g.nimg = s.nimg; g.ntile_n = cdiv(s.N, BN);
   g.w = FRAGW ? s.wfrag : s.w; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;
+  g.in_mean = s.in_mean; g.in_rstd = s.in_rstd;
+  ATDN_CHECK(NORM == (s.in_mean != nullptr) && (!NORM || (s.in_rstd && s.C1 == 0 && s.ld0 == s.C0)),
+             "normalise-on-load: one dense fp32 source with its mean / rstd");
   ATDN_CHECK(g.w != nullptr, "missing weight copy for this kernel");
   set_groups(ep, g.tiles_x * g.tiles_y * (TH * TW / 32));
   const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW, FAST, NIMG>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
+  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW, FAST, NIMG, NORM>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
   ATDN_HIP(hipGetLastError());
 }
 
@@ -470,6 +508,22 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   // small grids: narrower blocks (more of them) until the chip is covered
   while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
   *th_out = 8;
+  if (s.in_mean) {   // normalise-on-load: statistics convs of the feature network (3x3, 64 / 96 / 128 channels)
+    if constexpr (Epi::kStats && KH == 3 && !FAST) {
+      const long tiles12n = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
+      const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 && tiles12n * cdiv(s.N, bn) >= 512;
+      *bn_out = bn; *th_out = tall ? 12 : 8;
+      if (bn == 64 && tall) launch_conv_sf6<12, 64, 2, 2, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
+      else if (bn == 64) launch_conv_sf6<8, 64, 2, 2, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
+      else if (bn == 96 && tall) launch_conv_sf6<12, 96, 2, 3, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
+      else if (bn == 96) launch_conv_sf6<8, 96, 2, 3, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
+      else if (bn == 128) launch_conv_sf6<8, 128, 1, 4, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
+      else return false;
+      return true;
+    } else {
+      return false;
+    }
+  }
   if constexpr (KH == 3) {
     if (bn == 32) { *bn_out = 32; launch_conv_sf6<8, 32, 4, 1, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true; }
     static const bool tall_ok = !(getenv("ATDN_NO_TALL_TILES") && getenv("ATDN_NO_TALL_TILES")[0] == '1');

@@ -27,6 +27,7 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
       int bn = 0, th = 8;
       if (conv_sf6_try(s, wscale, ep, st, &bn, &th, sf_fast_mode())) return TileChoice{th * 16, bn, cdiv(Wo, 16) * cdiv(Ho, th) * (th / 2), true};
     }
+    ATDN_CHECK(s.in_mean == nullptr, "normalise-on-load is served by the generation-6 statistics kernels only");
     static const int big_min = getenv("ATDN_BIG_TILE_MIN") ? atoi(getenv("ATDN_BIG_TILE_MIN")) : 224;
     const int tiles16 = s.nimg * cdiv(Wo, 16) * cdiv(Ho, 16);
     if (s.N > 64 && (long)tiles16 * cdiv(s.N, 128) >= big_min) {
@@ -44,6 +45,7 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
     else               { if (wide) launch_conv_sf4<2>(s, wscale, ep, st); else launch_conv_sf4<1>(s, wscale, ep, st); }
     return t2;
   }
+  ATDN_CHECK(s.in_mean == nullptr, "normalise-on-load is served by the generation-6 statistics kernels only");
   TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);
   t.groups_per_img = cdiv(Ho * Wo, t.BM) * (t.BM / 32);
   set_groups(ep, t.groups_per_img);

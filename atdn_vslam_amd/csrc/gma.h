@@ -50,6 +50,9 @@ class GmaNet {
   void profile(int B, int iters, int reps, float* ms, hipStream_t st);
 
   int H, W, H8, W8, N, ldN, maxB, precision;
+  // feature network, split-f16 pipeline: conv2 of every residual block normalises conv1's raw output in its own
+  // patch loader (conv_sf6.h NORM); ATDN_NORM_ON_LOAD=0 keeps the separate normalisation pass
+  bool norm_on_load_ = false;
 
  private:
   void run_body(int B, int iters, hipStream_t st);  // everything between input prep and upsampling

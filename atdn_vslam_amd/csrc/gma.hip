@@ -135,6 +135,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   ATDN_CHECK(H % 8 == 0 && W % 8 == 0 && H >= 64 && W >= 64, "frame size must be a multiple of 8 (use the padder)");
   ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
+  norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
 }
@@ -411,9 +412,12 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
   const float* images = img4_.p + (long)first_img * H * W * 4;
   int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
   float* X = enc_[0].p; float* R = enc_[1].p; float* Y = enc_[2].p; float* O = enc_[3].p;
+  // in_slot >= 0: `src` is the RAW output of the previous statistics conv and mean_/rstd_[in_slot] are its statistics
+  // (normalise-on-load: the conv's patch loader applies InstanceNorm + ReLU itself)
   auto stats_sf = [&](const PackedConv& L, const float* src, int ld, int ih, int iw, int stride, int pad, float* dst,
-                      int slot) {
+                      int slot, int in_slot = -1) {
     ConvShape s = conv_shape(L, src, ld, (long)ih * iw * ld, nimg, ih, iw, stride, pad, pad);
+    if (in_slot >= 0) { s.in_mean = mean_[in_slot].p; s.in_rstd = rstd_[in_slot].p; }
     const int oh = conv_out(ih, L.KH, stride, pad), ow = conv_out(iw, L.KW, stride, pad);
     EpiBiasStats ep{L.b, dst, (long)oh * ow * L.N, L.N, psum_.p, pm2_.p, 0, pcnt_.p};
     TileChoice t = conv_sf_dispatch(s, L.wscale, ep, st);
@@ -445,7 +449,19 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
     const int co = Bk.c1.N;
     const int oh = conv_out(h, 3, stride, 1), ow = conv_out(w, 3, stride, 1);
     const long ohw = (long)oh * ow;
-    if (instance) {
+    if (instance && norm_on_load_) {
+      // conv1 -> (InstanceNorm + ReLU inside conv2's patch loader) -> conv2: the pass that used to materialise
+      // relu(IN(conv1)) between them (4 B read + 4 B written per element) is gone. conv2's statistics land in slot 1
+      // because slot 0 (conv1's) is read by conv2 itself.
+      stats_sf(Bk.c1, X, c, h, w, stride, 1, R, 0);
+      stats_sf(Bk.c2, R, co, oh, ow, 1, 1, Y, 1, 0);
+      if (Bk.has_ds) {
+        stats_sf(Bk.ds, X, c, h, w, 2, 0, R, 0);  // R is dead once conv2 has consumed it: holds the raw shortcut
+        launch_in_apply_sf(Y, O, mean_[1].p, rstd_[1].p, nullptr, R, mean_[0].p, rstd_[0].p, nimg, ohw, co, st);
+      } else {
+        launch_in_apply_sf(Y, O, mean_[1].p, rstd_[1].p, X, nullptr, nullptr, nullptr, nimg, ohw, co, st);
+      }
+    } else if (instance) {
       stats_sf(Bk.c1, X, c, h, w, stride, 1, R, 0);
       launch_in_apply_sf(R, Y, mean_[0].p, rstd_[0].p, nullptr, nullptr, nullptr, nullptr, nimg, ohw, co, st);
       stats_sf(Bk.c2, Y, co, oh, ow, 1, 1, R, 0);
