@@ -135,6 +135,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   ATDN_CHECK(H % 8 == 0 && W % 8 == 0 && H >= 64 && W >= 64, "frame size must be a multiple of 8 (use the padder)");
   ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
+  pool_features_ = precision >= 1 && !(getenv("ATDN_POOL_FEATURES") && getenv("ATDN_POOL_FEATURES")[0] == '0');
   norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
@@ -146,7 +147,7 @@ GmaNet::~GmaNet() {
   DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
-                      &pre_zr_[1], &pre_q_[0], &pre_q_[1]};
+                      &pre_zr_[1], &pre_q_[0], &pre_q_[1], &fpool_};
   for (auto* b : all) b->release();
   arena_.release();
 }
@@ -220,6 +221,7 @@ void GmaNet::finalize() {
   for (int l = 1; l < 4; ++l) { pyrH_[l] = pyrH_[l - 1] / 2; pyrW_[l] = pyrW_[l - 1] / 2; }
   ATDN_CHECK(pyrH_[3] >= 2 && pyrW_[3] >= 2, "frame too small for a 4-level pyramid");
   for (int l = 0; l < 4; ++l) pyr_[l].alloc(n8 * pyrH_[l] * pyrW_[l]);
+  if (sf) fpool_.alloc((long)B * pyrH_[1] * pyrW_[1] * 256);
   h_[0].alloc(n8 * 128); h_[1].alloc(n8 * 128); x_.alloc(n8 * XLD);
   qk_.alloc(n8 * 256); attn_.alloc(n8 * ldN); vT_.alloc((long)B * 128 * ldN);
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
@@ -570,7 +572,16 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   c.w = fmap_.p + (long)(seq_ ? 1 : B) * N * 256; c.wb = (long)N * 256; c.ldw = 256; c.N = N; c.nimg = B;
   conv_sf_dispatch(c, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[0].p, (long)N * N, N}, st);
   mark(ST_CORR, st);
-  for (int l = 1; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
+  if (pool_features_) {
+    const int N1 = pyrH_[1] * pyrW_[1];
+    launch_pool_features_sf(c.w, B, H8, W8, 256, (long)N * 256, fpool_.p, (long)N1 * 256, st);
+    ConvShape c1 = c;
+    c1.w = fpool_.p; c1.wb = (long)N1 * 256; c1.N = N1;
+    conv_sf_dispatch(c1, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[1].p, (long)N * N1, N1}, st);
+    for (int l = 2; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
+  } else {
+    for (int l = 1; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
+  }
   mark(ST_POOL, st);
 
   run_encoder_sf(cnet_, false, B, st, &f);

@@ -88,6 +88,8 @@ void launch_in_apply_sf(const float* x, float* y, const float* mean, const float
 void launch_lookup_sf(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
                       hipStream_t st);
 // row softmax, fp32 logits [rows][ld] -> sf probabilities [rows][ld] (pad columns zero); ld % 32 == 0
+// 2x2 average (floor sizes) of an sf feature map [img][H*W][C] (per-image strides sb / db in floats)
+void launch_pool_features_sf(const float* src, int nimg, int H, int W, int C, long sb, float* dst, long db, hipStream_t st);
 void launch_softmax_rows_sf(const float* x, float* y, long rows, int n, int ld, hipStream_t st);
 // as launch_init_coords, x flow channels written in sf at channels cflow, cflow+1 of the sf GRU input
 void launch_init_coords_sf(const float* flow_init, int B, int H8, int W8, float* coords1, float* flow4, float* x,

@@ -940,6 +940,34 @@ void launch_softmax_rows_sf(const float* x, float* y, long rows, int n, int ld, 
   ATDN_HIP(hipGetLastError());
 }
 
+// 2x2 average of an sf feature map [img][H*W][C] -> [img][(H/2)*(W/2)][C] (floor sizes, as avg_pool2d(2, stride 2)).
+// Correlation is linear in the target features, so <f1[p], mean of four f2> is the 2x2-pooled correlation of
+// corr.py:28-30: level 1 of the pyramid then comes from a quarter-size GEMM instead of a pass over the 210 MB level 0.
+__global__ void pool_features_sf_kernel(const float* __restrict__ src, int H, int W, int C, long sb, float* __restrict__ dst,
+                                        long db, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Ho = H / 2, Wo = W / 2, c4 = C / 4;
+  const int cq = (int)(i % c4);
+  const long pq = i / c4;
+  const int po = (int)(pq % ((long)Ho * Wo));
+  const long img = pq / ((long)Ho * Wo);
+  const int y = po / Wo, x = po - y * Wo;
+  const float* s = src + img * sb;
+  const long p00 = ((long)(2 * y) * W + 2 * x) * C;
+  const float4 a = sf_load4(s, p00, 4 * cq), b = sf_load4(s, p00 + C, 4 * cq);
+  const float4 c = sf_load4(s, p00 + (long)W * C, 4 * cq), d = sf_load4(s, p00 + (long)W * C + C, 4 * cq);
+  const float4 o = make_float4((((a.x + b.x) + c.x) + d.x) * 0.25f, (((a.y + b.y) + c.y) + d.y) * 0.25f,
+                               (((a.z + b.z) + c.z) + d.z) * 0.25f, (((a.w + b.w) + c.w) + d.w) * 0.25f);
+  sf_store4(dst + img * db, (long)po * C, 4 * cq, o);
+}
+void launch_pool_features_sf(const float* src, int nimg, int H, int W, int C, long sb, float* dst, long db, hipStream_t st) {
+  ATDN_CHECK(C % 32 == 0, "sf tensors need C % 32 == 0");
+  const long total = (long)nimg * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(pool_features_sf_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, src, H, W, C, sb, dst, db, total);
+  ATDN_HIP(hipGetLastError());
+}
+
 __global__ void init_coords_sf_kernel(const float* __restrict__ flow_init, int B, int H8, int W8,
                                       float* __restrict__ coords1, float* __restrict__ flow4, float* __restrict__ x,
                                       int ldx, int cflow) {
