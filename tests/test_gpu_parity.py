@@ -403,6 +403,30 @@ def test_clvo_head_matches_golden_and_oracle(golden_dir, hsd):
         assert _maxerr(rot_seq[t].cpu(), torch.from_numpy(g["rot%d" % t])) < 1e-5
 
 
+def test_flow_network_fused_passes_agree_with_the_separate_ones(gsd, monkeypatch):
+    """Normalise-on-load in the feature network and the pooled-feature pyramid level against the passes they replaced
+    (separate InstanceNorm pass; 2x2 pooling of the level-0 volume), at the plumbing size and a ragged one."""
+    sd = {"module." + k: v for k, v in gsd.items()}
+
+    def run(h, w):
+        m = RAFTGMA(max_batch=1, precision="split_f16")
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        fr = torch.from_numpy(syn.make_frames(2, h, w, seed=23)).to(DEV)
+        low, up = m(fr[0:1], fr[1:2], iters=6, test_mode=True)
+        return low.cpu(), up.cpu()
+
+    for (h, w) in ((160, 512), (184, 328)):
+        new = run(h, w)
+        monkeypatch.setenv("ATDN_NORM_ON_LOAD", "0")
+        monkeypatch.setenv("ATDN_POOL_FEATURES", "0")
+        old = run(h, w)
+        monkeypatch.delenv("ATDN_NORM_ON_LOAD")
+        monkeypatch.delenv("ATDN_POOL_FEATURES")
+        # the normalisation is the same arithmetic in another place; the pooled level differs at fp32 rounding level
+        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4
+
+
 def test_clvo_head_kernel_generations_agree(hsd, monkeypatch):
     """The 16x16x4 encoder kernels and the one-launch-per-step recurrent pipeline against the paths they replaced
     (32x32x2 implicit-GEMM engine, two scans), which stay selectable: same features, same poses over a sequence."""
