@@ -48,6 +48,12 @@ SIGNATURES = {
     "atdn_pose_rel2abs": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "atdn_pose_accumulate_f32": (C.c_int, [_vp, _vp, _vp]),
     "atdn_resize_frames": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "atdn_resize_frames_mode": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "atdn_resize_frames_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "atdn_pad_frames": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "atdn_ingest_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "atdn_ingest_frames_u8": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "atdn_ingest_destroy": (None, [_vp]),
     "atdn_corr_lookup": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "atdn_corr_pyramid": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "atdn_conv2d_nhwc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
@@ -57,7 +63,7 @@ SIGNATURES = {
 }
 
 GMA_STAGES = ("fnet", "corr", "pool", "cnet", "attention", "lookup", "motion_encoder", "aggregate", "gru_zr", "gru_q",
-              "flow_head", "mask", "gru_ctx")
+              "flow_head", "mask", "gru_ctx", "attn_logits", "agg_vt", "convc1")
 
 _lib = None
 

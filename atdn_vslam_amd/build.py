@@ -14,6 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libatdn_hip.so")
+# diagnostic micro-benchmarks (ablation builds of the kernels): their own library, not part of the product one
+MB_SRC = os.path.join(os.path.dirname(HERE), "tools", "microbench", "microbench.hip")
+MB_LIB = os.path.join(HERE, "libatdn_microbench.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -61,7 +64,20 @@ def build(force=False, jobs=None):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stdout)
+    _build_microbench()
     return LIB
+
+
+def _build_microbench():
+    if not os.path.exists(MB_SRC):
+        return
+    newest = max([_mtime(MB_SRC), _mtime(LIB)] + [_mtime(h) for h in _headers()])
+    if _mtime(MB_LIB) >= newest:
+        return
+    cmd = [HIPCC] + FLAGS + ["-shared", MB_SRC, "-o", MB_LIB, "-L" + HERE, "-latdn_hip", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on the micro-benchmark library:\n%s" % r.stdout)
 
 
 if __name__ == "__main__":

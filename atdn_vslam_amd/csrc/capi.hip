@@ -7,6 +7,7 @@
 #include "gma.h"
 #include "vae.h"
 #include "clvo_train.h"
+#include "frontend.h"
 #include "conv_sf.h"
 #include "epilogues_sf.h"
 
@@ -29,6 +30,7 @@ using namespace atdn;
 struct atdn_gma { GmaNet net; atdn_gma(int H, int W, int B, int prec) : net(H, W, B, prec) {} };
 struct atdn_clvo { ClvoNet net; atdn_clvo(int H, int W, int B) : net(H, W, B) {} };
 struct atdn_vae { VaeEncoder net; atdn_vae(int H, int W, int B) : net(H, W, B) {} };
+struct atdn_ingest { FrameIngest in; atdn_ingest(int a, int b, int c, int d, int n, int aa) : in(a, b, c, d, n, aa) {} };
 struct atdn_clvo_trainer { ClvoTrainer net; atdn_clvo_trainer(int H, int W, int B, int T) : net(H, W, B, T) {} };
 
 #define ATDN_API_BEGIN try {
@@ -41,49 +43,6 @@ struct atdn_clvo_trainer { ClvoTrainer net; atdn_clvo_trainer(int H, int W, int 
     set_last_error("unknown error");                      \
     return 1;                                             \
   }
-
-// ---- antialiased resize tables (ATen upsample_bilinear2d_aa weight computation, in fp32)
-namespace {
-struct ResizePlan { int Hin, Win, Hout, Wout; ResizeTable* ty = nullptr; ResizeTable* tx = nullptr; float* tmp = nullptr; long tmp_n = 0; };
-std::vector<ResizePlan> g_resize_plans;
-
-std::vector<ResizeTable> make_resize_table(int in, int out) {
-  std::vector<ResizeTable> tab(out);
-  const float scale = (float)in / (float)out;                  // area_pixel_compute_scale, align_corners = false
-  const float support = (scale >= 1.0f) ? 1.0f * scale : 1.0f; // interp_size (2) * 0.5 [* scale]
-  const float invscale = (scale >= 1.0f) ? 1.0f / scale : 1.0f;
-  for (int i = 0; i < out; ++i) {
-    const float center = scale * ((float)i + 0.5f);
-    int xmin = (int)(center - support + 0.5f); if (xmin < 0) xmin = 0;
-    int xmax = (int)(center + support + 0.5f); if (xmax > in) xmax = in;
-    int size = xmax - xmin;
-    ATDN_CHECK(size >= 1 && size <= RESIZE_TAPS, "resize ratio outside the supported range (down-scaling by more than 3.5x)");
-    float total = 0.f;
-    ResizeTable t{};
-    t.start = xmin; t.count = size;
-    for (int j = 0; j < size; ++j) {
-      float x = ((float)(j + xmin) - center + 0.5f) * invscale;
-      if (x < 0.f) x = -x;
-      const float w = (x < 1.0f) ? 1.0f - x : 0.0f;
-      t.w[j] = w; total += w;
-    }
-    if (total != 0.f) for (int j = 0; j < size; ++j) t.w[j] /= total;
-    tab[i] = t;
-  }
-  return tab;
-}
-ResizePlan& resize_plan(int Hin, int Win, int Hout, int Wout) {
-  for (auto& p : g_resize_plans) if (p.Hin == Hin && p.Win == Win && p.Hout == Hout && p.Wout == Wout) return p;
-  ResizePlan p{Hin, Win, Hout, Wout};
-  auto ty = make_resize_table(Hin, Hout), tx = make_resize_table(Win, Wout);
-  ATDN_HIP(hipMalloc(&p.ty, ty.size() * sizeof(ResizeTable)));
-  ATDN_HIP(hipMalloc(&p.tx, tx.size() * sizeof(ResizeTable)));
-  ATDN_HIP(hipMemcpy(p.ty, ty.data(), ty.size() * sizeof(ResizeTable), hipMemcpyHostToDevice));
-  ATDN_HIP(hipMemcpy(p.tx, tx.data(), tx.size() * sizeof(ResizeTable), hipMemcpyHostToDevice));
-  g_resize_plans.push_back(p);
-  return g_resize_plans.back();
-}
-}  // namespace
 
 // host pose algebra helpers
 template <class T>
@@ -388,18 +347,45 @@ int atdn_conv2d_nhwc(const float* src, int nimg, int H, int W, int Cin, const fl
 }
 
 int atdn_resize_frames(const float* src, int planes, int Hin, int Win, int Hout, int Wout, float* dst, void* stream) {
+  return atdn_resize_frames_mode(src, planes, Hin, Win, Hout, Wout, ATDN_RESIZE_ANTIALIAS, dst, stream);
+}
+int atdn_resize_frames_mode(const float* src, int planes, int Hin, int Win, int Hout, int Wout, int antialias, float* dst,
+                            void* stream) {
   ATDN_API_BEGIN
   ATDN_CHECK(src && dst && planes >= 1 && Hin >= 1 && Win >= 1 && Hout >= 1 && Wout >= 1, "bad argument");
-  ResizePlan& p = resize_plan(Hin, Win, Hout, Wout);
-  const long need = (Hin != Hout && Win != Wout) ? (long)planes * Hin * Wout : 0;
-  if (need > p.tmp_n) {
-    if (p.tmp) (void)hipFree(p.tmp);
-    ATDN_HIP(hipMalloc(&p.tmp, (size_t)need * sizeof(float)));
-    p.tmp_n = need;
-  }
-  launch_resize_aa(src, planes, Hin, Win, p.ty, p.tx, Hout, Wout, p.tmp, dst, (hipStream_t)stream);
+  ATDN_CHECK(antialias == 0 || antialias == 1, "antialias must be ATDN_RESIZE_BILINEAR or ATDN_RESIZE_ANTIALIAS");
+  launch_resize<float>(src, planes, Hin, Win, Hout, Wout, antialias, dst, (hipStream_t)stream);
   ATDN_API_END
 }
+int atdn_resize_frames_u8(const uint8_t* src, int planes, int Hin, int Win, int Hout, int Wout, int antialias, float* dst,
+                          void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(src && dst && planes >= 1 && Hin >= 1 && Win >= 1 && Hout >= 1 && Wout >= 1, "bad argument");
+  ATDN_CHECK(antialias == 0 || antialias == 1, "antialias must be ATDN_RESIZE_BILINEAR or ATDN_RESIZE_ANTIALIAS");
+  launch_resize<unsigned char>(src, planes, Hin, Win, Hout, Wout, antialias, dst, (hipStream_t)stream);
+  ATDN_API_END
+}
+int atdn_pad_frames(const float* src, int planes, int H, int W, int left, int right, int top, int bottom, float* dst,
+                    void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(src && dst && planes >= 1 && H >= 1 && W >= 1 && left >= 0 && right >= 0 && top >= 0 && bottom >= 0, "bad argument");
+  launch_pad_replicate(src, planes, H, W, left, right, top, bottom, dst, (hipStream_t)stream);
+  ATDN_API_END
+}
+int atdn_ingest_create(atdn_ingest** out, int Hin, int Win, int Hout, int Wout, int max_frames, int antialias) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(out, "null out pointer");
+  ATDN_CHECK(antialias == 0 || antialias == 1, "antialias must be ATDN_RESIZE_BILINEAR or ATDN_RESIZE_ANTIALIAS");
+  *out = new atdn_ingest(Hin, Win, Hout, Wout, max_frames, antialias);
+  ATDN_API_END
+}
+int atdn_ingest_frames_u8(atdn_ingest* h, const uint8_t* host_frames, int n_frames, float* dst, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->in.ingest(host_frames, n_frames, dst, (hipStream_t)stream);
+  ATDN_API_END
+}
+void atdn_ingest_destroy(atdn_ingest* h) { delete h; }
 
 int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
                         const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, float* dst,

@@ -1,8 +1,8 @@
-// Split-f16 halo-patch convolution, generation 6: weights never touch LDS.
-//
-// Generations 2-5 stream a [BN][32-chunk] weight tile through LDS every (chunk, tap) step and pay one workgroup
-// barrier per step for it; with two waves per SIMD that lock-step is what holds the matrix pipe at ~40 % busy
-// (tools/microbench_conv.py: registers, LDS-DMA, two- and three-deep rings all land within 3 % of each other).
+// Split-f16 halo-patch convolution: an M tile is a TH x TW block of OUTPUT pixels of one image; per 32-channel
+// chunk the (TH+KH-1) x (TW+KW-1) input patch (true zero padding included) is staged in LDS ONCE and all KH*KW taps
+// read it at an address offset. Weights never touch LDS: earlier generations (round 1, since removed) streamed a
+// [BN][32-chunk] weight tile through LDS every (chunk, tap) step and paid one workgroup barrier per step for it;
+// with two waves per SIMD that lock-step held the matrix pipe at ~40 % busy whichever way the tile reached LDS.
 // Here every wave loads ITS OWN weight fragments straight from global memory (L2/L1-resident: the whole layer is
 // 1-2 MB) into registers in MFMA operand layout, one step ahead of use:
 //   lane (r = lane & 31, h = lane >> 5) holds, for output channel n0 + (wn*TN + j)*32 + r and K sub-step t,
@@ -19,9 +19,31 @@
 // classic orientation.
 #pragma once
 #include <type_traits>
-#include "conv_sf2.h"
+#include "conv_sf.h"
 
 namespace atdn {
+
+struct Conv2Geom {
+  const float* src0; const float* src1;
+  long sb0, sb1;
+  int ld0, ld1, C0, C1;
+  int H, W, Ho, Wo;
+  int KH, KW, padH, padW;
+  int PH, PW;            // patch size in pixels
+  int tiles_x, tiles_y;  // per image
+  int nimg, ntile_n;
+  const float* w; int ldw; int N;
+  float wscale;
+  // normalise-on-load (NORM): src0 is RAW fp32 [pix][C0] and the patch loader applies
+  // relu((x - in_mean[img][c]) * in_rstd[img][c]) before splitting to sf (InstanceNorm + ReLU of the producer)
+  const float* in_mean; const float* in_rstd;
+};
+
+// shapes the halo-patch kernel serves: stride-1 3x3 / 1x5 / 5x1 convolutions with shared weights
+inline bool conv_halo_eligible(const ConvShape& s) {
+  if (s.stride != 1 || s.wb != 0) return false;
+  return (s.KH == 3 && s.KW == 3) || (s.KH == 1 && s.KW == 5) || (s.KH == 5 && s.KW == 1);
+}
 
 // which kernel shapes an epilogue is instantiated for on this path (bit 0: 3x3, bit 1: 1x5 and 5x1)
 template <class E, class = void> struct epi_gen6 : std::integral_constant<int, 0> {};
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
     }
     return;
   }
-  // ---- epilogue (as conv_sf2.h, TM x TN tiles per wave)
+  // ---- pixel-major epilogue (TM x TN tiles per wave)
   // per-column constants once per wave, before any store (a load issued after a store waits for that store too)
   typename EpiCol<Epi>::type colj[TN];
   float biasj[TN];
@@ -487,7 +509,7 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
 // Picks the block shape for N output channels and launches the fragment-major-weight kernel: 8x16-pixel tiles, or
 // 12x16 for the 64- and 96-wide blocks (3 MFMA row tiles per wave: less halo, fewer tile seams; measured
 // 7-10 % faster on the encoder shapes and on N = 192) when the taller tiles pad the image no worse and still
-// cover the chip. Returns false when this path does not serve the shape (the caller falls back to generation 4).
+// cover the chip. Returns false when this path does not serve the shape (the caller falls back to the plain implicit GEMM).
 template <int KH, int KW, class Epi, bool FAST>
 inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out, int* th_out) {
   const int Ho = conv_out(s.H, s.KH, 1, s.padH), Wo = conv_out(s.W, s.KW, 1, s.padW);

@@ -25,9 +25,9 @@ struct EpiBias {
     if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
     dst[(long)img * ob + (long)m * ld + n] = v * scale;
   }
-  // channel-vector form (conv_sf6.h): channels n..n+3 of pixel m; 3x3 halo kernels only
+  // channel-vector form (conv_sf6.h): channels n..n+3 of pixel m; 3x3 and 1x5 / 5x1 halo kernels
   static constexpr bool kVec4 = true;
-  static constexpr int kGen6 = 1;
+  static constexpr int kGen6 = 3;
   // bias of channels n..n+3, fetched once per channel run by the kernel (see SfBias)
   __device__ __forceinline__ float4 bias4(int n) const {
     return bias ? make_float4(bias[n], bias[n + 1], bias[n + 2], bias[n + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);

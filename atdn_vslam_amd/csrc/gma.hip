@@ -108,6 +108,7 @@ void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
   ATDN_CHECK(ready_ && B >= 1 && B <= maxB && reps >= 1, "bad profile request");
   for (int i = 0; i < ST_COUNT; ++i) ms[i] = 0.f;
   seq_ = 0;
+  last_frame_ = 0;   // fmap_ is overwritten: a continued sequence call must not read it
   for (int r = 0; r < reps; ++r) {
     Timer t;
     timer_ = &t;
@@ -142,6 +143,8 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
 }
 
 GmaNet::~GmaNet() {
+  // a graph replay or kernel of this handle may still be running on the caller's stream
+  (void)hipDeviceSynchronize();
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
   DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
@@ -240,6 +243,7 @@ void GmaNet::finalize() {
                       &rh_, &fh_, &mask_, &coords1_, &flow4_};
   for (auto* b : all) ws_bytes_ += (size_t)b->n * sizeof(float);
   (void)zero_line();  // allocate the shared zero line now: never inside a stream capture
+  sf_counter_attach(); // saturation counter of the sf format (sf.h): attached before the first launch
   ATDN_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
   ready_ = true;
 }
@@ -320,6 +324,7 @@ void GmaNet::iteration(int B, hipStream_t st) {
   // -- motion encoder (update.py:76-84); torch.cat is realised by writing channel slices
   ConvShape s = conv_shape(convc1_, corrfeat_.p, CORR_LD, (long)N * CORR_LD, B, H8, W8, 1, 0, 0);
   conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{convc1_.b, cor1_.p, (long)N * 256, 256, 1.f}, st);
+  mark(ST_CONVC1, st);
   s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256, 1.f}, st);
   s = conv_shape(convf1_, flow4_.p, 4, (long)N * 4, B, H8, W8, 1, 3, 3);
@@ -334,6 +339,7 @@ void GmaNet::iteration(int B, hipStream_t st) {
   // -- global motion aggregation (gma.py:102-115): v^T, then attn @ v with the residual fused
   s = conv_shape(to_v_, mf, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
   conv_dispatch<MODE_TAP>(s, EpiStoreT{vT_.p, (long)128 * ldN, ldN}, st);
+  mark(ST_AGG_VT, st);
   ConvShape a;
   a.src0 = attn_.p; a.ld0 = ldN; a.sb0 = (long)N * ldN; a.C0 = ldN; a.H = 1; a.W = N;
   a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
@@ -394,6 +400,7 @@ void GmaNet::run_body(int B, int iters, hipStream_t st) {
   q.src0 = qk_.p; q.ld0 = 256; q.sb0 = (long)N * 256; q.C0 = 128; q.H = 1; q.W = N;
   q.w = qk_.p + 128; q.wb = (long)N * 256; q.ldw = 256; q.N = N; q.nimg = B;
   conv_dispatch<MODE_TAP>(q, EpiScale{1.0f, attn_.p, (long)N * ldN, ldN}, st);
+  mark(ST_ATTN_LOGITS, st);
   launch_softmax_rows(attn_.p, (long)B * N, N, ldN, st);
   mark(ST_ATTN, st);
 
@@ -501,6 +508,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
 
   ConvShape s = conv_shape(convc1_, corrfeat_.p, CORR_LD, (long)N * CORR_LD, B, H8, W8, 1, 0, 0);
   conv_sf_dispatch(s, convc1_.wscale, SfBias<ACT_RELU>{convc1_.b, cor1_.p, (long)N * 256, 256}, st);
+  mark(ST_CONVC1, st);
   s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
   static const bool small = !(getenv("ATDN_SMALL_CONVS") && getenv("ATDN_SMALL_CONVS")[0] == '0');
@@ -523,6 +531,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   v.src0 = to_v_.w; v.ld0 = 128; v.sb0 = 0; v.C0 = 128; v.H = 1; v.W = 128;
   v.w = mf; v.wb = (long)N * XLD; v.ldw = XLD; v.N = N; v.nimg = B;
   conv_sf_dispatch(v, to_v_.wscale, SfBias<ACT_NONE>{nullptr, vT_.p, (long)128 * ldN, ldN}, st);
+  mark(ST_AGG_VT, st);
   ConvShape a;
   a.src0 = attn_.p; a.ld0 = ldN; a.sb0 = (long)N * ldN; a.C0 = ldN; a.H = 1; a.W = N;
   a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
@@ -596,6 +605,7 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   q.src0 = qk_.p; q.ld0 = 256; q.sb0 = (long)N * 256; q.C0 = 128; q.H = 1; q.W = N;
   q.w = qk_.p + 128; q.wb = (long)N * 256; q.ldw = 256; q.N = N; q.nimg = B;
   conv_sf_dispatch(q, 1.f, EpiScale{1.0f, sim_.p, (long)N * ldN, ldN}, st);
+  mark(ST_ATTN_LOGITS, st);
   launch_softmax_rows_sf(sim_.p, attn_.p, (long)B * N, N, ldN, st);
   mark(ST_ATTN, st);
 
@@ -654,11 +664,12 @@ void GmaNet::forward_sequence(const float* frames, int B, int iters, const float
     seq_ = 1;
   }
   // frames 0..B-1 are the first images, frame B the last second image: img4 = [frame 0 .. frame B]
+  last_frame_ = 0;   // stays 0 if anything below throws: the next call cannot continue from a half-launched clip
   launch_prep_images(frames, frames + (long)B * frame, B, H, W, img4_.p, st, 1);
-  last_frame_ = B;
   launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
   launch_body(B, iters, st);
   launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
+  last_frame_ = B;
 }
 
 void GmaNet::launch_body(int B, int iters, hipStream_t st) {
@@ -678,6 +689,7 @@ void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const
   ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
   ATDN_CHECK(im1 && im2 && flow_low && flow_up, "null tensor");
   seq_ = 0;
+  last_frame_ = 0;   // pair mode overwrites fmap_: a later continued sequence call fails loudly instead of reading it
   launch_prep_images(im1, im2, B, H, W, img4_.p, st, B);
   if (precision >= 1) launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
   else launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
@@ -687,6 +699,11 @@ void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const
 
 long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_t st) {
   const std::string k(name);
+  if (k == "sf_clamped") {   // values the split-f16 format had to clamp (|x| > 65504 or NaN) since the last read
+    ATDN_CHECK(capacity >= 1, "sf_clamped needs room for one float");
+    host[0] = (float)sf_counter_read_reset(st);
+    return 1;
+  }
   const DeviceBuf* b = nullptr;
   if (k == "fmap") b = &fmap_; else if (k == "pyr0") b = &pyr_[0]; else if (k == "pyr1") b = &pyr_[1];
   else if (k == "pyr2") b = &pyr_[2]; else if (k == "pyr3") b = &pyr_[3]; else if (k == "net") b = &h_[0];

@@ -95,15 +95,6 @@ void launch_softmax_rows_sf(const float* x, float* y, long rows, int n, int ld, 
 void launch_init_coords_sf(const float* flow_init, int B, int H8, int W8, float* coords1, float* flow4, float* x,
                            int ldx, int cflow, hipStream_t st);
 
-// Antialiased bilinear resize of NCHW planes (torchvision's tensor resize = F.interpolate(bilinear, antialias=True,
-// align_corners=False), as NeuralSLAM applies it to every frame, neural_slam.py:198,220). Separable: per output
-// column/row a window start and up to RESIZE_TAPS normalised triangle weights, computed on the host in fp32 exactly
-// like ATen's _upsample_bilinear2d_aa (HelperInterpLinear::compute_indices_weights_aa).
-constexpr int RESIZE_TAPS = 8;
-struct ResizeTable { int start; int count; float w[RESIZE_TAPS]; };
-void launch_resize_aa(const float* src, int planes, int Hin, int Win, const ResizeTable* ty, const ResizeTable* tx,
-                      int Hout, int Wout, float* tmp, float* dst, hipStream_t st);
-
 void launch_fill(float* p, long n, float v, hipStream_t st);
 
 }  // namespace atdn

@@ -599,50 +599,6 @@ void launch_mlp_heads(const float* h2, int B, MlpHead rot, MlpHead tr, float* ro
   ATDN_HIP(hipGetLastError());
 }
 
-// one pass along x (axis == 1) or y (axis == 0); dst has the resized extent on that axis
-__global__ void resize_aa_kernel(const float* __restrict__ src, const ResizeTable* __restrict__ tab, int planes, int Hin,
-                                 int Win, int Hout, int Wout, int axis, float* __restrict__ dst) {
-  const long total = (long)planes * Hout * Wout;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % Wout);
-    const long r = i / Wout;
-    const int y = (int)(r % Hout);
-    const long pl = r / Hout;
-    const ResizeTable t = tab[axis ? x : y];
-    const float* s = src + pl * (long)Hin * Win;
-    float acc = 0.f;
-    if (axis) {
-      const float* row = s + (long)y * Win + t.start;
-      for (int k = 0; k < t.count; ++k) acc += t.w[k] * row[k];
-    } else {
-      const float* col = s + (long)t.start * Win + x;
-      for (int k = 0; k < t.count; ++k) acc += t.w[k] * col[(long)k * Win];
-    }
-    dst[i] = acc;
-  }
-}
-void launch_resize_aa(const float* src, int planes, int Hin, int Win, const ResizeTable* ty, const ResizeTable* tx,
-                      int Hout, int Wout, float* tmp, float* dst, hipStream_t st) {
-  // ATen's separable antialias kernel interpolates the LAST dimension first (horizontal), then vertical
-  const long n1 = (long)planes * Hin * Wout, n2 = (long)planes * Hout * Wout;
-  const bool need_x = Win != Wout, need_y = Hin != Hout;
-  const float* cur = src;
-  if (need_x) {
-    float* out = need_y ? tmp : dst;
-    hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)std::min<long>(cdivl(n1, 256), 8192)), dim3(256), 0, st, cur, tx,
-                       planes, Hin, Win, Hin, Wout, 1, out);
-    ATDN_HIP(hipGetLastError());
-    cur = out;
-  }
-  if (need_y) {
-    hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)std::min<long>(cdivl(n2, 256), 8192)), dim3(256), 0, st, cur, ty,
-                       planes, Hin, Wout, Hout, Wout, 0, dst);
-    ATDN_HIP(hipGetLastError());
-  } else if (!need_x) {
-    ATDN_HIP(hipMemcpyAsync(dst, src, (size_t)n2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-  }
-}
-
 const float* zero_line() {
   static float* z = nullptr;
   if (!z) {
@@ -666,7 +622,45 @@ void launch_fill(float* p, long n, float v, hipStream_t st) {
 
 // ================================================================== split-f16 ("sf") variants
 #include "sf.h"
+#include <mutex>
+#include <vector>
 namespace atdn {
+
+// ---- saturation counter of the sf format (sf.h)
+namespace {
+std::vector<const void*>& sf_counter_symbols() { static std::vector<const void*> v; return v; }
+std::mutex g_sf_counter_mutex;
+struct SfCounterDev { int dev; unsigned int* ptr; };
+std::vector<SfCounterDev> g_sf_counters;
+unsigned int* sf_counter_for_current_device(bool create) {
+  int dev = 0;
+  ATDN_HIP(hipGetDevice(&dev));
+  for (auto& c : g_sf_counters) if (c.dev == dev) return c.ptr;
+  if (!create) return nullptr;
+  unsigned int* p = nullptr;
+  ATDN_HIP(hipMalloc(&p, sizeof(unsigned int)));
+  ATDN_HIP(hipMemset(p, 0, sizeof(unsigned int)));
+  for (const void* sym : sf_counter_symbols())
+    ATDN_HIP(hipMemcpyToSymbol(sym, &p, sizeof(p), 0, hipMemcpyHostToDevice));
+  ATDN_HIP(hipDeviceSynchronize());
+  g_sf_counters.push_back({dev, p});
+  return p;
+}
+}  // namespace
+void sf_counter_register(const void* symbol) { sf_counter_symbols().push_back(symbol); }
+void sf_counter_attach() {
+  std::lock_guard<std::mutex> lock(g_sf_counter_mutex);
+  (void)sf_counter_for_current_device(true);
+}
+unsigned int sf_counter_read_reset(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_sf_counter_mutex);
+  unsigned int* p = sf_counter_for_current_device(true);
+  unsigned int v = 0;
+  ATDN_HIP(hipStreamSynchronize(st));
+  ATDN_HIP(hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost));
+  ATDN_HIP(hipMemset(p, 0, sizeof(v)));
+  return v;
+}
 
 // one thread = 4 consecutive channels of one pixel: 16-B fp32 read, two 8-B half stores (hi plane, lo plane)
 __device__ __forceinline__ void sf_store4(float* dst, long i4, float4 v) {

@@ -15,7 +15,26 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct SfPair { _Float16 hi, lo; };
 
+// Saturation counter. The format clamps at +-65504 (max finite f16): a value beyond that no longer round-trips, and a
+// network whose activations get there (a hot BatchNorm-folded channel of a real checkpoint, say) must be noticed, not
+// silently wrong. Every sf_split that clamps (or sees a NaN) bumps a device counter; atdn_gma_debug_read("sf_clamped")
+// returns and resets it. The library is built without relocatable device code, so each translation unit carries its own
+// pointer to the one counter; sf_counter_attach() (kernels.hip) points them all at it before the first launch.
+namespace { __device__ unsigned int* sf_clamp_counter_tu_ = nullptr; }
+void sf_counter_register(const void* symbol);
+namespace {
+struct SfCounterRegistration { SfCounterRegistration() { sf_counter_register(HIP_SYMBOL(sf_clamp_counter_tu_)); } };
+static SfCounterRegistration sf_counter_registration_;
+}
+// points every translation unit's pointer at one device counter (idempotent per device); read_reset returns the count
+void sf_counter_attach();
+unsigned int sf_counter_read_reset(hipStream_t st);
+
 __device__ __forceinline__ SfPair sf_split(float v) {
+  if (__builtin_expect(!(fabsf(v) <= 65504.f), 0)) {   // clamped value or NaN: rare, counted
+    unsigned int* c = sf_clamp_counter_tu_;
+    if (c) atomicAdd(c, 1u);
+  }
   v = fminf(fmaxf(v, -65504.f), 65504.f);
   SfPair p;
   p.hi = (_Float16)v;

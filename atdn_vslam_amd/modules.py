@@ -73,6 +73,18 @@ class _NativeModule(nn.Module):
             ent[2](ent[0])
         self._handles = {}
 
+    @staticmethod
+    def _key(H, W):
+        """Native handles own weights and workspace on ONE device: keyed by (device index, H, W), so a module moved
+        with .to(other_gpu) builds a new handle there instead of launching on the old device's memory."""
+        return (torch.cuda.current_device(), H, W)
+
+    def _apply(self, fn, *args, **kw):
+        # .to() / .cuda() / .float(): parameters move, handles built from the old ones are stale
+        out = super()._apply(fn, *args, **kw)
+        self._drop_handles()
+        return out
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         # DataParallel checkpoints carry a "module." prefix (neural_slam.py:51-52)
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
@@ -114,7 +126,7 @@ class RAFTGMA(_NativeModule):
         self.att.pos_emb.rel_ind.copy_(d + n - 1)
 
     def _handle(self, H, W, B):
-        key = (H, W)
+        key = self._key(H, W)
         fp = self._fingerprint()
         ent = self._handles.get(key)
         if ent is not None and (ent[1] != fp or ent[3] < B):
@@ -186,7 +198,7 @@ class RAFTGMA(_NativeModule):
     def debug_read(self, name, shape, H, W):
         """Copy an internal activation of the (H, W) handle to a CPU tensor (parity tests)."""
         out = torch.empty(shape, dtype=torch.float32)
-        h = self._handles[(H, W)][0]
+        h = self._handles[self._key(H, W)][0]
         n = _lib.lib().atdn_gma_debug_read(h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), _stream())
         if n < 0:
             _lib.check(1)
@@ -234,7 +246,7 @@ class ATDNVO(_NativeModule):
         return self
 
     def _handle(self, H, W, B):
-        key = (H, W)
+        key = self._key(H, W)
         fp = self._fingerprint()
         ent = self._handles.get(key)
         if ent is not None and (ent[1] != fp or ent[3] < B):
@@ -307,7 +319,7 @@ class MappingVAE(_NativeModule):
         return super().load_state_dict(sd, strict=strict, **kw)
 
     def _handle(self, H, W, B):
-        key = (H, W)
+        key = self._key(H, W)
         fp = self._fingerprint()
         ent = self._handles.get(key)
         if ent is not None and (ent[1] != fp or ent[3] < B):

@@ -15,23 +15,67 @@ from .sharding import sharded_odometry
 SLAM_SIZE = (376, 1232)  # neural_slam.py:198
 
 
-def resize_frames(frames, size=SLAM_SIZE):
-    """torchvision's tensor resize (bilinear, antialias) as NeuralSLAM applies it (neural_slam.py:198,220), on the
-    GPU through libatdn_hip (atdn_resize_frames)."""
+def resize_frames(frames, size=SLAM_SIZE, antialias=True):
+    """torchvision's tensor resize as NeuralSLAM applies it (neural_slam.py:198,220), on the GPU through libatdn_hip:
+    bilinear, align_corners=False; `antialias=True` is what torchvision >= 0.17 does for tensors, `False` what older
+    versions do (the reference pins none). uint8 frames are converted inside the resize kernel."""
     import ctypes as C
     from . import _lib
     if tuple(frames.shape[-2:]) == tuple(size):
         return frames
     if not frames.is_cuda:
         raise RuntimeError("resize_frames: the MI355X path needs tensors on a HIP device")
-    x = frames.float().contiguous()
+    u8 = frames.dtype == torch.uint8
+    x = frames.contiguous() if u8 else frames.float().contiguous()
     out = torch.empty(tuple(x.shape[:-2]) + tuple(size), dtype=torch.float32, device=x.device)
     planes = int(x.numel() // (x.shape[-2] * x.shape[-1]))
+    fn = _lib.lib().atdn_resize_frames_u8 if u8 else _lib.lib().atdn_resize_frames_mode
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().atdn_resize_frames(C.c_void_p(x.data_ptr()), planes, x.shape[-2], x.shape[-1], size[0],
-                                                 size[1], C.c_void_p(out.data_ptr()),
-                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        _lib.check(fn(C.c_void_p(x.data_ptr()), planes, x.shape[-2], x.shape[-1], size[0], size[1], int(bool(antialias)),
+                      C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
+
+
+class FrameIngest:
+    """uint8 camera frames in host memory -> fp32 frames at the network size on the device (atdn_ingest_*): async H2D
+    on the handle's copy stream into alternating staging slots, resize fused with the uint8 -> fp32 conversion on the
+    current stream. Replaces `im.to(device)` + `TF.resize` of neural_slam.py:197-199,219-221 for whole clips."""
+
+    def __init__(self, in_size, max_frames, size=SLAM_SIZE, antialias=True, device="cuda:0"):
+        import ctypes as C
+        from . import _lib
+        self.device = torch.device(device)
+        self.in_size, self.size, self.max_frames = tuple(in_size), tuple(size), int(max_frames)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().atdn_ingest_create(C.byref(self._h), self.in_size[0], self.in_size[1], self.size[0],
+                                                     self.size[1], self.max_frames, int(bool(antialias))))
+
+    def __call__(self, host_frames):
+        """host_frames [n,3,Hin,Win] uint8 CPU tensor (pinned for an asynchronous copy) -> [n,3,H,W] fp32 on the device."""
+        import ctypes as C
+        from . import _lib
+        if host_frames.is_cuda or host_frames.dtype != torch.uint8 or host_frames.dim() != 4 or host_frames.shape[1] != 3 \
+                or tuple(host_frames.shape[-2:]) != self.in_size:
+            raise RuntimeError("FrameIngest expects uint8 host frames [n,3,%d,%d], got %s %s on %s"
+                               % (self.in_size + (tuple(host_frames.shape), host_frames.dtype, host_frames.device)))
+        x = host_frames.contiguous()
+        n = x.shape[0]
+        out = torch.empty((n, 3) + self.size, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().atdn_ingest_frames_u8(self._h, C.c_void_p(x.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._keep = x   # the copy is asynchronous: the host buffer must outlive it
+        return out
+
+    def __del__(self):
+        try:
+            from . import _lib
+            if self._h:
+                _lib.lib().atdn_ingest_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class OdometryPipeline:

@@ -107,9 +107,11 @@ class NeuralSLAM:
             os.makedirs(os.path.join(self._base, "rgb"), exist_ok=True)
             for f in glob.glob(os.path.join(self._base, "rgb", "*")):
                 os.remove(f)
-            poses_path = os.path.join(self._base, "poses.pth")
-            if os.path.exists(poses_path):
-                os.remove(poses_path)
+            # a cold start owns the directory: poses and map weights of an earlier session go too
+            for stale in ("poses.pth", "MappingVAE_weights.pth"):
+                stale_path = os.path.join(self._base, stale)
+                if os.path.exists(stale_path):
+                    os.remove(stale_path)
             self._mode = "idle"
 
     # ------------------------------------------------------------------ state machine
@@ -120,18 +122,20 @@ class NeuralSLAM:
             print("Odometry cannot be performed in current SLAM stage")
 
     def end_odometry(self, mapping_weights=None):
-        """Persist the keyframe poses (`poses.pth`, [K,12]) and move to mapping; with trained MappingVAE weights
-        (argument or `<keyframes_path>/MappingVAE_weights.pth`) embed every keyframe and enter relocalization."""
+        """Persist the keyframe poses (`poses.pth`, [K,12]), create the map (train the MappingVAE on the keyframes, as
+        neural_slam.py:160 does; skipped only when `mapping_weights` is given explicitly), embed every keyframe and
+        enter relocalization."""
         if self._mode == "odometry" and len(self._keyframes) > 0:
             poses = torch.stack([kf.pose.flatten()[:12] for kf in self._keyframes], dim=0)
             torch.save(poses, os.path.join(self._base, "poses.pth"))
             self._mode = "mapping"
             default = os.path.join(self._base, "MappingVAE_weights.pth")
-            if mapping_weights is None and os.path.exists(default):
-                mapping_weights = default
             if mapping_weights is None:
-                # map creation (neural_slam.py:305-352): the auto-encoder is trained on the keyframes with stock
-                # PyTorch, as in the reference; the embedding it yields runs on the HIP path again
+                # map creation (neural_slam.py:160,305-352): the reference ALWAYS trains the auto-encoder on the current
+                # keyframes here and overwrites MappingVAE_weights.pth — a file left in the directory by an earlier
+                # session belongs to another environment and is never picked up. Training runs on stock PyTorch, as in
+                # the reference; the embedding it yields runs on the HIP path again. Only an explicit `mapping_weights`
+                # argument skips the training.
                 from .mapping import create_map
                 create_map(self._base, device=self._device, **self._map_options)
                 mapping_weights = default

@@ -75,7 +75,25 @@ class InputPadder:
     def pad(self, *inputs):
         if not any(self._pad):  # 376x1232: nothing to pad (neural_slam.py:54) — skip the copy
             return list(inputs)
-        return [torch.nn.functional.pad(x, self._pad, mode="replicate") for x in inputs]
+        return [self._pad_one(x) for x in inputs]
+
+    def _pad_one(self, x):
+        """F.pad(x, pad, mode="replicate") (utils.py:19-20). Device tensors go through libatdn_hip's pad kernel; host
+        tensors (the reference pads on whatever device the frame is on) use torch."""
+        if not x.is_cuda:
+            return torch.nn.functional.pad(x, self._pad, mode="replicate")
+        import ctypes as C
+        from . import _lib
+        l, r, t, b = self._pad
+        src = x.float().contiguous()
+        H, W = src.shape[-2:]
+        out = torch.empty(tuple(src.shape[:-2]) + (H + t + b, W + l + r), dtype=torch.float32, device=src.device)
+        planes = int(src.numel() // (H * W))
+        with torch.cuda.device(src.device):
+            _lib.check(_lib.lib().atdn_pad_frames(C.c_void_p(src.data_ptr()), planes, H, W, l, r, t, b,
+                                                  C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
 
     def unpad(self, x):
         ht, wd = x.shape[-2:]

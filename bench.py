@@ -8,7 +8,8 @@ One "step" = one pass of the hot path over one batch of synthetic frame pairs pe
 (12 GRU iterations, 376x1232 after the reference's resize of 376x1241 KITTI frames) -> CLVO CNN
 encoder -> 512-d feature. After the K steps the timed region also holds the sequence tail: ONE RCCL
 all-gather of the features and the ordered LSTM/MLP scan + rel2abs that turns them into the 6-DoF
-trajectory (every rank ends up with all N*K*B poses). Frames are resident in HBM before timing starts.
+trajectory (every rank ends up with all N*K*B poses). The uint8 frames are resident in HBM before timing starts
+(`value`); a second timed pass ingests them from pinned host memory instead (`h2d_inclusive`, never the headline).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
 """
@@ -27,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 from atdn_vslam_amd import synthetic as syn  # noqa: E402
 from atdn_vslam_amd import transforms  # noqa: E402
-from atdn_vslam_amd.pipeline import OdometryPipeline, resize_frames  # noqa: E402
+from atdn_vslam_amd.pipeline import FrameIngest, OdometryPipeline, resize_frames  # noqa: E402
 from atdn_vslam_amd.sharding import gather_features  # noqa: E402
 
 H_KITTI, W_KITTI = 376, 1241
@@ -36,30 +37,64 @@ N8 = (H // 8) * (W // 8)
 ITERS = 12
 # Algorithmic work per frame pair (SURVEY §8d / BASELINE.md §3): mask head + upsampling counted once.
 FLOP_PER_PAIR = 0.951e12
-# Dominant kernel: the fused z|r convolution of the separable ConvGRU (1x5 / 5x1, 256 output channels) over the
-# 384 iteration-dependent input channels [h | motion | motion_global] (the 128 context channels are hoisted out
-# of the loop): 2 * N8 * 256 * (5*384) FLOP per pair and launch, 24 launches per forward.
-GRU_ZR_FLOP = 2.0 * N8 * 256 * 1920
-LOOKUP_BYTES = N8 * (400 + 324) * 4.0  # <=400 cells read + 324 samples written per source pixel (fp32)
+# ... of which the path no longer EXECUTES 70.6 GMAC per pair: one feature-network pass per pair (shared frames, 31.5 GMAC)
+# and the context-channel part of the ConvGRU convolutions in iterations 2..12 (39.1 GMAC, computed once per pair)
+FLOP_PER_PAIR_EXECUTED = FLOP_PER_PAIR - 2.0 * (31.48e9 + 39.13e9)
+LOOKUP_BYTES = N8 * (400 + 324) * 4.0  # <=400 cells read + 324 samples written per source pixel (fp32), SURVEY §8d
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: f16/bf16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_table(stages, B):
+    """Per-kernel rows from the SAME-RUN per-stage HIP-event timing (atdn_gma_profile; stages that hold launches of one
+    kernel only): name, rocprof name fragment, launches per forward, us per launch, bounding roofline, algorithmic bytes
+    or FLOP per launch (SURVEY §8d figures x B pairs), achieved, fraction of the gfx950 peak. Sorted by time per forward."""
+    nn = float(N8) * N8
+    spec = [
+        # (stage, label, rocprof fragment, launches, bound, algorithmic work per launch)
+        ("aggregate", "attention x V (gma.py:102-115): streams the [N x N] attention matrix of every pair once",
+         "SfAggregate", ITERS, "hbm", nn * 4.0 * B),
+        ("gru_zr", "fused z|r ConvGRU convolution 1x5 / 5x1 (update.py:48-63), K = 5*384",
+         "SfGruZR", 2 * ITERS, "mfma", 2.0 * N8 * 256 * 1920 * B),
+        ("gru_q", "q ConvGRU convolution 1x5 / 5x1, K = 5*384", "SfGruQ", 2 * ITERS, "mfma", 2.0 * N8 * 128 * 1920 * B),
+        ("lookup", "correlation-pyramid lookup (corr.py:32-53)", "lookup", ITERS, "hbm", LOOKUP_BYTES * B),
+        ("convc1", "convc1 1x1 324->256 behind the lookup (update.py:76-78)", "SfBias<1>", ITERS, "mfma", 2.0 * N8 * 256 * 324 * B),
+        ("corr", "all-pairs correlation volume (corr.py:55-63), K = 256", "EpiScale", 1, "mfma", 2.0 * nn * 256 * B),
+        ("attention", "row softmax of the attention logits (gma.py:74)", "softmax_rows", 1, "hbm", 2.0 * nn * 4.0 * B),
+    ]
+    rows = []
+    for stage, label, frag, launches, bound, work in spec:
+        ms = stages.get(stage, 0.0)
+        if ms <= 0.0:
+            continue
+        us = ms * 1e3 / launches
+        if bound == "hbm":
+            ach, peak, unit = work / (us * 1e-6) / 1e9, PEAK_HBM_GBS, "GB/s"
+        else:
+            ach, peak, unit = work / (us * 1e-6) / 1e12, PEAK_F16_MFMA_TFLOPS, "TFLOP/s"
+        rows.append({"stage": stage, "kernel": label, "rocprof_name_contains": frag, "launches_per_forward": launches,
+                     "us_per_launch": round(us, 2), "ms_per_forward": round(ms, 4), "bound": bound,
+                     "algorithmic_per_launch": work, "algorithmic_unit": "bytes" if bound == "hbm" else "FLOP",
+                     "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
+    rows.sort(key=lambda r: -r["ms_per_forward"])
+    return rows
+
+
 def pmc_traffic(kernel_fragment, batch):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, collected in separate --pmc runs at B = 4)."""
+    """HBM-side bytes per launch of a kernel from the newest committed rocprofv3 PMC passes (profiles/*_pmc.json:
+    2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs). Returns (bytes, file) or (None, None): NOT measured in this run."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not files:
-        return None
+        return None, None
     data = json.load(open(files[-1]))
     if data.get("_batch") != batch:
-        return None
+        return None, None
     for name, v in data.items():
         if kernel_fragment in name:
-            return v["hbm_bytes_per_launch"]
-    return None
+            return v["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
+    return None, None
 
 
 def usable_cores():
@@ -112,6 +147,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frame pairs per step per GPU")
     ap.add_argument("--streams", type=int, default=2, help="independent clips in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed pass that ingests host frames")
     ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f16", "f32"],
                     help="arithmetic of the flow network; the headline is split_f16 (fp32-grade). f16 = fast mode")
     args = ap.parse_args()
@@ -133,36 +169,35 @@ def main():
     # S pipelines on S streams: consecutive steps (clips) overlap, which fills the tails of each other's kernels
     S = max(1, args.streams)
     pipes = [OdometryPipeline(gsd, hsd, device=dev, max_batch=B, iters=ITERS, precision=args.precision) for _ in range(S)]
+    ingests = [FrameIngest((H_KITTI, W_KITTI), max_frames=B + 1, device=dev) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     pipe = pipes[0]
-    # synthetic clip, different per rank (each rank owns its own stretch of the sequence); resized once, resident
+    # Synthetic uint8 camera frames (what a KITTI png decodes to), different per rank (each rank owns its own stretch of
+    # the sequence). Every pipeline walks its own long sequence clip by clip; the sequence is a 2B+1-frame clip played
+    # forwards and backwards, so consecutive frames are always neighbours and each frame of the sequence passes through
+    # the feature network once (continued clips reuse the shared frame). Laid out in sequence order, once in pinned
+    # host memory (the H2D-inclusive leg) and once resident in HBM (the headline leg).
     clip = 2 * B + 1
-    raw = torch.from_numpy(syn.make_frames(clip, H_KITTI, W_KITTI, seed=100 + rank)).to(dev)  # 376x1241, resident
+    period = 2 * (clip - 1)
+    base = torch.from_numpy(syn.make_frames(clip, H_KITTI, W_KITTI, seed=100 + rank)).round().clamp(0, 255).to(torch.uint8)
+    order = [(k if k < clip else period - k) for k in range(period)] + list(range(B + 1))
+    seq_host = base[order].contiguous().pin_memory()      # [period + B + 1, 3, 376, 1241] uint8
+    seq_dev = seq_host.to(dev)
     torch.cuda.synchronize()
 
-    # Every pipeline walks its own long sequence clip by clip. The sequence is the resident clip played forwards and
-    # backwards (frame k of the sequence = raw[triangle(k)]), so consecutive frames are always neighbours of the clip
-    # and each frame of the sequence passes through the feature network once (continued clips reuse the shared frame).
-    period = 2 * (clip - 1)
     calls = [0] * S
-    idx_cache = {}
 
-    def tri(k):
-        k %= period
-        return k if k < clip else period - k
-
-    def step(i, feats, slot=None):
-        nonlocal calls
+    def step(i, feats, slot=None, host=False):
         p = i % S
         j = calls[p]
         calls[p] += 1
         slot = i if slot is None else slot
         key = ((j + p) * B) % period
-        if key not in idx_cache:
-            idx_cache[key] = torch.tensor([tri(key + t) for t in range(B + 1)], device=dev)
-        idx = idx_cache[key]
         with torch.cuda.stream(streams[p]):
-            frames = resize_frames(raw[idx])             # the reference's per-frame resize to 376x1232, on the GPU
+            if host:   # uint8 frames in host memory: async H2D on the ingest's copy stream, then convert + resize
+                frames = ingests[p](seq_host[key:key + B + 1])
+            else:      # uint8 frames resident in HBM: the reference's per-frame resize to 376x1232, fused with the conversion
+                frames = resize_frames(seq_dev[key:key + B + 1])
             f, _ = pipes[p].features_clip(frames, continued=(j > 0))   # B consecutive pairs of the sequence
             feats[slot * B:(slot + 1) * B] = f
 
@@ -170,79 +205,100 @@ def main():
         for st_ in streams:
             torch.cuda.current_stream().wait_stream(st_)
 
-    feats = torch.empty((max(K, Wm) * B, 512), device=dev)
-    # W warm-up steps, and at least two on EVERY pipeline (the graphs of a first and of a continued clip) before timing
-    for i in range(max(Wm, 2 * S)):
-        step(i, feats, slot=i % max(Wm, 1))
-    calls = [0] * S   # the timed region starts a fresh sequence on every pipeline: nothing computed earlier is reused
-    join()
-    if Wm:
+    feats = torch.empty((max(K, Wm, 2 * S) * B, 512), device=dev)
+
+    def timed(host):
+        """W warm-up steps (at least two on EVERY pipeline: the graphs of a first and of a continued clip), then exactly
+        K timed steps + the sequence tail, bracketed by barrier + synchronize. Returns (seconds, step_ms, tail_ms)."""
+        nonlocal calls
+        calls = [0] * S
+        nw = max(Wm, 2 * S)
+        for i in range(nw):
+            step(i, feats, slot=i % nw, host=host)
+        calls = [0] * S   # the timed region starts a fresh sequence on every pipeline: nothing computed earlier is reused
+        join()
         pipe.scan(feats[:B])  # warm the tail kernels too
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(K):
-        step(i, feats)
-        ev[i + 1].record(streams[i % S])
-    join()
-    torch.cuda.current_stream().synchronize()
-    t_tail = time.perf_counter()   # sequence tail: all-gather + ordered LSTM scan over all N*K*B features + rel2abs
-    allf = gather_features(feats[:K * B], world * K * B) if world > 1 else feats[:K * B]
-    rot, tr = pipe.scan(allf)
-    poses = transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tail_ms = (time.perf_counter() - t_tail) * 1e3
-    assert tuple(poses.shape) == (world * K * B + 1, 4, 4) and bool(torch.isfinite(poses).all())
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    # completion-to-completion intervals on the launch streams (steps overlap when S > 1)
-    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(S, K)] if K > S else [dt * 1e3 / K]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(K):
+            step(i, feats, host=host)
+            ev[i + 1].record(streams[i % S])
+        join()
+        torch.cuda.current_stream().synchronize()
+        t_tail = time.perf_counter()   # sequence tail: all-gather + ordered LSTM scan over all N*K*B features + rel2abs
+        allf = gather_features(feats[:K * B], world * K * B) if world > 1 else feats[:K * B]
+        rot, tr = pipe.scan(allf)
+        poses = transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        tail_ms = (time.perf_counter() - t_tail) * 1e3
+        assert tuple(poses.shape) == (world * K * B + 1, 4, 4) and bool(torch.isfinite(poses).all())
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # completion-to-completion intervals on the launch streams (steps overlap when S > 1)
+        step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(S, K)] if K > S else [dt * 1e3 / K]
+        return float(tmax.item()), step_ms, tail_ms
+
+    dt, step_ms, tail_ms = timed(host=False)
+    h2d = None if args.no_h2d_leg else timed(host=True)
 
     if rank == 0:
         total_pairs = world * K * B
-        # per-stage device time of the same forward, eager with HIP events on the launch stream
+        # per-stage device time of the same forward in this run, eager with HIP events on the launch stream
         reps = 3
         st = pipe.flow_net.profile(H, W, B, iters=ITERS, reps=reps)
-        zr_launch_ms = st["gru_zr"] / (2 * ITERS)
-        zr_tflops = GRU_ZR_FLOP * B / (zr_launch_ms * 1e-3) / 1e12
-        lookup_ms = st["lookup"] / ITERS
+        rows = kernel_table(st, B)
+        top = rows[0]
+        traffic, traffic_src = pmc_traffic(top["rocprof_name_contains"], B)
         fwd_ms = float(np.median(step_ms))
+        mfma_x = MFMA_PER_PRODUCT[args.precision]
         out = {
             "metric": "frame-pairs/sec, KITTI 1241x376 odometry inference at 1/2/4/8 MI355X",
             "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_LABEL[args.precision], "data": "synthetic",
-            "config": {"workload": "KITTI seq-03-shaped 376x1241 frames resized to 376x1232, GMA flow 12 GRU iters + "
-                                   "CLVO head -> 6-DoF trajectory (BASELINE configs[1])",
+            "config": {"workload": "KITTI seq-03-shaped 376x1241 uint8 frames (resident in HBM) resized to 376x1232, GMA flow "
+                                   "12 GRU iters + CLVO head -> 6-DoF trajectory (BASELINE configs[1])",
                        "pairs_per_step_per_gpu": B, "streams_per_gpu": S, "gru_iters": ITERS, "parallelism": "pairs sharded x%d, one "
                        "all-gather of 512-d features, replicated LSTM scan" % world},
-            # achieved = ALGORITHMIC flops / launch time; the kernel executes 3 f16 MFMAs per algorithmic product, so
-            # the matrix pipe runs at 3x `achieved` (mfma_executed_*); peak = dense f16 MFMA.
-            "roofline": {"bound": "mfma", "kernel": "conv_sf6_kernel<8,16,256,1,8,1,5|5,1,SfGruZR> (fused z|r ConvGRU convolution: 8x16-pixel x 256-channel blocks, fragment-major weights straight to registers)",
-                         "achieved": zr_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": zr_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic("SfGruZR", B),
-                         "launch_ms": zr_launch_ms, "flop_per_launch": GRU_ZR_FLOP * B,
-                         "mfma_executed_tflops": MFMA_PER_PRODUCT[args.precision] * zr_tflops,
-                         "mfma_executed_frac": MFMA_PER_PRODUCT[args.precision] * zr_tflops / PEAK_F16_MFMA_TFLOPS,
-                         "vs_f32_mfma_peak": zr_tflops / PEAK_F32_MFMA_TFLOPS},
-            "forward": {"ms_per_batch_median": fwd_ms, "tflops": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12,
+            # the dominant kernel = the top row of `kernels` (same-run HIP-event time per forward). For an hbm-bound kernel
+            # achieved = algorithmic bytes / launch time; for an mfma-bound one algorithmic FLOP / launch time (the split-f16
+            # engine executes 3 f16 MFMAs per algorithmic product: mfma_executed_*). `traffic` is NOT measured in this run:
+            # it is the PMC figure (2 x FETCH_SIZE + WRITE_SIZE per launch) of the committed profile named in traffic_source.
+            "roofline": {"bound": top["bound"], "kernel": top["kernel"], "rocprof_name_contains": top["rocprof_name_contains"],
+                         "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": top["us_per_launch"] / 1e3,
+                         "algorithmic_per_launch": top["algorithmic_per_launch"],
+                         "algorithmic_unit": top["algorithmic_unit"], "share_of_forward": top["ms_per_forward"] / sum(st.values())},
+            "kernels": rows[:5],
+            "forward": {"ms_per_batch_median": fwd_ms,
+                        "tflops_algorithmic_0.951_per_pair": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12,
+                        "tflops_executed_work": FLOP_PER_PAIR_EXECUTED * B / (fwd_ms * 1e-3) / 1e12,
+                        "mfma_executed_tflops": mfma_x * FLOP_PER_PAIR_EXECUTED * B / (fwd_ms * 1e-3) / 1e12,
+                        "frac_of_f16_mfma_peak_algorithmic": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                         "frac_of_f32_mfma_peak": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
-            "lookup": {"ms_per_launch": lookup_ms, "achieved_GBps": LOOKUP_BYTES * B / (lookup_ms * 1e-3) / 1e9,
+            "lookup": {"ms_per_launch": st["lookup"] / ITERS, "achieved_GBps": LOOKUP_BYTES * B / (st["lookup"] / ITERS * 1e-3) / 1e9,
                        "peak_GBps": PEAK_HBM_GBS},
             "stages_ms_per_forward": {k: round(v, 4) for k, v in st.items()},
             # inside the timed region, after the K steps: grows with N (every rank scans all N*K*B features in order)
             "sequence_tail_ms": round(tail_ms, 3),
         }
+        out["stages_ms_per_forward"]["attention_total"] = round(st["attention"] + st["attn_logits"], 4)
+        if h2d is not None:
+            # second timed pass of the same K steps with the uint8 frames in pinned HOST memory: H2D (copy stream,
+            # double-buffered) + convert + resize inside the timed region. Never the headline `value`.
+            out["h2d_inclusive"] = {"value": total_pairs / h2d[0], "unit": "frame-pairs/s", "ms_per_step": h2d[0] * 1e3 / K,
+                                    "ratio_to_value": (total_pairs / h2d[0]) / (total_pairs / dt),
+                                    "host_bytes_per_step": (B + 1) * 3 * H_KITTI * W_KITTI}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only (rank 0)
-            out["cpu_baseline"] = cpu_baseline(gsd, hsd, resize_frames(raw[:6]))
+            out["cpu_baseline"] = cpu_baseline(gsd, hsd, resize_frames(seq_dev[:6]))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -73,14 +73,19 @@ int atdn_gma_forward_sequence_continued(atdn_gma* h, const float* frames, int B,
                                         float* flow_low, float* flow_up, void* stream);
 
 /* Copies an internal activation to a HOST buffer for parity tests ("fmap", "pyr0".."pyr3", "attn", "net",
- * "x", "corrfeat", "mask", "coords1", "flow4", "qk", "img4"). Returns the number of floats copied, -1 on error. */
+ * "x", "corrfeat", "mask", "coords1", "flow4", "qk", "img4"). Returns the number of floats copied, -1 on error.
+ * "sf_clamped" returns ONE float: how many values the split-f16 storage format had to clamp (|x| > 65504, or NaN)
+ * on this device since the last such read, and resets the count — non-zero means the activations of this checkpoint
+ * left the format's range and results are not fp32-grade (use ATDN_PRECISION_F32). */
 long atdn_gma_debug_read(atdn_gma* h, const char* name, float* host, long capacity, void* stream);
 
 /* Per-stage device time (ms, summed over `reps` eager forwards of batch B), measured with HIP events on
- * `stream`. ms_out has ATDN_GMA_STAGES entries: fnet, corr, pool, cnet, attention, lookup, motion_encoder,
- * aggregate, gru_zr (fused z|r convolution), gru_q, flow_head, mask, gru_ctx (once-per-pair context part of the
- * GRU convolutions; split-f16 pipeline only). */
-#define ATDN_GMA_STAGES 13
+ * `stream`. ms_out has ATDN_GMA_STAGES entries: fnet, corr, pool, cnet, attention (row softmax), lookup, motion_encoder
+ * (without convc1), aggregate (the attention x V kernel alone), gru_zr (fused z|r convolution), gru_q, flow_head, mask,
+ * gru_ctx (once-per-pair context part of the GRU convolutions; split-f16 pipeline only), attn_logits (q,k projection +
+ * Q K^T), agg_vt (the v^T projection in front of attention x V), convc1 (the 1x1 convolution behind the lookup).
+ * Stages that hold launches of ONE kernel (aggregate, gru_zr, gru_q, lookup, corr) divide into per-launch times. */
+#define ATDN_GMA_STAGES 16
 int atdn_gma_profile(atdn_gma* h, int B, int iters, int reps, float* ms_out, void* stream);
 
 size_t atdn_gma_workspace_bytes(atdn_gma* h);
@@ -159,12 +164,39 @@ int atdn_pose_rel2abs(const float* rot, const float* tr, int T, double* poses);
 int atdn_pose_accumulate_f32(float* pose16, const float* rot, const float* tr);
 
 /* ---------------------------------------------------------------------------------------------------
- * Frame front-end  —  replaces TF.resize(im, (376, 1232)) (neural_slam.py:198,220)
+ * Frame front-end  —  replaces, per camera frame, `im.to(device)`, `TF.resize(im, (376, 1232))` and
+ * `InputPadder.pad` (neural_slam.py:197-199,219-221; whl:GMA/core/utils/utils.py:8-20)
  * ------------------------------------------------------------------------------------------------- */
 
-/* torchvision tensor resize = bilinear with antialiasing, align_corners = False: src [planes,Hin,Win] (planes = any
- * product of leading dims, e.g. B*3) -> dst [planes,Hout,Wout]. Weight tables are cached per geometry. */
+/* torchvision's tensor resize is bilinear, align_corners = False; it antialiases from torchvision 0.17 on
+ * (F.interpolate(..., antialias=True)) and does not before that. The reference pins no version
+ * (/root/reference/pyproject.toml:14-16), so both are served; ANTIALIAS is the default everywhere. */
+#define ATDN_RESIZE_BILINEAR 0
+#define ATDN_RESIZE_ANTIALIAS 1
+
+/* src [planes,Hin,Win] (planes = any product of leading dims, e.g. B*3) -> dst [planes,Hout,Wout]; antialiased.
+ * Weight tables are cached per (device, geometry, mode); no intermediate buffer: safe on any number of streams. */
 int atdn_resize_frames(const float* src, int planes, int Hin, int Win, int Hout, int Wout, float* dst, void* stream);
+int atdn_resize_frames_mode(const float* src, int planes, int Hin, int Win, int Hout, int Wout, int antialias, float* dst,
+                            void* stream);
+/* the same from uint8 pixels already on the device (the conversion to fp32 is fused into the resize) */
+int atdn_resize_frames_u8(const uint8_t* src, int planes, int Hin, int Win, int Hout, int Wout, int antialias, float* dst,
+                          void* stream);
+
+/* F.pad(x, [left, right, top, bottom], mode="replicate") as InputPadder.pad applies it (utils.py:19-20):
+ * src [planes,H,W] -> dst [planes,H+top+bottom,W+left+right] */
+int atdn_pad_frames(const float* src, int planes, int H, int W, int left, int right, int top, int bottom, float* dst,
+                    void* stream);
+
+/* uint8 camera frames in HOST memory -> fp32 frames at the network size on the device, in one call:
+ * asynchronous H2D copy (pinned host memory; pageable memory works but serialises) on the handle's own copy stream
+ * into one of two device staging slots, then resize + uint8->fp32 on `stream`. Consecutive calls alternate slots, so
+ * the copy of the next clip overlaps the flow network of the current one.
+ *   host_frames [n_frames,3,Hin,Win] uint8 (HOST) -> dst [n_frames,3,Hout,Wout] fp32 (DEVICE), n_frames <= max_frames */
+typedef struct atdn_ingest atdn_ingest;
+int atdn_ingest_create(atdn_ingest** out, int Hin, int Win, int Hout, int Wout, int max_frames, int antialias);
+int atdn_ingest_frames_u8(atdn_ingest* h, const uint8_t* host_frames, int n_frames, float* dst, void* stream);
+void atdn_ingest_destroy(atdn_ingest* h);
 
 /* ---------------------------------------------------------------------------------------------------
  * Individual kernels, exported for unit parity tests and roofline micro-benchmarks

@@ -122,7 +122,7 @@ def test_neuralslam_relocalization_matches_reference(golden_dir, gsd, hsd, vsd, 
         np.testing.assert_allclose(refined.numpy(), g[name + "_refined"], rtol=0, atol=5e-5)
 
 
-def test_neuralslam_creates_its_map_and_relocalizes(gsd, hsd, tmp_path):
+def test_neuralslam_creates_its_map_and_relocalizes(gsd, hsd, vsd, tmp_path):
     """BASELINE config 5 end to end: a keyframe directory as odometry leaves it, `start_mode="mapping"` -> the
     MappingVAE is trained on the keyframes (stock PyTorch, two epochs here), every keyframe is embedded on the HIP
     path and queries relocalise. The HIP embedding of the trained weights must agree with the torch module that was
@@ -137,6 +137,9 @@ def test_neuralslam_creates_its_map_and_relocalizes(gsd, hsd, tmp_path):
     for i in range(16):
         torch.save(frames[i].byte(), os.path.join(kf, "rgb", "%06d.pth" % i))
     torch.save(poses, os.path.join(kf, "poses.pth"))
+    # map weights left behind by an earlier session in the same directory: the reference always retrains and
+    # overwrites them (neural_slam.py:160,305-352), so they must not be picked up
+    torch.save(vsd, os.path.join(kf, "MappingVAE_weights.pth"))
     cwd = os.getcwd()
     os.chdir(str(tmp_path))   # mapping_loss.pth goes to the working directory, as in the reference
     try:
@@ -150,7 +153,10 @@ def test_neuralslam_creates_its_map_and_relocalizes(gsd, hsd, tmp_path):
     assert list(torch.load(os.path.join(str(tmp_path), "mapping_loss.pth")).shape) == [2]
     # the torch module with the trained weights, eval mode, against the HIP embedding stored on the keyframes
     net = mapping.MappingVAENet()
-    net.load_state_dict(torch.load(os.path.join(kf, "MappingVAE_weights.pth")))
+    trained = torch.load(os.path.join(kf, "MappingVAE_weights.pth"))
+    key = "mean_lin.weight" if "mean_lin.weight" in trained else next(k for k in trained if k.endswith("weight"))
+    assert not torch.equal(trained[key].cpu(), torch.as_tensor(vsd[key]).cpu()), "stale map weights were reused"
+    net.load_state_dict(trained)
     net = net.to(DEV).eval()
     with torch.no_grad():
         mu = net(frames[5:6].byte().float().to(DEV))[0]

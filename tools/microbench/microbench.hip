@@ -1,13 +1,15 @@
-// Diagnostic micro-benchmark of the halo-patch kernels on a ConvGRU-shaped problem (not on the product path).
+// Diagnostic micro-benchmarks (ablation builds of the product kernels: wrong results, timing only). Built by
+// atdn_vslam_amd/build.py into its own libatdn_microbench.so, which links against libatdn_hip.so: none of these
+// template variants is part of the product library.
 #include "../../include/atdn_hip.h"
-#include "conv_sf_dispatch_impl.h"
-#include "conv_sf6.h"
-#include "kernels.h"
+#include "../../atdn_vslam_amd/csrc/conv_sf_dispatch_impl.h"
+#include "../../atdn_vslam_amd/csrc/conv_sf6.h"
+#include "../../atdn_vslam_amd/csrc/kernels.h"
 
 using namespace atdn;
 
-// us_out[12]: gen-6 (8x16 pixels x 256 / 128 / 64 channels), its ablation ladder on the 256-wide block (diagnostic
-// builds that skip work: wrong results, timing only), then generations 4, 3 and 2 for reference.
+// us_out[12]: the halo kernel at 8x16 pixels x 256 / 128 / 64 channels and its ablation ladder on the 256-wide block
+// (diagnostic builds that skip work: wrong results, timing only); entries 7-11 unused.
 extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH, int KW, int reps, float* us_out) {
   try {
     hipStream_t st = nullptr;
@@ -62,11 +64,7 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
     us_out[5] = ATDN_MB_SF6(256, 1, 8, 13);   // ... and no LDS reads in the loop
     us_out[6] = ATDN_MB_SF6(256, 1, 8, 15);   // ... and no patch refresh: the bare MFMA stream of this tiling
 #undef ATDN_MB_SF6
-    us_out[7] = time_it([&]() { launch_conv_sf4<2, E, 16>(s, 1.f, ep, st); });
-    us_out[8] = time_it([&]() { launch_conv_sf4<2, E, 8>(s, 1.f, ep, st); });
-    us_out[9] = time_it([&]() { launch_conv_sf3<2, E, 0>(s, 1.f, ep, st); });
-    us_out[10] = time_it([&]() { launch_conv_sf2<2, E, 16>(s, 1.f, ep, st); });
-    us_out[11] = time_it([&]() { launch_conv_sf2<2, E, 8>(s, 1.f, ep, st); });
+    for (int i = 7; i < 12; ++i) us_out[i] = 0.f;   // (generations 2-4 were removed in round 2)
     (void)hipFree(x); (void)hipFree(w); (void)hipFree(wf); (void)hipFree(y); (void)hipFree(bias);
     return 0;
   } catch (const std::exception& e) {

@@ -1,5 +1,5 @@
 """Timings of the halo-patch split-f16 kernels on ConvGRU-shaped convolutions (diagnostic, not the product path):
-generation 6 at three block widths, its ablation ladder, and generations 4 / 3 / 2.  ATDN_MB_ZERO=1 runs on all-zero
+the halo kernel at three block widths and its ablation ladder (generations 2-4 were removed in round 2).  ATDN_MB_ZERO=1 runs on all-zero
 operands (the chip then holds ~2.4 GHz: the difference to the default run is the DVFS share)."""
 import ctypes as C
 import os
@@ -7,12 +7,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401  (initialises the HIP runtime the same way the product does)
 from atdn_vslam_amd import _lib
-L = C.CDLL(_lib.LIB_PATH)
+_lib.lib()
+L = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libatdn_microbench.so"))
 out = (C.c_float * 12)()
 names = ["gen6 8x16 px x 256 ch (8 waves)", "gen6 8x16 px x 128 ch (4 waves)", "gen6 8x16 px x 64 ch (2x2 waves)",
          "  x256 minus epilogue", "  ... minus weight loads", "  ... minus LDS reads", "  ... minus patch refresh (bare MFMA)",
-         "gen4 LDS-DMA weights 16x16 px x 128 ch", "gen4 LDS-DMA weights 8x16 px x 128 ch", "gen3 warp-specialised 8x16",
-         "gen2 register-staged 16x16", "gen2 register-staged 8x16"]
+         ]
 for (nimg, H, W, Cc, N, KH, KW) in ((8, 47, 154, 384, 256, 1, 5), (8, 47, 154, 256, 192, 3, 3), (8, 47, 154, 128, 256, 3, 3)):
     torch.cuda.synchronize()
     rc = L.atdn_microbench_conv(nimg, H, W, Cc, N, KH, KW, 50, out)

@@ -6,7 +6,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 from atdn_vslam_amd import _lib
-L = C.CDLL(_lib.LIB_PATH)
+_lib.lib()
+L = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libatdn_microbench.so"))
 out = (C.c_float * 10)()
 names = ["8x16 px x 64 ch (2x2 waves)", "12x16 px x 64 ch (2x2 waves)", "16x16 px x 64 ch (4x2 waves)", "  8x16 minus epilogue",
          "  ... minus weight loads", "  ... minus LDS reads", "  ... minus patch refresh (bare MFMA)", "  12x16 minus epilogue",

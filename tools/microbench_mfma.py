@@ -6,7 +6,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 from atdn_vslam_amd import _lib
-L = C.CDLL(_lib.LIB_PATH)
+_lib.lib()
+L = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libatdn_microbench.so"))
 out = (C.c_float * 8)()
 torch.cuda.synchronize()
 assert L.atdn_microbench_mfma(2000, 200, out) == 0
