@@ -1,0 +1,40 @@
+// GMA attention on the split-f16 engine (attention.hip): the [N x N] attention matrix of gma.py:54-76 is produced by a
+// QK^T kernel with the row softmax fused in, stored in MFMA-operand ("fragment-major") order, and streamed by the
+// attention x V kernel of gma.py:102-115 straight into operand registers.
+#pragma once
+#include "common.h"
+
+namespace atdn {
+
+// Geometry of the stored attention matrix of one batch.
+//   strips  RT = ceil(N / 32) 32-row strips per pair, chunks Q = ldN / 32 32-column chunks per row
+//   block (pair, strip, chunk) = 32 rows x 32 columns = AT_BLK bytes, strip-major: ((pair*RT + strip)*Q + chunk)*AT_BLK
+//   inside a block: [k-step t = 0,1][hi | lo][lane = 0..63][16 B]; lane (m = lane & 31, h = lane >> 5) holds row
+//   32*strip + m, columns 32*chunk + 16t + 8*(i >> 2) + 4h + (i & 3) for its eight halves i = 0..7 — the accumulator
+//   order of the producing MFMA, so the producer stores and the consumer loads 1 KiB per wave instruction with no
+//   shuffle; the V^T operand is brought into the same column order when it is written to LDS.
+// Values are e = exp(s - rowmax~) * 2^AT_SHIFT, NOT normalised: rinv[pair][row] = 1 / sum_k e is applied by the
+// consumer. rowmax~ comes from a cheap first pass (f16 x f16 logits); softmax is shift-invariant, so any shift close to
+// the true maximum gives the same probabilities and keeps e inside the f16 range.
+constexpr int AT_BLK = 4096;
+constexpr int AT_SHIFT = 10;
+struct AttnGeom {
+  int B, N, ldN, RT, Q, Npad;   // Npad = 32 * RT: row count of rowmax / rinv per pair
+};
+inline AttnGeom attn_geom(int B, int N, int ldN) { return {B, N, ldN, (N + 31) / 32, ldN / 32, ((N + 31) / 32) * 32}; }
+inline long attn_floats(const AttnGeom& g) { return (long)g.B * g.RT * g.Q * (AT_BLK / 4); }
+
+// qk: sf [B][N][256] = q (pre-scaled, channels 0..127) | k (channels 128..255)            (gma.py:57-60)
+// pass 1: rowmax[b][m] ~ max_n q_m . k_n  (f16 x f16 products)
+void launch_qk_rowmax(const float* qk, const AttnGeom& g, float* rowmax, hipStream_t st);
+// pass 2: P (fragment-major, see above) and rinv[b][m] = 1 / sum_n exp(s_mn - rowmax_m) * 2^-AT_SHIFT scaling included
+void launch_qk_softmax(const float* qk, const AttnGeom& g, const float* rowmax, float* P, float* rinv, bool fast,
+                       hipStream_t st);
+// out[b][m][c] = mf[b][m][c] + gamma * rinv[b][m] * sum_k P[b][m][k] * V[b][k][c]          (gma.py:111-115)
+//   vT sf [B][128][ldN] (V transposed, k contiguous); mf / out sf rows with pixel stride ld (floats), per-pair stride sb
+void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const float* vT, const float* gamma,
+                   const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st);
+// debug / tests: normalised probabilities as fp32 rows [B][N][ldN]
+void launch_attn_decode(const float* P, const float* rinv, const AttnGeom& g, float* rows, hipStream_t st);
+
+}  // namespace atdn

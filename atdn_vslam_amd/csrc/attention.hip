@@ -1,0 +1,338 @@
+// GMA attention on the split-f16 engine (see attention.h for the data layout).
+//
+//   qk_softmax_kernel<STATS>   Q K^T with the row softmax fused in (gma.py:60-74). A block owns 128 query rows (one
+//       32-row strip per wave, its 32 x 128 query fragments resident in registers) and sweeps ALL keys in 64-key tiles
+//       staged through LDS. Operands are swapped (keys = MFMA rows), so a lane owns ONE query row: running maximum
+//       and running sum need no cross-lane traffic. STATS = true is the cheap first pass (hi x hi products only ->
+//       rowmax~); STATS = false recomputes the logits at full split-f16 precision, writes e = exp(s - rowmax~) in
+//       fragment-major order (1 KiB per wave store, non-temporal) and the row sums. The fp32 logits (1.68 GB at 8 pairs)
+//       never exist in memory; the separate softmax pass (read 1.68 GB, write 1.68 GB) is gone.
+//   attn_v_kernel              attention x V (gma.py:102-115). Every wave streams ITS strip of the attention matrix
+//       — one contiguous 0.9 MB run — straight into MFMA operand registers, four chunks (16 KiB per block) ahead, with
+//       1 KiB per wave load; only V^T (L2-resident, shared by the block) goes through LDS. The previous kernel staged
+//       both operands through LDS behind two barriers per 32-wide chunk.
+#include "attention.h"
+
+#include "conv_mfma.h"
+#include "sf.h"
+
+namespace atdn {
+namespace {
+
+constexpr int ROWB = 144;   // LDS row pitch (128 B of operands + 16): 32 consecutive rows read by ds_read_b128 do not conflict
+constexpr float LOG2E = 1.4426950408889634f;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f16x8 ld_frag(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
+__device__ __forceinline__ f16x8 ld_frag_nt(const char* p) {
+  const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return __builtin_bit_cast(f16x8, t);
+}
+__device__ __forceinline__ void st_frag_nt(char* p, f16x8 v) {
+  __builtin_nontemporal_store(__builtin_bit_cast(v4f, v), reinterpret_cast<v4f*>(p));
+}
+__device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// ------------------------------------------------------------------------------------------------ Q K^T + softmax
+template <bool STATS, bool FAST>
+__global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restrict__ qk, const AttnGeom g,
+                                                           const float* __restrict__ rowmax_in,
+                                                           float* __restrict__ rowmax_out, float* __restrict__ P,
+                                                           float* __restrict__ rinv) {
+  constexpr int KT = 64;               // keys per LDS tile
+  constexpr int CH = KT * ROWB;        // one 32-channel chunk of the tile
+  constexpr int IMG = 4 * CH;          // [4 channel chunks][64 keys][144 B]
+  constexpr bool FULL = !STATS && !FAST;   // all three products of the split
+  __shared__ __attribute__((aligned(16))) char lds[2 * IMG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = (g.RT + 3) >> 2;
+  const int id = xcd_remap(blockIdx.x, g.B * tiles);
+  const int b = id / tiles, tile = id - b * tiles;
+  const int strip = tile * 4 + wave;
+  const bool strip_ok = strip < g.RT;
+  const int r = lane & 31, h = lane >> 5;
+  const int m = strip * 32 + r;
+  const bool m_ok = strip_ok && m < g.N;
+  const char* qkb = reinterpret_cast<const char*>(qk + (long)b * g.N * 256);
+
+  // query fragments (the column operand), resident for the whole sweep: row m, channel chunk c, k-step t
+  f16x8 qh[4][2], ql[4][2];
+  {
+    const char* qrow = qkb + (long)min(m, g.N - 1) * 1024 + 16 * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        qh[c][t] = ld_frag(qrow + c * 128 + 32 * t);
+        if (FULL) ql[c][t] = ld_frag(qrow + c * 128 + 32 * t + 64);
+      }
+  }
+
+  // key tile loader: thread -> key rows lr, lr + 32 of the tile, 16-byte slot ls of every 128-byte channel chunk
+  const int lr = tid >> 3, ls = tid & 7;
+  float4 kreg[2][4];
+  auto fetch = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n = min(j * KT + lr + 32 * i, g.N - 1);   // keys past N: clamped, their columns are masked below
+      const char* src = qkb + (long)n * 1024 + 512 + 16 * ls;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) kreg[i][c] = *reinterpret_cast<const float4*>(src + c * 128);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<float4*>(lds + buf * IMG + c * CH + (lr + 32 * i) * ROWB + 16 * ls) = kreg[i][c];
+  };
+
+  const int NHT = (g.Q + 1) >> 1;
+  float run = STATS ? -INFINITY : 0.f;   // running row maximum / running row sum of this lane's columns
+  float c0 = 0.f;
+  if (!STATS) c0 = (float)AT_SHIFT - rowmax_in[(long)b * g.Npad + min(m, g.Npad - 1)] * LOG2E;
+  char* pdst = reinterpret_cast<char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * g.Q) * AT_BLK + lane * 16;
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  fetch(min(1, NHT - 1));
+  for (int j = 0; j < NHT; ++j) {
+    const char* img = lds + (j & 1) * IMG + r * ROWB + 16 * h;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const char* kp = img + c * CH + nt * 32 * ROWB + 32 * t;
+          const f16x8 kh = ld_frag(kp);
+          if (FULL) {
+            const f16x8 kl = ld_frag(kp + 64);
+            acc[nt] = mfma(kl, qh[c][t], acc[nt]);
+            acc[nt] = mfma(kh, ql[c][t], acc[nt]);
+          }
+          acc[nt] = mfma(kh, qh[c][t], acc[nt]);
+        }
+    // the next tile goes into the other image: it was last read in iteration j - 1 and every wave has passed the
+    // barrier since; the tile after that is requested now and lands during the epilogue and the next MFMA block
+    stash((j + 1) & 1);
+    fetch(min(j + 2, NHT - 1));
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col0 = j * KT + nt * 32 + 4 * h;
+      if (STATS) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (col0 + (e & 3) + 8 * (e >> 2) < g.N) run = fmaxf(run, acc[nt][e]);
+      } else {
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool ok = m_ok && (col0 + (e & 3) + 8 * (e >> 2) < g.N);
+          const float x = __builtin_amdgcn_exp2f(fmaf(acc[nt][e], LOG2E, c0));
+          v[e] = ok ? x : 0.f;
+          run += v[e];
+        }
+        const int q = 2 * j + nt;
+        if (strip_ok && q < g.Q) {
+          char* d = pdst + (long)q * AT_BLK;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const SfPair p = sf_split(v[8 * t + i]);
+              hi[i] = p.hi;
+              lo[i] = p.lo;
+            }
+            st_frag_nt(d + (2 * t) * 1024, hi);
+            st_frag_nt(d + (2 * t + 1) * 1024, lo);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (STATS) {
+    run = fmaxf(run, __shfl_xor(run, 32));
+    if (h == 0 && strip_ok) rowmax_out[(long)b * g.Npad + m] = run;
+  } else {
+    run += __shfl_xor(run, 32);
+    if (h == 0 && strip_ok) rinv[(long)b * g.Npad + m] = (m < g.N && run > 0.f) ? 1.0f / run : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attention x V
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
+                                                       const AttnGeom g, const float* __restrict__ vT,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mf,
+                                                       float* __restrict__ out, const long sb, const int ld) {
+  constexpr int D = 4;                 // chunks of the attention stream in flight per wave (4 KiB each)
+  constexpr int IMG = 128 * ROWB;      // V^T chunk: [128 channels][144 B]
+  __shared__ __attribute__((aligned(16))) char lds[2 * IMG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = (g.RT + 3) >> 2;
+  const int id = xcd_remap(blockIdx.x, g.B * tiles);
+  const int b = id / tiles, tile = id - b * tiles;
+  const int strip = tile * 4 + wave;
+  const bool strip_ok = strip < g.RT;
+  const int r = lane & 31, h = lane >> 5;
+  const int m = strip * 32 + r;
+  const int Q = g.Q;
+
+  // this wave's strip of the attention matrix: chunk q is the 4 KiB at pblk + q * AT_BLK, in operand order
+  const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * AT_BLK + lane * 16;
+  f16x8 ring[D][4];   // [slot][2t + (hi | lo)]
+  auto loadP = [&](int q, int slot) __attribute__((always_inline)) {
+    const char* p = pblk + (long)q * AT_BLK;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ring[slot][u] = ld_frag_nt(p + u * 1024);
+  };
+
+  // V^T chunk loader: thread -> channel rows lr + 32 i, 16-byte slot ls of the row's 128-byte [32 hi | 32 lo] chunk.
+  // The eight halves of a slot are columns 8s'..8s'+7 (s' = ls & 3); the attention fragments hold their columns with
+  // bits 2 and 3 of the in-chunk index swapped (accumulator order of the producer), so the two 8-byte halves of the
+  // slot go to the swapped positions of the LDS image.
+  const int lr = tid >> 3, ls = tid & 7;
+  const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
+  float4 breg[4];
+  auto fetchB = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) breg[i] = *reinterpret_cast<const float4*>(vrow + (long)(32 * i) * g.ldN + q * 32);
+  };
+  const int sp = ls & 3;
+  const int boff = lr * ROWB + 64 * (ls >> 2) + 32 * (sp >> 1) + 8 * (sp & 1);
+  auto stashB = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      char* d = lds + buf * IMG + boff + 32 * i * ROWB;
+      *reinterpret_cast<float2*>(d) = make_float2(breg[i].x, breg[i].y);
+      *reinterpret_cast<float2*>(d + 16) = make_float2(breg[i].z, breg[i].w);
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) loadP(min(d, Q - 1), d);
+  fetchB(0);
+  stashB(0);
+  __syncthreads();
+  fetchB(min(1, Q - 1));
+  // branch-free ring: the trip count is rounded up to a multiple of D, look-ahead loads past the end are clamped and a
+  // surplus chunk skips its MFMAs (uniform branch), so every slot index is a compile-time constant
+  const int nq = (Q + D - 1) / D * D;
+  for (int q0 = 0; q0 < nq; q0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int q = q0 + d;
+      loadP(min(q + D - 1, Q - 1), (d + D - 1) % D);
+      if (q < Q) {
+        const char* img = lds + (q & 1) * IMG + r * ROWB + 16 * h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f16x8 ph = ring[d][2 * t], pl = ring[d][2 * t + 1];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const char* vp = img + 32 * j * ROWB + 32 * t;
+            const f16x8 vh = ld_frag(vp);
+            if (!FAST) {
+              const f16x8 vl = ld_frag(vp + 64);
+              acc[j] = mfma(vl, ph, acc[j]);
+              acc[j] = mfma(vh, pl, acc[j]);
+            }
+            acc[j] = mfma(vh, ph, acc[j]);
+          }
+        }
+      }
+      stashB((q + 1) & 1);              // last read in iteration q - 1; every wave has passed the barrier since
+      fetchB(min(q + 2, Q - 1));
+      __syncthreads();
+    }
+  }
+
+  if (strip_ok && m < g.N) {
+    const float rv = rinv[(long)b * g.Npad + m] * gamma[0];
+    const float* mfb = mf + (long)b * sb;
+    float* ob = out + (long)b * sb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int c = 32 * j + 8 * jj + 4 * h;
+        const float4 x = sf_load4(mfb, (long)m * ld, c);
+        const float4 o = make_float4(x.x + rv * acc[j][4 * jj], x.y + rv * acc[j][4 * jj + 1], x.z + rv * acc[j][4 * jj + 2],
+                                     x.w + rv * acc[j][4 * jj + 3]);
+        sf_store4(ob, (long)m * ld, c, o);
+      }
+  }
+}
+
+// one wave per (pair, strip, chunk) block: normalised probabilities as fp32 rows (tests / debug only)
+__global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
+                                                         const AttnGeom g, float* __restrict__ rows) {
+  const long blk = blockIdx.x;
+  const int q = (int)(blk % g.Q);
+  const long bs = blk / g.Q;
+  const int strip = (int)(bs % g.RT), b = (int)(bs / g.RT);
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int m = strip * 32 + r;
+  if (m >= g.N) return;
+  const char* p = reinterpret_cast<const char*>(P) + blk * AT_BLK + lane * 16;
+  const float rv = rinv[(long)b * g.Npad + m];
+  float* row = rows + ((long)b * g.N + m) * g.ldN + q * 32;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f16x8 hi = ld_frag(p + (2 * t) * 1024), lo = ld_frag(p + (2 * t + 1) * 1024);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) row[16 * t + 8 * (i >> 2) + 4 * h + (i & 3)] = ((float)hi[i] + (float)lo[i]) * rv;
+  }
+}
+
+}  // namespace
+
+void launch_qk_rowmax(const float* qk, const AttnGeom& g, float* rowmax, hipStream_t st) {
+  const int nblk = g.B * ((g.RT + 3) / 4);
+  hipLaunchKernelGGL((qk_softmax_kernel<true, false>), dim3(nblk), dim3(256), 0, st, qk, g, nullptr, rowmax, nullptr, nullptr);
+  ATDN_HIP(hipGetLastError());
+}
+
+void launch_qk_softmax(const float* qk, const AttnGeom& g, const float* rowmax, float* P, float* rinv, bool fast,
+                       hipStream_t st) {
+  const int nblk = g.B * ((g.RT + 3) / 4);
+  if (fast) hipLaunchKernelGGL((qk_softmax_kernel<false, true>), dim3(nblk), dim3(256), 0, st, qk, g, rowmax, nullptr, P, rinv);
+  else hipLaunchKernelGGL((qk_softmax_kernel<false, false>), dim3(nblk), dim3(256), 0, st, qk, g, rowmax, nullptr, P, rinv);
+  ATDN_HIP(hipGetLastError());
+}
+
+void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const float* vT, const float* gamma,
+                   const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st) {
+  ATDN_CHECK(g.ldN % 32 == 0 && g.Q * 32 == g.ldN && ld % 32 == 0, "attention geometry");
+  const int nblk = g.B * ((g.RT + 3) / 4);
+  if (fast) hipLaunchKernelGGL((attn_v_kernel<true>), dim3(nblk), dim3(256), 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld);
+  else hipLaunchKernelGGL((attn_v_kernel<false>), dim3(nblk), dim3(256), 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld);
+  ATDN_HIP(hipGetLastError());
+}
+
+void launch_attn_decode(const float* P, const float* rinv, const AttnGeom& g, float* rows, hipStream_t st) {
+  const long nblk = (long)g.B * g.RT * g.Q;
+  hipLaunchKernelGGL(attn_decode_kernel, dim3((unsigned)nblk), dim3(64), 0, st, P, rinv, g, rows);
+  ATDN_HIP(hipGetLastError());
+}
+
+}  // namespace atdn

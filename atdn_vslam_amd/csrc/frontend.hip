@@ -15,6 +15,7 @@
 #include "frontend.h"
 
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -55,7 +56,9 @@ std::vector<ResizeTable> make_table_bilinear(int in, int out) {
   std::vector<ResizeTable> tab(out);
   const float scale = (float)in / (float)out;
   for (int i = 0; i < out; ++i) {
-    float src = scale * ((float)i + 0.5f) - 0.5f;
+    // one rounding (fused multiply-add), as the ATen CPU kernels of this torch build compute it: lambda carries the
+    // rounding of `src` (ulp 6e-5 at x ~ 600) times the local contrast into the output, so the contraction matters
+    float src = std::fmaf(scale, (float)i + 0.5f, -0.5f);
     if (src < 0.f) src = 0.f;
     int x0 = (int)src;
     if (x0 > in - 1) x0 = in - 1;

@@ -3,6 +3,7 @@
 #include <map>
 #include <memory>
 
+#include "attention.h"
 #include "conv_dispatch.h"
 #include "kernels.h"
 #include "weights.h"
@@ -57,6 +58,10 @@ class GmaNet {
   // 210 MB level-0 volume (correlation is linear in the target features); ATDN_POOL_FEATURES=0 pools the volume
   bool pool_features_ = false;
   DeviceBuf fpool_;
+  // split-f16 pipeline: attention as QK^T with the softmax fused in + the streaming attention x V kernel (attention.hip);
+  // ATDN_ATTN_LEGACY=1 keeps the round-1 path (logits GEMM, softmax pass, attention x V on the generic GEMM kernel)
+  bool attn_legacy_ = false;
+  DeviceBuf rowmax_, rinv_;
 
  private:
   void run_body(int B, int iters, hipStream_t st);  // everything between input prep and upsampling

@@ -138,6 +138,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
   pool_features_ = precision >= 1 && !(getenv("ATDN_POOL_FEATURES") && getenv("ATDN_POOL_FEATURES")[0] == '0');
   norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
+  attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
 }
@@ -150,7 +151,7 @@ GmaNet::~GmaNet() {
   DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
-                      &pre_zr_[1], &pre_q_[0], &pre_q_[1], &fpool_};
+                      &pre_zr_[1], &pre_q_[0], &pre_q_[1], &fpool_, &rowmax_, &rinv_};
   for (auto* b : all) b->release();
   arena_.release();
 }
@@ -215,7 +216,7 @@ void GmaNet::finalize() {
   const long n8 = (long)B * N;
   img4_.alloc(2L * B * H * W * 4);
   for (int i = 0; i < (sf ? 4 : 3); ++i) enc_[i].alloc(2L * B * H2 * W2 * 64);
-  if (sf) sim_.alloc((long)B * N * ldN);
+  if (sf && attn_legacy_) sim_.alloc((long)B * N * ldN);
   fmap_.alloc(2L * B * N * 256);
   const long groups = (long)cdiv(H2 * W2, 64) * 4 + 8;
   psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128); pcnt_.alloc(2L * B * groups); fin_.alloc(2L * B * 8 * 128 * 3 * 2);
@@ -226,7 +227,9 @@ void GmaNet::finalize() {
   for (int l = 0; l < 4; ++l) pyr_[l].alloc(n8 * pyrH_[l] * pyrW_[l]);
   if (sf) fpool_.alloc((long)B * pyrH_[1] * pyrW_[1] * 256);
   h_[0].alloc(n8 * 128); h_[1].alloc(n8 * 128); x_.alloc(n8 * XLD);
-  qk_.alloc(n8 * 256); attn_.alloc(n8 * ldN); vT_.alloc((long)B * 128 * ldN);
+  const AttnGeom ag = attn_geom(B, N, ldN);
+  qk_.alloc(n8 * 256); attn_.alloc(std::max(n8 * ldN, attn_floats(ag))); vT_.alloc((long)B * 128 * ldN);
+  if (!attn_legacy_) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
   z_.alloc(n8 * 128); rh_.alloc(n8 * 128); fh_.alloc(n8 * 256); mask_.alloc(n8 * 576);
   coords1_.alloc(n8 * 2); flow4_.alloc(n8 * 4);
@@ -532,10 +535,15 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   v.w = mf; v.wb = (long)N * XLD; v.ldw = XLD; v.N = N; v.nimg = B;
   conv_sf_dispatch(v, to_v_.wscale, SfBias<ACT_NONE>{nullptr, vT_.p, (long)128 * ldN, ldN}, st);
   mark(ST_AGG_VT, st);
-  ConvShape a;
-  a.src0 = attn_.p; a.ld0 = ldN; a.sb0 = (long)N * ldN; a.C0 = ldN; a.H = 1; a.W = N;
-  a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
-  conv_sf_dispatch(a, 1.f, SfAggregate{gamma_, mf, (long)N * XLD, XLD, x_.p + 256, (long)N * XLD, XLD}, st);
+  if (attn_legacy_) {
+    ConvShape a;
+    a.src0 = attn_.p; a.ld0 = ldN; a.sb0 = (long)N * ldN; a.C0 = ldN; a.H = 1; a.W = N;
+    a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
+    conv_sf_dispatch(a, 1.f, SfAggregate{gamma_, mf, (long)N * XLD, XLD, x_.p + 256, (long)N * XLD, XLD}, st);
+  } else {
+    launch_attn_v(attn_.p, rinv_.p, attn_geom(B, N, ldN), vT_.p, gamma_, mf, x_.p + 256, (long)N * XLD, XLD,
+                  sf_fast_mode(), st);
+  }
   mark(ST_AGG, st);
 
   for (int p = 0; p < 2; ++p) {
@@ -601,12 +609,21 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
 
   s = conv_shape(to_qk_, x_.p, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
   conv_sf_dispatch(s, to_qk_.wscale, SfQK{1.0f / sqrtf(128.0f), 128, qk_.p, (long)N * 256, 256}, st);
-  ConvShape q;
-  q.src0 = qk_.p; q.ld0 = 256; q.sb0 = (long)N * 256; q.C0 = 128; q.H = 1; q.W = N;
-  q.w = qk_.p + 128; q.wb = (long)N * 256; q.ldw = 256; q.N = N; q.nimg = B;
-  conv_sf_dispatch(q, 1.f, EpiScale{1.0f, sim_.p, (long)N * ldN, ldN}, st);
-  mark(ST_ATTN_LOGITS, st);
-  launch_softmax_rows_sf(sim_.p, attn_.p, (long)B * N, N, ldN, st);
+  if (attn_legacy_) {
+    ConvShape q;
+    q.src0 = qk_.p; q.ld0 = 256; q.sb0 = (long)N * 256; q.C0 = 128; q.H = 1; q.W = N;
+    q.w = qk_.p + 128; q.wb = (long)N * 256; q.ldw = 256; q.N = N; q.nimg = B;
+    conv_sf_dispatch(q, 1.f, EpiScale{1.0f, sim_.p, (long)N * ldN, ldN}, st);
+    mark(ST_ATTN_LOGITS, st);
+    launch_softmax_rows_sf(sim_.p, attn_.p, (long)B * N, N, ldN, st);
+  } else {
+    // Q K^T with the row softmax fused in (attention.hip): a cheap first sweep (f16 x f16 logits) for the row maxima,
+    // then the full-precision sweep that writes exp(s - max) in MFMA-operand order and the row sums
+    const AttnGeom ag = attn_geom(B, N, ldN);
+    launch_qk_rowmax(qk_.p, ag, rowmax_.p, st);
+    mark(ST_ATTN_LOGITS, st);
+    launch_qk_softmax(qk_.p, ag, rowmax_.p, attn_.p, rinv_.p, sf_fast_mode(), st);
+  }
   mark(ST_ATTN, st);
 
   // context-channel part of the six ConvGRU convolutions: identical in every iteration, computed once
@@ -711,7 +728,17 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
   else if (k == "mask") b = &mask_; else if (k == "coords1") b = &coords1_; else if (k == "flow4") b = &flow4_;
   else if (k == "qk") b = &qk_; else if (k == "img4") b = &img4_;
   if (!b) return -1;
-  const long n = std::min(capacity, b->n);
+  long n = std::min(capacity, b->n);
+  if (k == "attn" && !attn_legacy_) {   // fragment-major exp(s - max) + row sums -> normalised fp32 rows [maxB][N][ldN]
+    const long rows = (long)maxB * N * ldN;
+    if (scratch_.n < rows) { scratch_.release(); scratch_.alloc(rows); }
+    ATDN_HIP(hipMemsetAsync(scratch_.p, 0, (size_t)rows * sizeof(float), st));
+    launch_attn_decode(attn_.p, rinv_.p, attn_geom(maxB, N, ldN), scratch_.p, st);
+    ATDN_HIP(hipStreamSynchronize(st));
+    n = std::min(capacity, rows);
+    ATDN_HIP(hipMemcpy(host, scratch_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return n;
+  }
   const bool is_sf = precision >= 1 && (k == "fmap" || k == "net" || k == "x" || k == "attn" || k == "corrfeat" || k == "qk");
   const float* src = b->p;
   if (is_sf) {  // decode the split-f16 tensor into a scratch fp32 copy first

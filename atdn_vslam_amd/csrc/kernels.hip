@@ -628,7 +628,7 @@ namespace atdn {
 
 // ---- saturation counter of the sf format (sf.h)
 namespace {
-std::vector<const void*>& sf_counter_symbols() { static std::vector<const void*> v; return v; }
+std::vector<void (*)(unsigned int*)>& sf_counter_setters() { static std::vector<void (*)(unsigned int*)> v; return v; }
 std::mutex g_sf_counter_mutex;
 struct SfCounterDev { int dev; unsigned int* ptr; };
 std::vector<SfCounterDev> g_sf_counters;
@@ -640,14 +640,16 @@ unsigned int* sf_counter_for_current_device(bool create) {
   unsigned int* p = nullptr;
   ATDN_HIP(hipMalloc(&p, sizeof(unsigned int)));
   ATDN_HIP(hipMemset(p, 0, sizeof(unsigned int)));
-  for (const void* sym : sf_counter_symbols())
-    ATDN_HIP(hipMemcpyToSymbol(sym, &p, sizeof(p), 0, hipMemcpyHostToDevice));
+  for (auto set : sf_counter_setters()) {   // one per translation unit that includes sf.h
+    set(p);
+    ATDN_HIP(hipGetLastError());
+  }
   ATDN_HIP(hipDeviceSynchronize());
   g_sf_counters.push_back({dev, p});
   return p;
 }
 }  // namespace
-void sf_counter_register(const void* symbol) { sf_counter_symbols().push_back(symbol); }
+void sf_counter_register(void (*setter)(unsigned int*)) { sf_counter_setters().push_back(setter); }
 void sf_counter_attach() {
   std::lock_guard<std::mutex> lock(g_sf_counter_mutex);
   (void)sf_counter_for_current_device(true);

@@ -20,10 +20,18 @@ struct SfPair { _Float16 hi, lo; };
 // silently wrong. Every sf_split that clamps (or sees a NaN) bumps a device counter; atdn_gma_debug_read("sf_clamped")
 // returns and resets it. The library is built without relocatable device code, so each translation unit carries its own
 // pointer to the one counter; sf_counter_attach() (kernels.hip) points them all at it before the first launch.
-namespace { __device__ unsigned int* sf_clamp_counter_tu_ = nullptr; }
-void sf_counter_register(const void* symbol);
 namespace {
-struct SfCounterRegistration { SfCounterRegistration() { sf_counter_register(HIP_SYMBOL(sf_clamp_counter_tu_)); } };
+__device__ unsigned int* sf_clamp_counter_tu_ = nullptr;
+// (a device variable with internal linkage cannot be reached by hipMemcpyToSymbol — the runtime looks symbols up by
+// name — so every translation unit carries a one-thread kernel that sets its own copy)
+__global__ void sf_counter_set_kernel_(unsigned int* p) { sf_clamp_counter_tu_ = p; }
+void sf_counter_set_tu_(unsigned int* p) {
+  hipLaunchKernelGGL(sf_counter_set_kernel_, dim3(1), dim3(1), 0, nullptr, p);
+}
+}  // namespace
+void sf_counter_register(void (*setter)(unsigned int*));
+namespace {
+struct SfCounterRegistration { SfCounterRegistration() { sf_counter_register(&sf_counter_set_tu_); } };
 static SfCounterRegistration sf_counter_registration_;
 }
 // points every translation unit's pointer at one device counter (idempotent per device); read_reset returns the count

@@ -171,3 +171,33 @@ def test_split_f16_saturation_is_counted(gsd):
     net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=1, test_mode=True)
     assert float(net.debug_read("sf_clamped", (1,), 160, 512)[0]) > 0.0
     assert float(net.debug_read("sf_clamped", (1,), 160, 512)[0]) == 0.0   # reading resets it
+
+
+def test_fused_attention_agrees_with_the_separate_passes(gsd, monkeypatch):
+    """Round-2 attention (QK^T with the softmax fused in, fragment-major storage, streaming attention x V) against the
+    round-1 path it replaced (logits GEMM -> softmax pass -> generic GEMM kernel), which stays selectable
+    (ATDN_ATTN_LEGACY=1): attention rows, the aggregated motion features and the flow, at the plumbing size and a
+    ragged one (N = 23 * 41 = 943: partial last strip, odd chunk count)."""
+    sd = {"module." + k: v for k, v in gsd.items()}
+
+    def run(h, w):
+        m = RAFTGMA(max_batch=2, precision="split_f16")
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        fr = torch.from_numpy(syn.make_frames(3, h, w, seed=29)).to(DEV)
+        low, up = m.forward_sequence(fr, iters=4)
+        n = (h // 8) * (w // 8)
+        ldn = (n + 31) // 32 * 32
+        attn = m.debug_read("attn", (2, n, ldn), h, w)[:, :, :n]
+        x = m.debug_read("x", (2 * n, 384), h, w)
+        return low.cpu(), up.cpu(), attn, x[:, 256:384]
+
+    for (h, w) in ((160, 512), (184, 328)):
+        new = run(h, w)
+        monkeypatch.setenv("ATDN_ATTN_LEGACY", "1")
+        old = run(h, w)
+        monkeypatch.delenv("ATDN_ATTN_LEGACY")
+        assert _maxerr(new[2].sum(-1), torch.ones_like(new[2].sum(-1))) < 1e-5
+        assert _maxerr(new[2], old[2]) < 1e-6 + 1e-4 * float(old[2].max())
+        assert _maxerr(new[3], old[3]) < 1e-4          # motion_features_global after the last iteration
+        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4
