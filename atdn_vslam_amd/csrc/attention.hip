@@ -8,9 +8,15 @@
 //       fragment-major order (1 KiB per wave store, non-temporal) and the row sums. The fp32 logits (1.68 GB at 8 pairs)
 //       never exist in memory; the separate softmax pass (read 1.68 GB, write 1.68 GB) is gone.
 //   attn_v_kernel              attention x V (gma.py:102-115). Every wave streams ITS strip of the attention matrix
-//       — one contiguous 0.9 MB run — straight into MFMA operand registers, four chunks (16 KiB per block) ahead, with
-//       1 KiB per wave load; only V^T (L2-resident, shared by the block) goes through LDS. The previous kernel staged
-//       both operands through LDS behind two barriers per 32-wide chunk.
+//       — one contiguous 0.7-0.9 MB run — straight into MFMA operand registers, three chunks ahead, 1 KiB per wave
+//       load; only V^T (L2-resident, shared by the block) goes through LDS, one barrier per chunk. The round-1 kernel
+//       staged both operands through LDS behind two barriers per 32-wide chunk.
+//       What bounds it (timing ladder of diagnostic builds, H3 operands, 8 pairs, MI355X, recorded in DESIGN.md): full
+//       kernel 362 us; attention loads + LDS reads without MFMAs and barriers 212 us = 5.9 TB/s (the stream itself is
+//       NOT the bound); MFMAs + LDS fragment reads without the stream 339 us: the 3-MFMA split makes this a matrix-pipe
+//       kernel (322 GFLOP executed per launch, 0.89 PF with the stream beside it). Two hand-scheduled variants were
+//       measured and dropped: all sixteen V^T fragments of a chunk requested up front (+2 %), and fragments read one
+//       MFMA group ahead across the chunk boundary with a ring of three LDS images (+5 %).
 #include "attention.h"
 
 #include "conv_mfma.h"
@@ -34,8 +40,51 @@ __device__ __forceinline__ void st_frag_nt(char* p, f16x8 v) {
 }
 __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// ---- H3 element format (attention.h): hi = f16(e); residual byte in units of 2^(E - 33), E = f16 exponent (>= 1) of the
+// largest hi of the group of eight
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void h3_encode(const float* v, f16x8& hi, u32x2& bytes) {
+  float hf[8];
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hi[i] = (_Float16)v[i];
+    hf[i] = (float)hi[i];
+    mx = fmaxf(mx, hf[i]);
+  }
+  // exponent field of the float = f16 exponent + 112; f16 subnormals (and zero) count as E = 1
+  const unsigned ef = max(__float_as_uint(mx) >> 23, 113u);
+  const float inv_unit = __uint_as_float((272u - ef) << 23);   // 2^(33 - E)
+  unsigned w0 = 0, w1 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    // |v - hi| <= ulp(hi) / 2 <= ulp(group) / 2: the quotient lies in [-128, 128]; +128 (a tie rounded down) is
+    // stored as 127, one unit = 2^-9 ulp off
+    const float q = fminf(rintf((v[i] - hf[i]) * inv_unit), 127.f) + 128.f;
+    if (i < 4) w0 = __builtin_amdgcn_cvt_pk_u8_f32(q, i, w0); else w1 = __builtin_amdgcn_cvt_pk_u8_f32(q, i - 4, w1);
+  }
+  bytes[0] = w0;
+  bytes[1] = w1;
+}
+__device__ __forceinline__ f16x8 h3_decode_lo(f16x8 hi, u32x2 bytes) {
+  _Float16 mx = hi[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) mx = hi[i] > mx ? hi[i] : mx;   // (values are non-negative)
+  const unsigned e = max((unsigned)(__builtin_bit_cast(unsigned short, mx) >> 10) & 31u, 1u);
+  const float unit = __uint_as_float((e + 94u) << 23);        // 2^(E - 33)
+  f16x8 lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned w = bytes[i >> 2];
+    const float q = (float)((w >> (8 * (i & 3))) & 255u) - 128.f;
+    lo[i] = (_Float16)(q * unit);   // exact while representable: |q| < 2^8 times a power of two
+  }
+  return lo;
+}
+
 // ------------------------------------------------------------------------------------------------ Q K^T + softmax
-template <bool STATS, bool FAST>
+template <bool STATS, bool FAST, int FMT>
 __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restrict__ qk, const AttnGeom g,
                                                            const float* __restrict__ rowmax_in,
                                                            float* __restrict__ rowmax_out, float* __restrict__ P,
@@ -44,6 +93,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   constexpr int CH = KT * ROWB;        // one 32-channel chunk of the tile
   constexpr int IMG = 4 * CH;          // [4 channel chunks][64 keys][144 B]
   constexpr bool FULL = !STATS && !FAST;   // all three products of the split
+  constexpr int BLK = attn_blk_bytes(FMT);
   __shared__ __attribute__((aligned(16))) char lds[2 * IMG];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,29 +122,29 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 
   // key tile loader: thread -> key rows lr, lr + 32 of the tile, 16-byte slot ls of every 128-byte channel chunk
   const int lr = tid >> 3, ls = tid & 7;
-  float4 kreg[2][4];
-  auto fetch = [&](int j) {
+  v4f kreg[2][4];
+  auto fetch = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int n = min(j * KT + lr + 32 * i, g.N - 1);   // keys past N: clamped, their columns are masked below
       const char* src = qkb + (long)n * 1024 + 512 + 16 * ls;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) kreg[i][c] = *reinterpret_cast<const float4*>(src + c * 128);
+      for (int c = 0; c < 4; ++c) kreg[i][c] = *reinterpret_cast<const v4f*>(src + c * 128);
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        *reinterpret_cast<float4*>(lds + buf * IMG + c * CH + (lr + 32 * i) * ROWB + 16 * ls) = kreg[i][c];
+        *reinterpret_cast<v4f*>(lds + buf * IMG + c * CH + (lr + 32 * i) * ROWB + 16 * ls) = kreg[i][c];
   };
 
   const int NHT = (g.Q + 1) >> 1;
   float run = STATS ? -INFINITY : 0.f;   // running row maximum / running row sum of this lane's columns
   float c0 = 0.f;
   if (!STATS) c0 = (float)AT_SHIFT - rowmax_in[(long)b * g.Npad + min(m, g.Npad - 1)] * LOG2E;
-  char* pdst = reinterpret_cast<char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * g.Q) * AT_BLK + lane * 16;
+  char* pdst = reinterpret_cast<char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * g.Q) * BLK;
 
   fetch(0);
   stash(0);
@@ -107,21 +157,36 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
+    // key fragments of channel chunk c + 1 are requested before the MFMAs of chunk c are issued (two register sets);
+    // left to itself the compiler reads each fragment right before its MFMA and waits out the LDS round trip
+    f16x8 kh[2][2][2], kl[2][2][2];   // [set][t][nt]
+    auto read_keys = [&](int set, int c) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const char* kp = img + c * CH + nt * 32 * ROWB + 32 * t;
-          const f16x8 kh = ld_frag(kp);
-          if (FULL) {
-            const f16x8 kl = ld_frag(kp + 64);
-            acc[nt] = mfma(kl, qh[c][t], acc[nt]);
-            acc[nt] = mfma(kh, ql[c][t], acc[nt]);
-          }
-          acc[nt] = mfma(kh, qh[c][t], acc[nt]);
+          kh[set][t][nt] = ld_frag(kp);
+          if (FULL) kl[set][t][nt] = ld_frag(kp + 64);
         }
+    };
+    read_keys(0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c + 1 < 4) read_keys((c + 1) & 1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (FULL) {
+            acc[nt] = mfma(kl[c & 1][t][nt], qh[c][t], acc[nt]);
+            acc[nt] = mfma(kh[c & 1][t][nt], ql[c][t], acc[nt]);
+          }
+          acc[nt] = mfma(kh[c & 1][t][nt], qh[c][t], acc[nt]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // the next tile goes into the other image: it was last read in iteration j - 1 and every wave has passed the
     // barrier since; the tile after that is requested now and lands during the epilogue and the next MFMA block
     stash((j + 1) & 1);
@@ -144,18 +209,26 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
         }
         const int q = 2 * j + nt;
         if (strip_ok && q < g.Q) {
-          char* d = pdst + (long)q * AT_BLK;
+          char* d = pdst + (long)q * BLK;
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            f16x8 hi, lo;
+            if (FMT == AT_FMT_H3) {
+              f16x8 hi;
+              u32x2 bytes;
+              h3_encode(v + 8 * t, hi, bytes);
+              st_frag_nt(d + t * 1024 + lane * 16, hi);
+              __builtin_nontemporal_store(bytes, reinterpret_cast<u32x2*>(d + 2048 + t * 512 + lane * 8));
+            } else {
+              f16x8 hi, lo;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const SfPair p = sf_split(v[8 * t + i]);
-              hi[i] = p.hi;
-              lo[i] = p.lo;
+              for (int i = 0; i < 8; ++i) {
+                const SfPair p = sf_split(v[8 * t + i]);
+                hi[i] = p.hi;
+                lo[i] = p.lo;
+              }
+              st_frag_nt(d + (2 * t) * 1024 + lane * 16, hi);
+              st_frag_nt(d + (2 * t + 1) * 1024 + lane * 16, lo);
             }
-            st_frag_nt(d + (2 * t) * 1024, hi);
-            st_frag_nt(d + (2 * t + 1) * 1024, lo);
           }
         }
       }
@@ -172,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ attention x V
-template <bool FAST>
+template <bool FAST, int FMT>
 __global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
                                                        const AttnGeom g, const float* __restrict__ vT,
                                                        const float* __restrict__ gamma, const float* __restrict__ mf,
@@ -191,13 +264,23 @@ __global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict_
   const int m = strip * 32 + r;
   const int Q = g.Q;
 
-  // this wave's strip of the attention matrix: chunk q is the 4 KiB at pblk + q * AT_BLK, in operand order
-  const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * AT_BLK + lane * 16;
-  f16x8 ring[D][4];   // [slot][2t + (hi | lo)]
+  // this wave's strip of the attention matrix: chunk q is the BLK bytes at pblk + q * BLK, in operand order
+  constexpr int BLK = attn_blk_bytes(FMT);
+  const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * BLK;
+  f16x8 ring[D][FMT == AT_FMT_H3 ? 2 : 4];   // SF4: [slot][2t + (hi | lo)]; H3: [slot][t] hi
+  u32x2 ringb[D][2];                          // H3: residual bytes of k-step t
   auto loadP = [&](int q, int slot) __attribute__((always_inline)) {
-    const char* p = pblk + (long)q * AT_BLK;
+    const char* p = pblk + (long)q * BLK;
+    if (FMT == AT_FMT_H3) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ring[slot][u] = ld_frag_nt(p + u * 1024);
+      for (int t = 0; t < 2; ++t) {
+        ring[slot][t] = ld_frag_nt(p + t * 1024 + lane * 16);
+        ringb[slot][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ring[slot][u] = ld_frag_nt(p + u * 1024 + lane * 16);
+    }
   };
 
   // V^T chunk loader: thread -> channel rows lr + 32 i, 16-byte slot ls of the row's 128-byte [32 hi | 32 lo] chunk.
@@ -206,19 +289,22 @@ __global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict_
   // slot go to the swapped positions of the LDS image.
   const int lr = tid >> 3, ls = tid & 7;
   const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
-  float4 breg[4];
-  auto fetchB = [&](int q) __attribute__((always_inline)) {
+  // two register sets: a V^T chunk is requested D - 1 iterations before it is multiplied, like the attention chunks.
+  // vmcnt retires in order, so a wait for an L2-hit V^T load also waits for every OLDER attention load: with the V^T
+  // loads issued later than the attention loads of the same distance the HBM look-ahead shrank to one iteration.
+  v4f breg[2][4];
+  auto fetchB = [&](int q, int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) breg[i] = *reinterpret_cast<const float4*>(vrow + (long)(32 * i) * g.ldN + q * 32);
+    for (int i = 0; i < 4; ++i) breg[set][i] = *reinterpret_cast<const v4f*>(vrow + (long)(32 * i) * g.ldN + q * 32);
   };
   const int sp = ls & 3;
   const int boff = lr * ROWB + 64 * (ls >> 2) + 32 * (sp >> 1) + 8 * (sp & 1);
-  auto stashB = [&](int buf) __attribute__((always_inline)) {
+  auto stashB = [&](int buf, int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       char* d = lds + buf * IMG + boff + 32 * i * ROWB;
-      *reinterpret_cast<float2*>(d) = make_float2(breg[i].x, breg[i].y);
-      *reinterpret_cast<float2*>(d + 16) = make_float2(breg[i].z, breg[i].w);
+      *reinterpret_cast<float2*>(d) = make_float2(breg[set][i].x, breg[set][i].y);
+      *reinterpret_cast<float2*>(d + 16) = make_float2(breg[set][i].z, breg[set][i].w);
     }
   };
 
@@ -228,12 +314,16 @@ __global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-#pragma unroll
-  for (int d = 0; d < D - 1; ++d) loadP(min(d, Q - 1), d);
-  fetchB(0);
-  stashB(0);
+  static_assert(D == 4, "the V^T register sets alternate with the parity of the chunk: D must be even");
+  // prologue: chunk 0 of V^T goes to LDS image 0 directly; chunks 1 and 2 wait in the two register sets
+  fetchB(0, 0);
+  loadP(0, 0);
+  fetchB(min(1, Q - 1), 1);
+  loadP(min(1, Q - 1), 1);
+  stashB(0, 0);
+  fetchB(min(2, Q - 1), 0);
+  loadP(min(2, Q - 1), 2);
   __syncthreads();
-  fetchB(min(1, Q - 1));
   // branch-free ring: the trip count is rounded up to a multiple of D, look-ahead loads past the end are clamped and a
   // surplus chunk skips its MFMAs (uniform branch), so every slot index is a compile-time constant
   const int nq = (Q + D - 1) / D * D;
@@ -241,12 +331,23 @@ __global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict_
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int q = q0 + d;
+      // V^T chunk q + 1 (requested two iterations ago) goes into the LDS image last read in iteration q - 1 (every wave
+      // has passed the barrier since); its register set takes chunk q + 3; then the attention chunk q + 3
+      stashB((q + 1) & 1, (d + 1) & 1);
+      fetchB(min(q + 3, Q - 1), (d + 1) & 1);
       loadP(min(q + D - 1, Q - 1), (d + D - 1) % D);
       if (q < Q) {
         const char* img = lds + (q & 1) * IMG + r * ROWB + 16 * h;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const f16x8 ph = ring[d][2 * t], pl = ring[d][2 * t + 1];
+          f16x8 ph, pl;
+          if (FMT == AT_FMT_H3) {
+            ph = ring[d][t];
+            if (!FAST) pl = h3_decode_lo(ph, ringb[d][t]);
+          } else {
+            ph = ring[d][2 * t];
+            pl = ring[d][2 * t + 1];
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const char* vp = img + 32 * j * ROWB + 32 * t;
@@ -260,8 +361,6 @@ __global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict_
           }
         }
       }
-      stashB((q + 1) & 1);              // last read in iteration q - 1; every wave has passed the barrier since
-      fetchB(min(q + 2, Q - 1));
       __syncthreads();
     }
   }
@@ -293,12 +392,20 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int m = strip * 32 + r;
   if (m >= g.N) return;
-  const char* p = reinterpret_cast<const char*>(P) + blk * AT_BLK + lane * 16;
+  const int BLK = attn_blk_bytes(g.fmt);
+  const char* p = reinterpret_cast<const char*>(P) + blk * BLK;
   const float rv = rinv[(long)b * g.Npad + m];
   float* row = rows + ((long)b * g.N + m) * g.ldN + q * 32;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const f16x8 hi = ld_frag(p + (2 * t) * 1024), lo = ld_frag(p + (2 * t + 1) * 1024);
+    f16x8 hi, lo;
+    if (g.fmt == AT_FMT_H3) {
+      hi = ld_frag(p + t * 1024 + lane * 16);
+      lo = h3_decode_lo(hi, *reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
+    } else {
+      hi = ld_frag(p + (2 * t) * 1024 + lane * 16);
+      lo = ld_frag(p + (2 * t + 1) * 1024 + lane * 16);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) row[16 * t + 8 * (i >> 2) + 4 * h + (i & 3)] = ((float)hi[i] + (float)lo[i]) * rv;
   }
@@ -308,15 +415,21 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict
 
 void launch_qk_rowmax(const float* qk, const AttnGeom& g, float* rowmax, hipStream_t st) {
   const int nblk = g.B * ((g.RT + 3) / 4);
-  hipLaunchKernelGGL((qk_softmax_kernel<true, false>), dim3(nblk), dim3(256), 0, st, qk, g, nullptr, rowmax, nullptr, nullptr);
+  hipLaunchKernelGGL((qk_softmax_kernel<true, false, AT_FMT_SF4>), dim3(nblk), dim3(256), 0, st, qk, g, nullptr, rowmax, nullptr, nullptr);
   ATDN_HIP(hipGetLastError());
 }
 
 void launch_qk_softmax(const float* qk, const AttnGeom& g, const float* rowmax, float* P, float* rinv, bool fast,
                        hipStream_t st) {
   const int nblk = g.B * ((g.RT + 3) / 4);
-  if (fast) hipLaunchKernelGGL((qk_softmax_kernel<false, true>), dim3(nblk), dim3(256), 0, st, qk, g, rowmax, nullptr, P, rinv);
-  else hipLaunchKernelGGL((qk_softmax_kernel<false, false>), dim3(nblk), dim3(256), 0, st, qk, g, rowmax, nullptr, P, rinv);
+  const dim3 gr(nblk), bl(256);
+  if (g.fmt == AT_FMT_H3) {
+    if (fast) hipLaunchKernelGGL((qk_softmax_kernel<false, true, AT_FMT_H3>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
+    else hipLaunchKernelGGL((qk_softmax_kernel<false, false, AT_FMT_H3>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
+  } else {
+    if (fast) hipLaunchKernelGGL((qk_softmax_kernel<false, true, AT_FMT_SF4>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
+    else hipLaunchKernelGGL((qk_softmax_kernel<false, false, AT_FMT_SF4>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
+  }
   ATDN_HIP(hipGetLastError());
 }
 
@@ -324,8 +437,11 @@ void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const f
                    const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st) {
   ATDN_CHECK(g.ldN % 32 == 0 && g.Q * 32 == g.ldN && ld % 32 == 0, "attention geometry");
   const int nblk = g.B * ((g.RT + 3) / 4);
-  if (fast) hipLaunchKernelGGL((attn_v_kernel<true>), dim3(nblk), dim3(256), 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld);
-  else hipLaunchKernelGGL((attn_v_kernel<false>), dim3(nblk), dim3(256), 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld);
+  const dim3 gr(nblk), bl(256);
+#define ATDN_AV(FASTV, FMTV) hipLaunchKernelGGL((attn_v_kernel<FASTV, FMTV>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld)
+  if (g.fmt == AT_FMT_H3) { if (fast) ATDN_AV(true, AT_FMT_H3); else ATDN_AV(false, AT_FMT_H3); }
+  else { if (fast) ATDN_AV(true, AT_FMT_SF4); else ATDN_AV(false, AT_FMT_SF4); }
+#undef ATDN_AV
   ATDN_HIP(hipGetLastError());
 }
 

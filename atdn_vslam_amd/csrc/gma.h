@@ -61,6 +61,7 @@ class GmaNet {
   // split-f16 pipeline: attention as QK^T with the softmax fused in + the streaming attention x V kernel (attention.hip);
   // ATDN_ATTN_LEGACY=1 keeps the round-1 path (logits GEMM, softmax pass, attention x V on the generic GEMM kernel)
   bool attn_legacy_ = false;
+  int attn_fmt_ = AT_FMT_H3;   // element format of the stored attention matrix (attention.h); ATDN_ATTN_FMT=sf4
   DeviceBuf rowmax_, rinv_;
 
  private:

@@ -139,6 +139,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   pool_features_ = precision >= 1 && !(getenv("ATDN_POOL_FEATURES") && getenv("ATDN_POOL_FEATURES")[0] == '0');
   norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
   attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
+  if (getenv("ATDN_ATTN_FMT") && std::string(getenv("ATDN_ATTN_FMT")) == "sf4") attn_fmt_ = AT_FMT_SF4;
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
 }
@@ -227,7 +228,7 @@ void GmaNet::finalize() {
   for (int l = 0; l < 4; ++l) pyr_[l].alloc(n8 * pyrH_[l] * pyrW_[l]);
   if (sf) fpool_.alloc((long)B * pyrH_[1] * pyrW_[1] * 256);
   h_[0].alloc(n8 * 128); h_[1].alloc(n8 * 128); x_.alloc(n8 * XLD);
-  const AttnGeom ag = attn_geom(B, N, ldN);
+  const AttnGeom ag = attn_geom(B, N, ldN, attn_fmt_);
   qk_.alloc(n8 * 256); attn_.alloc(std::max(n8 * ldN, attn_floats(ag))); vT_.alloc((long)B * 128 * ldN);
   if (!attn_legacy_) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
@@ -541,7 +542,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
     a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
     conv_sf_dispatch(a, 1.f, SfAggregate{gamma_, mf, (long)N * XLD, XLD, x_.p + 256, (long)N * XLD, XLD}, st);
   } else {
-    launch_attn_v(attn_.p, rinv_.p, attn_geom(B, N, ldN), vT_.p, gamma_, mf, x_.p + 256, (long)N * XLD, XLD,
+    launch_attn_v(attn_.p, rinv_.p, attn_geom(B, N, ldN, attn_fmt_), vT_.p, gamma_, mf, x_.p + 256, (long)N * XLD, XLD,
                   sf_fast_mode(), st);
   }
   mark(ST_AGG, st);
@@ -619,7 +620,7 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   } else {
     // Q K^T with the row softmax fused in (attention.hip): a cheap first sweep (f16 x f16 logits) for the row maxima,
     // then the full-precision sweep that writes exp(s - max) in MFMA-operand order and the row sums
-    const AttnGeom ag = attn_geom(B, N, ldN);
+    const AttnGeom ag = attn_geom(B, N, ldN, attn_fmt_);
     launch_qk_rowmax(qk_.p, ag, rowmax_.p, st);
     mark(ST_ATTN_LOGITS, st);
     launch_qk_softmax(qk_.p, ag, rowmax_.p, attn_.p, rinv_.p, sf_fast_mode(), st);
@@ -733,7 +734,7 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
     const long rows = (long)maxB * N * ldN;
     if (scratch_.n < rows) { scratch_.release(); scratch_.alloc(rows); }
     ATDN_HIP(hipMemsetAsync(scratch_.p, 0, (size_t)rows * sizeof(float), st));
-    launch_attn_decode(attn_.p, rinv_.p, attn_geom(maxB, N, ldN), scratch_.p, st);
+    launch_attn_decode(attn_.p, rinv_.p, attn_geom(maxB, N, ldN, attn_fmt_), scratch_.p, st);
     ATDN_HIP(hipStreamSynchronize(st));
     n = std::min(capacity, rows);
     ATDN_HIP(hipMemcpy(host, scratch_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));

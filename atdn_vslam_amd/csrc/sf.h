@@ -40,8 +40,12 @@ unsigned int sf_counter_read_reset(hipStream_t st);
 
 __device__ __forceinline__ SfPair sf_split(float v) {
   if (__builtin_expect(!(fabsf(v) <= 65504.f), 0)) {   // clamped value or NaN: rare, counted
+    // one atomic per wave (the lanes that got here, counted by the first of them): a tensor that saturates everywhere
+    // would otherwise serialise millions of atomics on one address
     unsigned int* c = sf_clamp_counter_tu_;
-    if (c) atomicAdd(c, 1u);
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    if (c && (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u)) == 0u)
+      atomicAdd(c, (unsigned)__builtin_popcountll(act));
   }
   v = fminf(fmaxf(v, -65504.f), 65504.f);
   SfPair p;
