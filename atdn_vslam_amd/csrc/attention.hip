@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 
   const int NHT = (g.Q + 1) >> 1;
   float run = STATS ? -INFINITY : 0.f;   // running row maximum / running row sum of this lane's columns
+  bool clamped = false;                  // (SF4 stores) saturation, reported once after the sweep
   float c0 = 0.f;
   if (!STATS) c0 = (float)AT_SHIFT - rowmax_in[(long)b * g.Npad + min(m, g.Npad - 1)] * LOG2E;
   char* pdst = reinterpret_cast<char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * g.Q) * BLK;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
               f16x8 hi, lo;
 #pragma unroll
               for (int i = 0; i < 8; ++i) {
-                const SfPair p = sf_split(v[8 * t + i]);
+                const SfPair p = sf_split_flag(v[8 * t + i], clamped);
                 hi[i] = p.hi;
                 lo[i] = p.lo;
               }
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
     }
     __syncthreads();
   }
+  sf_report(clamped);
   if (STATS) {
     run = fmaxf(run, __shfl_xor(run, 32));
     if (h == 0 && strip_ok) rowmax_out[(long)b * g.Npad + m] = run;

@@ -60,6 +60,13 @@ class GmaNet {
   DeviceBuf fpool_;
   // split-f16 pipeline: attention as QK^T with the softmax fused in + the streaming attention x V kernel (attention.hip);
   // ATDN_ATTN_LEGACY=1 keeps the round-1 path (logits GEMM, softmax pass, attention x V on the generic GEMM kernel)
+  // split-f16 pipeline: correlation pyramid in bricks (4 x 8 cells = one 128-byte line), every level a GEMM against
+  // pooled features in brick order, lookup fused with convc1 (lookup_fused.hip); ATDN_LOOKUP_LEGACY=1 keeps the
+  // row-major pyramid, the separate lookup kernel and the convc1 GEMM of round 1
+  bool lookup_legacy_ = false;
+  DeviceBuf fbrick_[4], fplain_[3], coords_used_;   // features in brick order (levels 0-3), plain pooled features (1-3)
+  int brickBW_[4], brickBH_[4], brickNB_[4];
+  BrickPyramid brick_pyramid() const;
   bool attn_legacy_ = false;
   int attn_fmt_ = AT_FMT_H3;   // element format of the stored attention matrix (attention.h); ATDN_ATTN_FMT=sf4
   DeviceBuf rowmax_, rinv_;

@@ -138,6 +138,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
   pool_features_ = precision >= 1 && !(getenv("ATDN_POOL_FEATURES") && getenv("ATDN_POOL_FEATURES")[0] == '0');
   norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
+  lookup_legacy_ = precision == 0 || (getenv("ATDN_LOOKUP_LEGACY") && getenv("ATDN_LOOKUP_LEGACY")[0] == '1');
   attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
   if (getenv("ATDN_ATTN_FMT") && std::string(getenv("ATDN_ATTN_FMT")) == "sf4") attn_fmt_ = AT_FMT_SF4;
   const char* ng = getenv("ATDN_NO_GRAPH");
@@ -152,7 +153,8 @@ GmaNet::~GmaNet() {
   DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
-                      &pre_zr_[1], &pre_q_[0], &pre_q_[1], &fpool_, &rowmax_, &rinv_};
+                      &pre_zr_[1], &pre_q_[0], &pre_q_[1], &fpool_, &rowmax_, &rinv_,
+                      &fbrick_[0], &fbrick_[1], &fbrick_[2], &fbrick_[3], &fplain_[0], &fplain_[1], &fplain_[2], &coords_used_};
   for (auto* b : all) b->release();
   arena_.release();
 }
@@ -168,6 +170,7 @@ void GmaNet::finalize() {
   fnet_ = pack_encoder(arena_, sd_, "fnet.", false, sf);
   cnet_ = pack_encoder(arena_, sd_, "cnet.", true, sf);
   convc1_ = tap({u + "encoder.convc1"});
+  if (sf && !lookup_legacy_) pack_fragment_major(arena_, convc1_);   // the fused lookup kernel loads operand-order weights
   convc2_ = tap({u + "encoder.convc2"});
   convf1_ = pack_conv(arena_, sd_, {u + "encoder.convf1"}, MODE_ROW, 4);
   {  // the same weights as [(ky*7 + kx)*2 + c][128] for the register-tiled VALU kernel (small_convs.hip)
@@ -225,8 +228,16 @@ void GmaNet::finalize() {
   pyrH_[0] = H8; pyrW_[0] = W8;
   for (int l = 1; l < 4; ++l) { pyrH_[l] = pyrH_[l - 1] / 2; pyrW_[l] = pyrW_[l - 1] / 2; }
   ATDN_CHECK(pyrH_[3] >= 2 && pyrW_[3] >= 2, "frame too small for a 4-level pyramid");
-  for (int l = 0; l < 4; ++l) pyr_[l].alloc(n8 * pyrH_[l] * pyrW_[l]);
-  if (sf) fpool_.alloc((long)B * pyrH_[1] * pyrW_[1] * 256);
+  for (int l = 0; l < 4; ++l) {
+    brickBW_[l] = cdiv(pyrW_[l], 8); brickBH_[l] = cdiv(pyrH_[l], 4); brickNB_[l] = brickBW_[l] * brickBH_[l] * 32;
+    pyr_[l].alloc(n8 * (lookup_legacy_ ? pyrH_[l] * pyrW_[l] : brickNB_[l]));
+  }
+  if (sf && lookup_legacy_) fpool_.alloc((long)B * pyrH_[1] * pyrW_[1] * 256);
+  if (sf && !lookup_legacy_) {
+    for (int l = 0; l < 4; ++l) fbrick_[l].alloc((long)B * brickNB_[l] * 256);
+    for (int l = 1; l < 4; ++l) fplain_[l - 1].alloc((long)B * pyrH_[l] * pyrW_[l] * 256);
+    coords_used_.alloc(n8 * 2);
+  }
   h_[0].alloc(n8 * 128); h_[1].alloc(n8 * 128); x_.alloc(n8 * XLD);
   const AttnGeom ag = attn_geom(B, N, ldN, attn_fmt_);
   qk_.alloc(n8 * 256); attn_.alloc(std::max(n8 * ldN, attn_floats(ag))); vT_.alloc((long)B * 128 * ldN);
@@ -505,14 +516,21 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
 
 void GmaNet::iteration_sf(int B, hipStream_t st) {
   const long n8 = (long)B * N;
-  PyramidLevels pl;
-  for (int l = 0; l < 4; ++l) { pl.base[l] = pyr_[l].p; pl.H[l] = pyrH_[l]; pl.W[l] = pyrW_[l]; }
-  launch_lookup_sf(pl, coords1_.p, n8, corrfeat_.p, CORR_LD, st);
-  mark(ST_LOOKUP, st);
-
-  ConvShape s = conv_shape(convc1_, corrfeat_.p, CORR_LD, (long)N * CORR_LD, B, H8, W8, 1, 0, 0);
-  conv_sf_dispatch(s, convc1_.wscale, SfBias<ACT_RELU>{convc1_.b, cor1_.p, (long)N * 256, 256}, st);
-  mark(ST_CONVC1, st);
+  ConvShape s;
+  if (!lookup_legacy_) {
+    // cor1 = relu(convc1(lookup(coords1))) in one kernel: the 324 samples of a pixel never leave the CU
+    launch_lookup_conv(brick_pyramid(), coords1_.p, n8, coords_used_.p, convc1_.wf, convc1_.wscale, convc1_.b, cor1_.p,
+                       sf_fast_mode(), st);
+    mark(ST_LOOKUP, st);
+  } else {
+    PyramidLevels pl;
+    for (int l = 0; l < 4; ++l) { pl.base[l] = pyr_[l].p; pl.H[l] = pyrH_[l]; pl.W[l] = pyrW_[l]; }
+    launch_lookup_sf(pl, coords1_.p, n8, corrfeat_.p, CORR_LD, st);
+    mark(ST_LOOKUP, st);
+    s = conv_shape(convc1_, corrfeat_.p, CORR_LD, (long)N * CORR_LD, B, H8, W8, 1, 0, 0);
+    conv_sf_dispatch(s, convc1_.wscale, SfBias<ACT_RELU>{convc1_.b, cor1_.p, (long)N * 256, 256}, st);
+    mark(ST_CONVC1, st);
+  }
   s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
   static const bool small = !(getenv("ATDN_SMALL_CONVS") && getenv("ATDN_SMALL_CONVS")[0] == '0');
@@ -588,6 +606,29 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   ConvShape c;
   c.src0 = fmap_.p; c.ld0 = 256; c.sb0 = (long)N * 256; c.C0 = 256; c.H = 1; c.W = N;
   c.w = fmap_.p + (long)(seq_ ? 1 : B) * N * 256; c.wb = (long)N * 256; c.ldw = 256; c.N = N; c.nimg = B;
+  if (!lookup_legacy_) {
+    // every level = fmap1 x (target features of that level in BRICK order)^T: output column n' is the brick address of
+    // the target cell, padding cells are zero feature rows (lookup_fused.hip). Levels 1-3: 2x2-pooled features —
+    // correlation is linear in the target features, so avg_pool2d of corr.py:28-30 commutes with the dot product.
+    const float* target = c.w;
+    for (int l = 0; l < 4; ++l) {
+      const float* plain = target;
+      long plain_sb = (long)N * 256;
+      if (l > 0) {
+        const float* prev = l == 1 ? target : fplain_[l - 2].p;
+        const long prev_sb = l == 1 ? (long)N * 256 : (long)pyrH_[l - 1] * pyrW_[l - 1] * 256;
+        plain_sb = (long)pyrH_[l] * pyrW_[l] * 256;
+        launch_pool_features_sf(prev, B, pyrH_[l - 1], pyrW_[l - 1], 256, prev_sb, fplain_[l - 1].p, plain_sb, st);
+        plain = fplain_[l - 1].p;
+      }
+      launch_brick_rows(plain, plain_sb, B, pyrH_[l], pyrW_[l], 256, fbrick_[l].p, (long)brickNB_[l] * 256, st);
+      ConvShape cl = c;
+      cl.w = fbrick_[l].p; cl.wb = (long)brickNB_[l] * 256; cl.N = brickNB_[l];
+      conv_sf_dispatch(cl, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[l].p, (long)N * brickNB_[l], brickNB_[l]}, st);
+      if (l == 0) mark(ST_CORR, st);
+    }
+    mark(ST_POOL, st);
+  } else {
   conv_sf_dispatch(c, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[0].p, (long)N * N, N}, st);
   mark(ST_CORR, st);
   if (pool_features_) {
@@ -601,6 +642,7 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
     for (int l = 1; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
   }
   mark(ST_POOL, st);
+  }
 
   run_encoder_sf(cnet_, false, B, st, &f);
   s = conv_shape(cnet_.head, f, 128, (long)N * 128, B, H8, W8, 1, 0, 0);
@@ -715,8 +757,32 @@ void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const
   launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
 }
 
+BrickPyramid GmaNet::brick_pyramid() const {
+  BrickPyramid bp;
+  for (int l = 0; l < 4; ++l) {
+    bp.base[l] = pyr_[l].p; bp.H[l] = pyrH_[l]; bp.W[l] = pyrW_[l];
+    bp.BW[l] = brickBW_[l]; bp.BH[l] = brickBH_[l]; bp.NB[l] = brickNB_[l];
+  }
+  return bp;
+}
+
 long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_t st) {
   const std::string k(name);
+  if (!lookup_legacy_ && k.size() == 4 && k.compare(0, 3, "pyr") == 0 && k[3] >= '0' && k[3] <= '3') {
+    // bricked level -> the reference's row-major [pixel][H_l * W_l]
+    const int l = k[3] - '0';
+    const long rows = (long)maxB * N, total = rows * pyrH_[l] * pyrW_[l];
+    if (scratch_.n < total) { scratch_.release(); scratch_.alloc(total); }
+    launch_unbrick(pyr_[l].p, brickNB_[l], pyrH_[l], pyrW_[l], rows, scratch_.p, st);
+    ATDN_HIP(hipStreamSynchronize(st));
+    const long n = std::min(capacity, total);
+    ATDN_HIP(hipMemcpy(host, scratch_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return n;
+  }
+  if (!lookup_legacy_ && k == "corrfeat") {
+    // the fused kernel keeps the samples on chip: recompute them at the coordinates the last lookup used
+    launch_lookup_bricks(brick_pyramid(), coords_used_.p, (long)maxB * N, corrfeat_.p, st);
+  }
   if (k == "sf_clamped") {   // values the split-f16 format had to clamp (|x| > 65504 or NaN) since the last read
     ATDN_CHECK(capacity >= 1, "sf_clamped needs room for one float");
     host[0] = (float)sf_counter_read_reset(st);

@@ -97,4 +97,22 @@ void launch_init_coords_sf(const float* flow_init, int B, int H8, int W8, float*
 
 void launch_fill(float* p, long n, float v, hipStream_t st);
 
+// ---- bricked correlation pyramid + lookup fused with convc1 (lookup_fused.hip; split-f16 pipeline)
+// level l of ONE batch: [B*N][NB[l]] fp32, NB = BH * BW * 32; cell (y, x) of a pixel's map sits at
+// ((y >> 2) * BW + (x >> 3)) * 32 + (y & 3) * 8 + (x & 7); cells past H / W are zeros
+struct BrickPyramid {
+  const float* base[4];
+  int H[4], W[4], BW[4], BH[4], NB[4];
+};
+// feature rows [img][H*W][C] -> brick order [img][BH*BW*32][C] (zero rows for padding cells); sb / db per-image strides
+void launch_brick_rows(const float* src, long sb, int nimg, int H, int W, int C, float* dst, long db, hipStream_t st);
+// bricked level -> row-major [npix][H*W] (debug reads)
+void launch_unbrick(const float* src, long NB, int H, int W, long npix, float* dst, hipStream_t st);
+// cor1 = relu(convc1(lookup(coords1))) (corr.py:32-53 + update.py:76-78): out sf [npix][256]; wfrag = convc1 weights in
+// fragment-major order (K = 352), bias [256]; coords_used (optional) receives the coordinates that were sampled
+void launch_lookup_conv(const BrickPyramid& pyr, const float* coords1, long npix, float* coords_used, const float* wfrag,
+                        float wscale, const float* bias, float* out, bool fast, hipStream_t st);
+// the lookup alone: out sf [npix][352]
+void launch_lookup_bricks(const BrickPyramid& pyr, const float* coords1, long npix, float* out, hipStream_t st);
+
 }  // namespace atdn

@@ -1,0 +1,311 @@
+// Correlation-pyramid lookup on a BRICKED pyramid, fused with the 1x1 convolution behind it (split-f16 pipeline).
+//
+// Reference: CorrBlock.__call__ + bilinear_sampler (whl:GMA/core/corr.py:32-53, utils/utils.py:59-73) followed by
+// BasicMotionEncoder.convc1 (whl:GMA/core/update.py:76-78): corr = relu(convc1(lookup(coords))).
+//
+// Round 1 kept level l of the pyramid row-major, [source pixel][H_l * W_l] floats, and gathered a 12 x 12 window per
+// (pixel, level) with scalar loads: twelve 48-byte row segments from rows 616 bytes apart, 3.7x the bytes the lookup
+// needs on the HBM side (PMC), then wrote the 324 samples (352-channel sf rows, 81.5 MB per iteration at 8 pairs) for
+// the 1x1 convolution to read back. Here
+//   * a level is stored in BRICKS of 4 rows x 8 columns = 32 floats = one 128-byte line:
+//       map[source pixel][(by * BW_l + bx) * 32 + (y & 3) * 8 + (x & 7)], by = y >> 2, bx = x >> 3,
+//     cells past H_l / W_l are zeros (they ARE grid_sample's zero padding for taps just outside). The correlation GEMM
+//     writes this layout by itself: its "target pixel" operand is a copy of the feature map in brick order with zero
+//     rows for the padding cells, so output column n' is the brick address and every row is 128-byte aligned. Levels 1-3
+//     come from 2x2-pooled features (correlation is linear in the target features) the same way.
+//   * a 12 x 12 window touches at most 3 x 4 bricks: one wave fetches them as whole lines (8 lanes x 16 B per brick, two
+//     load instructions), three (pixel, level) units ahead;
+//   * a block owns 32 source pixels: its eight waves (level = wave & 3, sixteen pixels each) sample into a 32 x 352
+//     split-f16 tile in LDS — the A operand of the 1x1 convolution — and then multiply it with the fragment-major weights (straight
+//     from L2 into operand registers, as the halo kernels do) and store relu(. + bias) as sf rows. The sampled
+//     correlation features never touch HBM.
+// Sample arithmetic is that of lookup_sf_kernel (kernels.hip), step by step, so results are unchanged.
+#include "conv_mfma.h"
+#include "kernels.h"
+#include "sf.h"
+
+namespace atdn {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int TP = 32;            // source pixels per block
+constexpr int NCH = 352;          // 4 * 81 samples padded to a multiple of 32
+constexpr int APITCH = 1424;      // bytes per pixel row of the A tile: 11 x 128 + 16 (144 mod 256: conflict-free b128 reads)
+constexpr int GW = 28, GH = 24;   // per-wave window grid: 3 x 4 bricks (24 x 16 cells); pitch 28: the 9 sample rows hit distinct banks.
+                                  // Rows 16-23 are a dump for the lanes without a brick / a sample: the unit body has NO branch
+                                  // (a branch around an LDS store made the compiler drain every prefetched load, vmcnt(0), per unit)
+constexpr int DEPTH = 4;          // (pixel, level) units in flight per wave
+constexpr int NWAVE = 8;          // waves per block: level = wave & 3, pixels (wave >> 2) * 16 .. + 15
+constexpr int UPW = TP * 4 / NWAVE;   // units (pixels of its level) per wave
+
+struct Unit { float xc, yc; bool sane; int wx0, wy0, bx0, by0; };
+
+__device__ __forceinline__ Unit unit_origin(float cx, float cy, float inv) {
+  Unit u;
+  u.xc = cx * inv; u.yc = cy * inv;
+  u.sane = (fabsf(u.xc) < 1.0e6f) && (fabsf(u.yc) < 1.0e6f);   // also rejects NaN
+  u.wx0 = u.sane ? (int)floorf(u.xc) - 5 : -(1 << 24);
+  u.wy0 = u.sane ? (int)floorf(u.yc) - 5 : -(1 << 24);
+  u.bx0 = u.wx0 >> 3; u.by0 = u.wy0 >> 2;                       // arithmetic shifts: floor for negative origins
+  return u;
+}
+
+// lane -> brick bi = 8k + (lane >> 3) of the 3 x 4 block of bricks (bi < 12), 16-byte part lane & 7 of its line
+__device__ __forceinline__ void fetch_bricks(const float* __restrict__ map, int BWl, int BHl, const Unit& u, int lane,
+                                             v4f* v, bool* ok) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int bi = 8 * k + (lane >> 3);
+    const int byi = bi / 3, bxi = bi - 3 * byi;
+    const int bx = u.bx0 + bxi, by = u.by0 + byi;
+    // only the bricks the 12 x 12 window really touches: 2-3 columns, 3-4 rows of bricks
+    const int nbx = (((u.wx0 & 7) + 11) >> 3) + 1, nby = (((u.wy0 & 3) + 11) >> 2) + 1;
+    ok[k] = (bxi < nbx) & (byi < nby) & ((unsigned)bx < (unsigned)BWl) & ((unsigned)by < (unsigned)BHl);
+    v[k] = *reinterpret_cast<const v4f*>(map + (ok[k] ? ((long)by * BWl + bx) * 32 : 0) + (lane & 7) * 4);
+  }
+}
+
+// FUSED: multiply the sampled tile with convc1 and store relu(. + bias) as sf rows [pixel][256];
+// !FUSED: store the sampled tile itself as sf rows [pixel][352] (debug reads, the unfused comparison path)
+template <bool FUSED, bool FAST>
+__global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickPyramid pyr, const float* __restrict__ coords1,
+                                                            const long npix, float* __restrict__ coords_used,
+                                                            const float* __restrict__ wfrag, const float wscale,
+                                                            const float* __restrict__ bias, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char atile[TP * APITCH];
+  __shared__ __attribute__((aligned(16))) float grid[NWAVE][GH * GW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lvl = wave & 3, pbase = (wave >> 2) * UPW;
+  const long p0 = (long)blockIdx.x * TP;
+  const int np = (int)min((long)TP, npix - p0);
+
+  // pad channels 324..351 of every row are zero
+  for (int i = tid; i < TP * 28; i += NWAVE * 64) {
+    const int row = i / 28, c = 324 + (i - row * 28);
+    _Float16* q = reinterpret_cast<_Float16*>(atile + row * APITCH + (c >> 5) * 128) + (c & 31);
+    q[0] = (_Float16)0.f;
+    q[32] = (_Float16)0.f;
+  }
+
+  // ---- phase 1: wave lvl samples level lvl of the block's pixels
+  const int Hl = pyr.H[lvl], Wl = pyr.W[lvl], BWl = pyr.BW[lvl], BHl = pyr.BH[lvl];
+  const long NBl = pyr.NB[lvl];
+  const float inv = 1.0f / (float)(1 << lvl);
+  const float wm1 = (float)(Wl - 1), hm1 = (float)(Hl - 1);
+  const float* lvl_base = pyr.base[lvl];
+  // coordinates of the block's pixels: lane i holds pixel i (pixels past the end repeat the last one; never stored)
+  const long pc = p0 + min(lane & 31, np - 1);
+  const float2 cmine = *reinterpret_cast<const float2*>(coords1 + pc * 2);
+  if (lvl == 0 && lane < np && coords_used) *reinterpret_cast<float2*>(coords_used + (p0 + lane) * 2) = cmine;
+
+  Unit un[DEPTH];
+  v4f bv[DEPTH][2];
+  bool bok[DEPTH][2];
+  auto issue = [&](int pi, int slot) __attribute__((always_inline)) {
+    const int pp = min(pbase + pi, np - 1);
+    const float cx = __shfl(cmine.x, pp), cy = __shfl(cmine.y, pp);
+    un[slot] = unit_origin(cx, cy, inv);
+    fetch_bricks(lvl_base + (p0 + pp) * NBl, BWl, BHl, un[slot], lane, bv[slot], bok[slot]);
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d) issue(d, d);
+  float* gw = grid[wave];
+  bool clamped = false;   // saturation of the sf format, reported once after the loop (sf.h)
+  // per-lane constants of the unit body: grid slot of this lane's two brick parts, its two samples (i, j) and where
+  // they go in a pixel's row of the A tile (the 17 lanes past the 81st sample write to the dump rows of the grid)
+  int gofs[2], si[2], sj[2], dofs[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int bi = 8 * k + (lane >> 3);   // bricks 12..15 do not exist: their lanes write zeros to rows 16..23
+    const int byi = bi / 3, bxi = bi - 3 * byi, part = lane & 7;
+    gofs[k] = (byi * 4 + (part >> 1)) * GW + bxi * 8 + (part & 1) * 4;
+    const int kk = min(lane + 64 * k, 80);
+    si[k] = kk / 9; sj[k] = 9 + (kk - si[k] * 9);
+    const int c = lvl * 81 + kk;
+    dofs[k] = (c >> 5) * 128 + (c & 31) * 2;
+  }
+  char* const dump = reinterpret_cast<char*>(gw + 22 * GW) + (lane & 15) * 2;
+  static_assert(UPW % DEPTH == 0, "units per wave must be a multiple of the prefetch depth");
+  // the unit loop is unrolled by DEPTH so that the register slots are compile-time constants
+  for (int pi0 = 0; pi0 < UPW; pi0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int pi = pi0 + d;
+      {
+        issue(pi + DEPTH - 1, (d + DEPTH - 1) % DEPTH);
+        const Unit u = un[d];
+        // window bricks -> grid (the previous unit's reads are complete: LDS operations of one wave execute in order)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool ok = bok[d][k];
+          const v4f val = {ok ? bv[d][k].x : 0.f, ok ? bv[d][k].y : 0.f, ok ? bv[d][k].z : 0.f, ok ? bv[d][k].w : 0.f};
+          *reinterpret_cast<v4f*>(gw + gofs[k]) = val;
+        }
+        // lanes 0-8 / 9-17 evaluate the 9 x / 9 y coordinate chains (with the reference's divisions) once; every
+        // sample lane then takes its two weights and two grid indices from them by lane permutation
+        float mywgt = 0.f;
+        int myidx = 0;
+        {
+          const bool isx = lane < 9;
+          const int dd = isx ? lane : lane - 9;
+          const float c0 = isx ? u.xc : u.yc, sz1 = isx ? wm1 : hm1;
+          const float pos = c0 + (float)(dd - 4);
+          const float gg = 2.f * pos / sz1 - 1.f;
+          const float uu = (gg + 1.f) * (sz1 / 2.f);
+          const float fl = floorf(uu);
+          mywgt = uu - fl;
+          const int org = isx ? u.wx0 : u.wy0, gorg = isx ? u.wx0 - 8 * u.bx0 : u.wy0 - 4 * u.by0;
+          myidx = u.sane ? min(max((int)fl - org, 0), 10) + gorg : 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's grid writes
+        __builtin_amdgcn_wave_barrier();
+        char* arow = atile + (pbase + pi) * APITCH;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float ww = __shfl(mywgt, si[t]), nn = __shfl(mywgt, sj[t]);
+          const int ix = __shfl(myidx, si[t]), iy = __shfl(myidx, sj[t]);
+          const float ee = 1.f - ww, ss = 1.f - nn;
+          const float* q = gw + iy * GW + ix;
+          float v = ((q[0] * (ee * ss) + q[1] * (ww * ss)) + q[GW] * (ee * nn)) + q[GW + 1] * (ww * nn);
+          v = u.sane ? v : 0.f;
+          const SfPair sp = sf_split_flag(v, clamped);
+          // (no branch around the store: lanes past the 81st sample write to the dump rows)
+          _Float16* dst = reinterpret_cast<_Float16*>((t == 0 || lane < 17) ? arow + dofs[t] : dump);
+          dst[0] = sp.hi;
+          dst[32] = sp.lo;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();   // all reads of the grid done before the next unit overwrites it
+      }
+    }
+  }
+  sf_report(clamped);
+
+  // ---- phase 2: [32 pixels x 352] x convc1^T -> 256 channels. Wave w owns channel tile w (32 channels); weights come
+  // straight from L2 in operand order (one contiguous KiB per wave load) through a ring of WD chunks — six MFMAs per
+  // chunk cover far less than an L2 round trip, so the first WD chunks are requested BEFORE the barrier that ends the
+  // sampling phase; operands swapped (weights are the row operand), so a lane ends up with 4-channel runs of ONE pixel
+  // and stores 8 + 8 bytes.
+  constexpr int NQ = NCH / 32;
+  constexpr int WD = 4;
+  const int r = lane & 31, h = lane >> 5;
+  const char* wbase = reinterpret_cast<const char*>(wfrag) + (long)wave * NQ * 4096 + lane * 16;
+  f16x8 wh[WD][2], wl[WD][2];   // [slot][t]
+  auto load_w = [&](int slot, int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const char* p = wbase + (long)q * 4096 + t * 2048;
+      wh[slot][t] = *reinterpret_cast<const f16x8*>(p);
+      if (!FAST) wl[slot][t] = *reinterpret_cast<const f16x8*>(p + 1024);
+    }
+  };
+  if (FUSED) {
+#pragma unroll
+    for (int q = 0; q < WD; ++q) load_w(q, q);
+  }
+  __syncthreads();
+
+  if (!FUSED) {   // the sampled rows themselves: 352 channels = 1408 bytes per pixel, dwordx4 per thread
+    for (int i = tid; i < np * 88; i += NWAVE * 64) {
+      const int row = i / 88, part = i - row * 88;
+      *reinterpret_cast<v4f*>(reinterpret_cast<char*>(out) + (p0 + row) * (NCH * 4L) + part * 16) =
+          *reinterpret_cast<const v4f*>(atile + row * APITCH + part * 16);
+    }
+    return;
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const char* arow = atile + r * APITCH + 16 * h;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + q * 128 + 32 * t);
+      if (!FAST) {
+        const f16x8 al = *reinterpret_cast<const f16x8*>(arow + q * 128 + 32 * t + 64);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q % WD][t], al, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[q % WD][t], ah, acc, 0, 0, 0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q % WD][t], ah, acc, 0, 0, 0);
+    }
+    if (q + WD < NQ) load_w(q % WD, q + WD);
+  }
+  if (r < np) {
+    float* orow = out + (p0 + r) * 256;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int c = 32 * wave + 8 * jj + 4 * h;
+      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+      const float4 o = make_float4(fmaxf(acc[4 * jj] * wscale + b.x, 0.f), fmaxf(acc[4 * jj + 1] * wscale + b.y, 0.f),
+                                   fmaxf(acc[4 * jj + 2] * wscale + b.z, 0.f), fmaxf(acc[4 * jj + 3] * wscale + b.w, 0.f));
+      sf_store4(orow, 0, c, o);
+    }
+  }
+}
+
+// feature rows in brick order: dst[img][n'][C] = src[img][y * W + x][C] for the cell (y, x) that brick position n'
+// addresses, zero rows for the padding cells. One thread = 16 bytes (the sf chunk layout is copied verbatim).
+__global__ void brick_rows_kernel(const float* __restrict__ src, long sb, int H, int W, int BW, int C,
+                                  float* __restrict__ dst, long db, long total4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = C / 4;
+  const int part = (int)(i % c4);
+  const long row = i / c4;
+  const long per_img = db / C;
+  const long img = row / per_img;
+  const int n = (int)(row - img * per_img);
+  const int brick = n >> 5, within = n & 31;
+  const int y = (brick / BW) * 4 + (within >> 3), x = (brick % BW) * 8 + (within & 7);
+  v4f v = {0.f, 0.f, 0.f, 0.f};
+  if (y < H && x < W) v = *reinterpret_cast<const v4f*>(src + img * sb + ((long)y * W + x) * C + part * 4);
+  *reinterpret_cast<v4f*>(dst + img * db + (long)n * C + part * 4) = v;
+}
+
+// bricked level -> row-major [pixels][H * W] (debug reads)
+__global__ void unbrick_kernel(const float* __restrict__ src, long NB, int H, int W, int BW, float* __restrict__ dst,
+                               long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int hw = H * W;
+  const long p = i / hw;
+  const int c = (int)(i - p * hw);
+  const int y = c / W, x = c - y * W;
+  dst[i] = src[p * NB + ((long)(y >> 2) * BW + (x >> 3)) * 32 + (y & 3) * 8 + (x & 7)];
+}
+
+}  // namespace
+
+void launch_brick_rows(const float* src, long sb, int nimg, int H, int W, int C, float* dst, long db, hipStream_t st) {
+  ATDN_CHECK(C % 4 == 0 && db % C == 0, "brick_rows: bad geometry");
+  const int BW = (W + 7) / 8;
+  const long total4 = (long)nimg * (db / C) * (C / 4);
+  hipLaunchKernelGGL(brick_rows_kernel, dim3((unsigned)cdivl(total4, 256)), dim3(256), 0, st, src, sb, H, W, BW, C, dst, db, total4);
+  ATDN_HIP(hipGetLastError());
+}
+
+void launch_unbrick(const float* src, long NB, int H, int W, long npix, float* dst, hipStream_t st) {
+  const long total = npix * H * W;
+  hipLaunchKernelGGL(unbrick_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, src, NB, H, W, (W + 7) / 8, dst, total);
+  ATDN_HIP(hipGetLastError());
+}
+
+void launch_lookup_conv(const BrickPyramid& pyr, const float* coords1, long npix, float* coords_used, const float* wfrag,
+                        float wscale, const float* bias, float* out, bool fast, hipStream_t st) {
+  ATDN_CHECK(wfrag && bias && out, "lookup_conv: missing operand");
+  const dim3 grid((unsigned)cdivl(npix, TP));
+  if (fast) hipLaunchKernelGGL((lookup_conv_kernel<true, true>), grid, dim3(NWAVE * 64), 0, st, pyr, coords1, npix, coords_used, wfrag, wscale, bias, out);
+  else hipLaunchKernelGGL((lookup_conv_kernel<true, false>), grid, dim3(NWAVE * 64), 0, st, pyr, coords1, npix, coords_used, wfrag, wscale, bias, out);
+  ATDN_HIP(hipGetLastError());
+}
+
+void launch_lookup_bricks(const BrickPyramid& pyr, const float* coords1, long npix, float* out, hipStream_t st) {
+  hipLaunchKernelGGL((lookup_conv_kernel<false, false>), dim3((unsigned)cdivl(npix, TP)), dim3(NWAVE * 64), 0, st, pyr, coords1,
+                     npix, nullptr, nullptr, 1.f, nullptr, out);
+  ATDN_HIP(hipGetLastError());
+}
+
+}  // namespace atdn

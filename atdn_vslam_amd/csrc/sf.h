@@ -38,11 +38,33 @@ static SfCounterRegistration sf_counter_registration_;
 void sf_counter_attach();
 unsigned int sf_counter_read_reset(hipStream_t st);
 
+// For loops that keep loads in flight: the clamp is remembered in a register and reported ONCE, after the loop
+// (sf_report). A counted sf_split inside such a loop puts an atomic on a cold path of the loop, and the wait-count
+// pass then drains every outstanding load at the loop header (it cannot know whether the cold path ran).
+__device__ __forceinline__ SfPair sf_split_flag(float v, bool& clamped) {
+  clamped |= !(fabsf(v) <= 65504.f);
+  v = fminf(fmaxf(v, -65504.f), 65504.f);
+  SfPair p;
+  p.hi = (_Float16)v;
+  p.lo = (_Float16)(v - (float)p.hi);
+  return p;
+}
+__device__ __forceinline__ void sf_report(bool clamped) {
+  if (__builtin_expect(clamped, 0)) {
+    unsigned int* c = *const_cast<unsigned int* volatile*>(&sf_clamp_counter_tu_);
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    if (c && (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u)) == 0u)
+      atomicAdd(c, (unsigned)__builtin_popcountll(act));
+  }
+}
+
 __device__ __forceinline__ SfPair sf_split(float v) {
   if (__builtin_expect(!(fabsf(v) <= 65504.f), 0)) {   // clamped value or NaN: rare, counted
     // one atomic per wave (the lanes that got here, counted by the first of them): a tensor that saturates everywhere
     // would otherwise serialise millions of atomics on one address
-    unsigned int* c = sf_clamp_counter_tu_;
+    // (volatile: the pointer is read HERE, on the cold path. Left to itself the compiler hoists the load above the
+    // branch, and waiting for it — vmcnt retires in order — drains every prefetch a kernel has in flight, per call)
+    unsigned int* c = *const_cast<unsigned int* volatile*>(&sf_clamp_counter_tu_);
     const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
     if (c && (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u)) == 0u)
       atomicAdd(c, (unsigned)__builtin_popcountll(act));

@@ -201,3 +201,36 @@ def test_fused_attention_agrees_with_the_separate_passes(gsd, monkeypatch):
         assert _maxerr(new[2], old[2]) < 1e-6 + 1e-4 * float(old[2].max())
         assert _maxerr(new[3], old[3]) < 1e-4          # motion_features_global after the last iteration
         assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4
+
+
+def test_bricked_pyramid_and_fused_lookup_agree_with_the_separate_kernels(gsd, monkeypatch):
+    """Round-2 lookup (bricked pyramid, every level a GEMM against pooled features, lookup fused with convc1) against the
+    round-1 path (row-major pyramid, pooled volume, separate lookup and 1x1 convolution; ATDN_LOOKUP_LEGACY=1): pyramid
+    levels, the 324 samples, and the flow, at the plumbing size and a ragged one with a non-zero flow_init (windows that
+    leave the map on every side)."""
+    sd = {"module." + k: v for k, v in gsd.items()}
+
+    def run(h, w):
+        m = RAFTGMA(max_batch=2, precision="split_f16")
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        fr = torch.from_numpy(syn.make_frames(3, h, w, seed=31)).to(DEV)
+        h8, w8 = h // 8, w // 8
+        r = np.random.RandomState(5)
+        fi = torch.from_numpy(r.uniform(-0.7, 0.7, (2, 2, h8, w8)).astype(np.float32) * np.array([w8, h8], np.float32).reshape(1, 2, 1, 1))
+        low, up = m.forward_sequence(fr, iters=3, flow_init=fi.to(DEV))
+        n = h8 * w8
+        pyr = [m.debug_read("pyr%d" % l, (2 * n, (h8 >> l) * (w8 >> l)), h, w) for l in range(4)]
+        look = m.debug_read("corrfeat", (2 * n, 352), h, w)[:, :324]
+        return low.cpu(), up.cpu(), pyr, look
+
+    for (h, w) in ((160, 512), (184, 328)):
+        new = run(h, w)
+        monkeypatch.setenv("ATDN_LOOKUP_LEGACY", "1")
+        old = run(h, w)
+        monkeypatch.delenv("ATDN_LOOKUP_LEGACY")
+        for l in range(4):
+            assert _maxerr(new[2][l], old[2][l]) < 2e-5, l      # pooled features vs pooled volume: fp32 rounding only
+        assert _maxerr(new[3], old[3]) < 1e-4
+        assert float(old[3].abs().max()) > 0.1 and float((old[3] == 0).float().mean()) > 0.01   # inside AND outside the map
+        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4
