@@ -10,7 +10,6 @@ import torch.nn.functional as F
 
 from . import transforms
 from .modules import ATDNVO, RAFTGMA
-from .sharding import sharded_odometry
 
 SLAM_SIZE = (376, 1232)  # neural_slam.py:198
 
@@ -116,20 +115,31 @@ class OdometryPipeline:
         return rot[:, 0], tr[:, 0]
 
     @torch.no_grad()
-    def run_sequence(self, frames, batch=4, group=None):
-        """frames [T,3,H,W] on the device (every rank holds the clip or at least its shard + 1 frame).
-        Returns absolute poses [T,4,4] float64 (identity first), identical on every rank."""
-        n_pairs = frames.shape[0] - 1
+    def run_sequence(self, frames, batch=4, group=None, antialias=True):
+        """A whole sequence -> absolute poses [T,4,4] float64 (identity first), identical on every rank of `group`.
 
-        def encode(lo, hi):
-            out = []
-            for s in range(lo, hi, batch):
-                e = min(s + batch, hi)
-                f, _ = self.features_clip(frames[s:e + 1], continued=(s > lo))   # consecutive clips of this shard
-                out.append(f)
-            return torch.cat(out) if out else torch.zeros((0, 512), device=self.device)
+        frames [T,3,Hin,Win]: uint8 in HOST memory (pinned for asynchronous copies; every rank needs at least its own
+        shard + 1 frame: the camera sequence as `evaluate_odometry.py` / NeuralSLAM walk it, neural_slam.py:196-221), or a
+        tensor already on the device (uint8 or float). Each rank takes the contiguous shard `shard_range` gives it, walks it
+        in clips of `batch` pairs (host frames: H2D on the ingest's copy stream + convert + resize; device frames: resize),
+        reuses the features of the frame two clips share, and the ranks exchange one all-gather of 512-d features
+        before the replicated ordered scan (sharding.py)."""
+        from .sharding import sharded_sequence
+        T = frames.shape[0]
+        host = not frames.is_cuda
+        if host and frames.dtype != torch.uint8:
+            raise RuntimeError("run_sequence: host frames must be uint8 (camera frames); move float frames to the device")
+        ingest = FrameIngest(tuple(frames.shape[-2:]), batch + 1, size=self.size, antialias=antialias,
+                             device=self.device) if host else None
 
-        rot, tr = sharded_odometry(n_pairs, encode, self.scan, group)
+        def encode_clip(s, e, continued):
+            clip = frames[s:e + 1]
+            fr = ingest(clip) if host else resize_frames(clip, self.size, antialias=antialias)
+            f, _ = self.features_clip(fr, continued=continued)
+            return f
+
+        encode_clip.device = self.device
+        rot, tr = sharded_sequence(T, encode_clip, self.scan, batch, group)
         return transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
 
 

@@ -56,3 +56,35 @@ def sharded_odometry(n_pairs, encode_pairs, scan, group=None):
     local = encode_pairs(lo, hi)
     feats = gather_features(local, n_pairs, group)
     return scan(feats)
+
+
+def clip_plan(lo, hi, batch):
+    """Clips of at most `batch` consecutive pairs covering pairs [lo, hi) of a sequence, in order:
+    [(first_pair, stop_pair, continued)]. Clip (s, e) needs frames s..e inclusive; `continued` is True when frame s was
+    the last frame of the previous clip of the SAME shard (its features can be reused). A shard need not start on a
+    multiple of `batch`: its first clip is simply not continued."""
+    return [(s, min(s + batch, hi), s > lo) for s in range(lo, hi, batch)]
+
+
+def sharded_sequence(n_frames, encode_clip, scan, batch, group=None):
+    """The sequence driver: frames 0..n_frames-1 -> (rot, tr) of the n_frames-1 pairs, identical on every rank.
+
+    encode_clip(first_pair, stop_pair, continued) -> [stop_pair-first_pair, 512] features of that clip (local work:
+    frame ingest, flow, CNN encoder); clips of one shard are requested in order. scan as in sharded_odometry."""
+    def encode_pairs(lo, hi):
+        parts = [encode_clip(s, e, c) for (s, e, c) in clip_plan(lo, hi, batch)]
+        if not parts:
+            return None
+        return torch.cat(parts, dim=0)
+
+    n_pairs = max(n_frames - 1, 0)
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    lo, hi = shard_range(n_pairs, rank, world)
+    local = encode_pairs(lo, hi)
+    if local is None:   # empty shard: a [0, 512] block on the device / dtype the scan expects
+        local = torch.zeros((0, 512), dtype=torch.float32, device=getattr(encode_clip, "device", "cpu"))
+    feats = gather_features(local, n_pairs, group)
+    return scan(feats)

@@ -11,7 +11,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from atdn_vslam_amd import synthetic as syn  # noqa: E402
-from atdn_vslam_amd.sharding import gather_features, shard_range, sharded_odometry  # noqa: E402
+from atdn_vslam_amd.sharding import clip_plan, gather_features, shard_range, sharded_odometry, sharded_sequence  # noqa: E402
 from oracle import clvo_ref  # noqa: E402
 
 
@@ -48,6 +48,21 @@ def main():
     tag = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
     full = gather_features(tag, n_pairs)
     assert torch.equal(full[:, 0], torch.arange(n_pairs, dtype=torch.float32))
+    # the sequence driver: clips of `batch` pairs inside each shard; a shard that does not start on a multiple of the
+    # clip length begins with a non-continued clip, every later clip of the shard continues the previous one
+    batch = 4
+    seen = []
+
+    def encode_clip(s, e, continued):
+        seen.append((s, e, continued))
+        assert 0 < e - s <= batch
+        return clvo_ref.clvo_encode(hsd, flows[s:e])     # pair p = flow p (frames p, p + 1)
+
+    rot2, tr2 = sharded_sequence(n_pairs + 1, encode_clip, scan, batch)
+    assert seen == clip_plan(lo, hi, batch)
+    assert all(c == (s > lo) for (s, e, c) in seen) and (not seen or (seen[0][0] == lo and seen[-1][1] == hi))
+    # (the CPU oracle's convolutions round differently for different batch sizes: equal to fp32 noise, not bit for bit)
+    assert float((rot2 - rot).abs().max()) < 1e-6 and float((tr2 - tr).abs().max()) < 1e-6
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rot=rot.numpy(), tr=tr.numpy())
     dist.barrier()
     dist.destroy_process_group()

@@ -234,3 +234,26 @@ def test_bricked_pyramid_and_fused_lookup_agree_with_the_separate_kernels(gsd, m
         assert _maxerr(new[3], old[3]) < 1e-4
         assert float(old[3].abs().max()) > 0.1 and float((old[3] == 0).float().mean()) > 0.01   # inside AND outside the map
         assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4
+
+
+def test_sequence_driver_from_host_uint8_matches_frame_by_frame(gsd, hsd):
+    """The sequence driver on a 40-frame uint8 camera sequence in (pinned) host memory — ingest (H2D on the copy stream
+    + convert + resize) clip by clip, continued clips, one ordered scan — against the reference's call pattern frame by
+    frame (VisualOdometry = NeuralSLAM.__call__ in odometry mode, neural_slam.py:192-227). World size 1 here; the
+    sharding of the same driver over ranks is covered on gloo (tests/test_sharding.py)."""
+    from atdn_vslam_amd.pipeline import OdometryPipeline, VisualOdometry
+    frames = _u8_sequence(40, seed=77).pin_memory()
+    pipe = OdometryPipeline(gsd, hsd, device=DEV, max_batch=8)
+    poses = pipe.run_sequence(frames, batch=8)
+    assert poses.dtype == torch.float64 and tuple(poses.shape) == (40, 4, 4)
+    # a clip length that does not divide the sequence (39 pairs = 5 x 7 + 4) gives the same trajectory
+    poses7 = pipe.run_sequence(frames, batch=7)
+    assert _maxerr(poses7, poses) < 1e-5
+    vo = VisualOdometry(gsd, hsd, device=DEV)
+    for i in range(40):
+        p = vo(frames[i])
+        if i in (1, 17, 39):
+            assert _maxerr(poses[i].float(), p) < 2e-4, i      # fp64 vs fp32 pose accumulation over up to 39 steps
+    assert float(poses[-1][:3, 3].norm()) > 0.1
+    # device-resident uint8 frames take the same path minus the copy
+    assert _maxerr(pipe.run_sequence(frames.to(DEV), batch=8), poses) == 0.0

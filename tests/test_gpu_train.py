@@ -61,3 +61,37 @@ def test_cosine_schedule_closed_form():
         sch.step()
     for i, r in enumerate(sched_ref):
         assert abs(cosine_lr(i, 1e-3, 7, 1e-9) - r) < 1e-15
+
+
+def test_gradient_buffer_all_reduces_through_rccl(golden_dir):
+    """Data-parallel path, as far as ONE GPU can show it (two ranks cannot share the leased card, the 8-GPU run is the
+    driver's): the library-owned flat gradient buffer, seen by torch through __cuda_array_interface__, goes through a
+    real RCCL all-reduce (world size 1) between forward_backward and the AdamW kernel. The collective must leave the
+    gradients bit for bit unchanged, be ordered after the backward kernels and before the optimiser (the update equals
+    the one of an identical trainer that skipped the collective), and a SUM over a 1-rank group followed by the mean
+    division must be the identity."""
+    import torch.distributed as dist
+    g = np.load(os.path.join(golden_dir, "train.npz"))
+    B, T = int(g["B"]), int(g["T"])
+    kw = dict(device=DEV, lr=float(g["hp_lr"]), weight_decay=float(g["hp_wd"]), eps=float(g["hp_eps"]),
+              total_steps=int(g["hp_total_steps"]), eta_min=float(g["hp_eta_min"]))
+    sd = syn.to_torch(syn.make_clvo_state(seed=int(g["seed_weights"])))
+    fl = torch.from_numpy(syn.make_flow(B * T, 376, 1232, seed=int(g["seed_flow"]))).view(B, T, 2, 376, 1232).to(DEV)
+    rot, trn = torch.from_numpy(g["true_rot0"]), torch.from_numpy(g["true_tr0"])
+    ref = CLVOTrainer(sd, B, T, **kw)
+    ref.forward_backward(fl, rot, trn)
+    want_grads = ref.grads.clone()
+    ref.optimizer_step()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29731", world_size=1, rank=0,
+                            device_id=torch.device(DEV))
+    try:
+        tr = CLVOTrainer(sd, B, T, **kw)
+        tr.forward_backward(fl, rot, trn)
+        dist.all_reduce(tr.grads, op=dist.ReduceOp.SUM)       # what allreduce_mean_ issues when world > 1
+        tr.grads.div_(dist.get_world_size())
+        assert torch.equal(tr.grads, want_grads)
+        tr.optimizer_step()
+        for k in ("lstm1.weight_hh", "encoder_CNN.1.conv.weight", "rotation_regressor.2.weight"):
+            assert torch.equal(tr.parameter(k), ref.parameter(k)), k
+    finally:
+        dist.destroy_process_group()

@@ -27,6 +27,22 @@ def test_shard_range_partitions_the_sequence():
     assert [shard_range(4540, r, 8)[1] - shard_range(4540, r, 8)[0] for r in range(8)] == [568] * 4 + [567] * 4
 
 
+def test_clip_plan_covers_a_shard_in_order():
+    from atdn_vslam_amd.sharding import clip_plan
+    assert clip_plan(0, 0, 8) == []
+    assert clip_plan(0, 8, 8) == [(0, 8, False)]
+    assert clip_plan(6, 11, 4) == [(6, 10, False), (10, 11, True)]          # shard not aligned to the clip length
+    for n, world, batch in ((4540, 8, 8), (11, 2, 4), (5, 3, 2)):
+        got = []
+        for r in range(world):
+            lo, hi = shard_range(n, r, world)
+            plan = clip_plan(lo, hi, batch)
+            assert all(0 < e - s <= batch for s, e, _ in plan)
+            assert [c for _, _, c in plan] == [i > 0 for i in range(len(plan))]
+            got += [p for s, e, _ in plan for p in range(s, e)]
+        assert got == list(range(n))
+
+
 def _single_process(n_pairs):
     hsd = syn.to_torch(syn.make_clvo_state(seed=1))
     flows = torch.from_numpy(syn.make_flow(n_pairs, 376, 1232, seed=31))
@@ -41,7 +57,7 @@ def _single_process(n_pairs):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,n_pairs", [(2, 6), (3, 5)])
+@pytest.mark.parametrize("world,n_pairs", [(2, 6), (3, 5), (2, 11)])   # (2, 11): rank 1 starts at pair 6, not a clip boundary
 def test_sharded_odometry_matches_single_process(tmp_path, world, n_pairs):
     port = 29600 + world * 7 + n_pairs
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
