@@ -45,6 +45,14 @@ class ClvoNet {
   DeviceBuf hseq2_;               // [(T+1)*Bs][512]: the h2 sequence of the pipelined scan
   bool pipe_ = true;              // ATDN_LSTM_PIPE=0: two scans of one launch per step each (earlier path)
   void ensure_scan(long rows, int Bs);
+  // the T + 2 dependent launches of the pipelined scan replay as ONE hipGraph per (T, Bs): the scan is bound by the rate
+  // of dependent launches (8.4 us per step issued eagerly, host-side), a graph replay leaves the ~1.3 us kernel boundary.
+  // The graph only references library-owned buffers (the caller's state is copied in and out around it).
+  DeviceBuf cstate_;              // [2][Bs][512]: c1, c2 of the scan in flight
+  std::map<std::pair<int, int>, hipGraphExec_t> scan_graphs_;
+  hipStream_t cap_stream_ = nullptr;
+  bool scan_graph_ = true;        // ATDN_NO_GRAPH=1: eager launches
+  void launch_scan_steps(int T, int Bs, hipStream_t st);
 };
 
 }  // namespace atdn

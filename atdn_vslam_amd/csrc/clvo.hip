@@ -25,7 +25,10 @@ ClvoNet::ClvoNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) 
 }
 
 ClvoNet::~ClvoNet() {
-  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &gates_, &x2_, &pre_, &hseq_, &x2seq_, &hseq2_}) b->release();
+  (void)hipDeviceSynchronize();   // a scan graph of this handle may still be running on the caller's stream
+  for (auto& kv : scan_graphs_) (void)hipGraphExecDestroy(kv.second);
+  if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
+  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &gates_, &x2_, &pre_, &hseq_, &x2seq_, &hseq2_, &cstate_}) b->release();
   arena_.release();
 }
 
@@ -101,6 +104,8 @@ void ClvoNet::finalize() {
   }
   conv16_ = !(getenv("ATDN_CLVO_CONV16") && getenv("ATDN_CLVO_CONV16")[0] == '0');
   pipe_ = !(getenv("ATDN_LSTM_PIPE") && getenv("ATDN_LSTM_PIPE")[0] == '0');
+  scan_graph_ = !(getenv("ATDN_NO_GRAPH") && getenv("ATDN_NO_GRAPH")[0] == '1');
+  ATDN_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
   for (Lin* l : {&fc_, &lstm1_ih_, &lstm1_hh_, &lstm_lin_, &lstm2_ih_, &lstm2_hh_, &rot_[0], &rot_[1], &rot_[2],
                  &tr_[0], &tr_[1], &tr_[2]}) {
     l->w = arena_.dev(l->w_off);
@@ -171,10 +176,36 @@ void ClvoNet::encode(const float* flow, int B, float* feat, hipStream_t st) {
 }
 
 void ClvoNet::ensure_scan(long rows, int Bs) {
-  if (pre_.n < rows * 2048) { pre_.release(); pre_.alloc(rows * 2048); }
-  if (hseq_.n < (rows + Bs) * 512) { hseq_.release(); hseq_.alloc((rows + Bs) * 512); }
-  if (x2seq_.n < rows * 512) { x2seq_.release(); x2seq_.alloc(rows * 512); }
-  if (hseq2_.n < (rows + Bs) * 512) { hseq2_.release(); hseq2_.alloc((rows + Bs) * 512); }
+  bool grown = false;
+  auto grow = [&](DeviceBuf& b, long n) { if (b.n < n) { b.release(); b.alloc(n); grown = true; } };
+  grow(pre_, rows * 2048);
+  grow(hseq_, (rows + Bs) * 512);
+  grow(x2seq_, rows * 512);
+  grow(hseq2_, (rows + Bs) * 512);
+  grow(cstate_, 2L * Bs * 512);
+  if (grown) {   // captured graphs hold the old addresses
+    (void)hipDeviceSynchronize();
+    for (auto& kv : scan_graphs_) (void)hipGraphExecDestroy(kv.second);
+    scan_graphs_.clear();
+  }
+}
+
+// the T + 2 launches of the three-stage pipeline (lstm1 step s, lstm_linear step s - 1, lstm2 step s - 2)
+void ClvoNet::launch_scan_steps(int T, int Bs, hipStream_t st) {
+  const long sb = (long)Bs * 512;
+  float* c1 = cstate_.p; float* c2 = cstate_.p + sb;
+  for (int sidx = 0; sidx < T + 2; ++sidx) {
+    LstmPipeArgs a{};
+    a.Hd = 512; a.B = Bs;
+    a.do1 = sidx < T; a.do_lin = sidx >= 1 && sidx <= T; a.do2 = sidx >= 2;
+    const int t1 = sidx < T ? sidx : 0, tl = a.do_lin ? sidx - 1 : 0, t2 = a.do2 ? sidx - 2 : 0;
+    a.pre1 = pre_.p + (long)t1 * Bs * 2048; a.Whh1 = lstm1_hh_.w; a.bhh1 = lstm1_hh_.b;
+    a.h1_in = hseq_.p + t1 * sb; a.c1 = c1; a.h1_out = hseq_.p + (t1 + 1) * sb;
+    a.Wlin = lstm_lin_.w; a.blin = lstm_lin_.b; a.lin_in = hseq_.p + (tl + 1) * sb; a.lin_out = x2seq_.p + tl * sb;
+    a.Wih2 = lstm2_ih_.w; a.bih2 = lstm2_ih_.b; a.Whh2 = lstm2_hh_.w; a.bhh2 = lstm2_hh_.b;
+    a.x2_in = x2seq_.p + t2 * sb; a.h2_in = hseq2_.p + t2 * sb; a.c2 = c2; a.h2_out = hseq2_.p + (t2 + 1) * sb;
+    launch_lstm_pipe(a, st);
+  }
 }
 
 // The recurrence of odometry/network.py:137-140 restructured so that only what is truly sequential stays in the
@@ -205,21 +236,40 @@ void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, f
   const MlpHead Tt{tr_[0].w, tr_[0].b, tr_[1].w, tr_[1].b, tr_[2].w};
   if (pipe_) {
     // lstm1 (step s), lstm_linear (step s - 1) and lstm2 with its input projection (step s - 2) share ONE launch per
-    // step: T + 2 dependent launches instead of 2T + 2 (the scan is bound by the launch rate)
+    // step: T + 2 dependent launches instead of 2T + 2, replayed as one hipGraph per (T, Bs)
     ATDN_HIP(hipMemcpyAsync(hseq_.p, h1, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     ATDN_HIP(hipMemcpyAsync(hseq2_.p, h2, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
-    for (int sidx = 0; sidx < T + 2; ++sidx) {
-      LstmPipeArgs a{};
-      a.Hd = 512; a.B = Bs;
-      a.do1 = sidx < T; a.do_lin = sidx >= 1 && sidx <= T; a.do2 = sidx >= 2;
-      const int t1 = sidx < T ? sidx : 0, tl = a.do_lin ? sidx - 1 : 0, t2 = a.do2 ? sidx - 2 : 0;
-      a.pre1 = pre_.p + (long)t1 * Bs * 2048; a.Whh1 = lstm1_hh_.w; a.bhh1 = lstm1_hh_.b;
-      a.h1_in = hseq_.p + t1 * sb; a.c1 = c1; a.h1_out = hseq_.p + (t1 + 1) * sb;
-      a.Wlin = lstm_lin_.w; a.blin = lstm_lin_.b; a.lin_in = hseq_.p + (tl + 1) * sb; a.lin_out = x2seq_.p + tl * sb;
-      a.Wih2 = lstm2_ih_.w; a.bih2 = lstm2_ih_.b; a.Whh2 = lstm2_hh_.w; a.bhh2 = lstm2_hh_.b;
-      a.x2_in = x2seq_.p + t2 * sb; a.h2_in = hseq2_.p + t2 * sb; a.c2 = c2; a.h2_out = hseq2_.p + (t2 + 1) * sb;
-      launch_lstm_pipe(a, st);
+    ATDN_HIP(hipMemcpyAsync(cstate_.p, c1, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ATDN_HIP(hipMemcpyAsync(cstate_.p + sb, c2, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (scan_graph_ && T >= 4) {
+      const auto key = std::make_pair(T, Bs);
+      if (!scan_graphs_.count(key)) {
+        hipGraph_t graph = nullptr;
+        ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
+        try {
+          launch_scan_steps(T, Bs, cap_stream_);
+        } catch (...) {
+          (void)hipStreamEndCapture(cap_stream_, &graph);
+          if (graph) (void)hipGraphDestroy(graph);
+          throw;
+        }
+        ATDN_HIP(hipStreamEndCapture(cap_stream_, &graph));
+        hipGraphExec_t exec = nullptr;
+        ATDN_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (scan_graphs_.size() >= 16) {   // bounded cache: sequences of many different lengths
+          (void)hipDeviceSynchronize();
+          for (auto& kv : scan_graphs_) (void)hipGraphExecDestroy(kv.second);
+          scan_graphs_.clear();
+        }
+        scan_graphs_[key] = exec;
+      }
+      ATDN_HIP(hipGraphLaunch(scan_graphs_[key], st));
+    } else {
+      launch_scan_steps(T, Bs, st);
     }
+    ATDN_HIP(hipMemcpyAsync(c1, cstate_.p, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ATDN_HIP(hipMemcpyAsync(c2, cstate_.p + sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     ATDN_HIP(hipMemcpyAsync(h1, hseq_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     ATDN_HIP(hipMemcpyAsync(h2, hseq2_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     launch_mlp_heads(hseq2_.p + sb, (int)rows, R, Tt, rot, tr, st);
