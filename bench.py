@@ -53,15 +53,17 @@ def kernel_table(stages, B):
     nn = float(N8) * N8
     spec = [
         # (stage, label, rocprof fragment, launches, bound, algorithmic work per launch)
-        ("aggregate", "attention x V (gma.py:102-115): streams the [N x N] attention matrix of every pair once",
-         "SfAggregate", ITERS, "hbm", nn * 4.0 * B),
+        ("aggregate", "attention x V (gma.py:102-115): streams the [N x N] attention matrix of every pair once "
+                      "(algorithmic bytes = fp32 storage, SURVEY 8d; the kernel stores 3 bytes per element)",
+         "attn_v_kernel", ITERS, "hbm", nn * 4.0 * B),
         ("gru_zr", "fused z|r ConvGRU convolution 1x5 / 5x1 (update.py:48-63), K = 5*384",
          "SfGruZR", 2 * ITERS, "mfma", 2.0 * N8 * 256 * 1920 * B),
         ("gru_q", "q ConvGRU convolution 1x5 / 5x1, K = 5*384", "SfGruQ", 2 * ITERS, "mfma", 2.0 * N8 * 128 * 1920 * B),
-        ("lookup", "correlation-pyramid lookup (corr.py:32-53)", "lookup", ITERS, "hbm", LOOKUP_BYTES * B),
-        ("convc1", "convc1 1x1 324->256 behind the lookup (update.py:76-78)", "SfBias<1>", ITERS, "mfma", 2.0 * N8 * 256 * 324 * B),
-        ("corr", "all-pairs correlation volume (corr.py:55-63), K = 256", "EpiScale", 1, "mfma", 2.0 * nn * 256 * B),
-        ("attention", "row softmax of the attention logits (gma.py:74)", "softmax_rows", 1, "hbm", 2.0 * nn * 4.0 * B),
+        ("lookup", "correlation-pyramid lookup fused with convc1 (corr.py:32-53 + update.py:76-78); bytes = SURVEY's "
+                   "lookup figure (<=400 cells read + 324 samples per pixel)", "lookup_conv_kernel", ITERS, "hbm", LOOKUP_BYTES * B),
+        ("corr", "all-pairs correlation volume, level 0 (corr.py:55-63), K = 256", "EpiScale", 1, "mfma", 2.0 * nn * 256 * B),
+        ("attention", "Q K^T with the row softmax fused in, full-precision sweep (gma.py:60-74), K = 128",
+         "qk_softmax_kernel<false", 1, "mfma", 2.0 * nn * 128 * B),
     ]
     rows = []
     for stage, label, frag, launches, bound, work in spec:
