@@ -68,6 +68,9 @@ __device__ __forceinline__ void h3_encode(const float* v, f16x8& hi, u32x2& byte
   bytes[1] = w1;
 }
 __device__ __forceinline__ f16x8 h3_decode_lo(f16x8 hi, u32x2 bytes) {
+  // through fp32: byte -> float (v_cvt_f32_ubyteN), minus 128, times 2^(E - 33), one conversion to f16. A packed-f16
+  // form (byte permute to 1024 + byte, v_pk_add_f16, v_pk_mul_f16: a third of the instructions) was measured 27 %
+  // SLOWER in the ping-pong kernel: packed VALU beside MFMAs is an anti-lever on this chip (MI355X_MICROARCH.md).
   _Float16 mx = hi[0];
 #pragma unroll
   for (int i = 1; i < 8; ++i) mx = hi[i] > mx ? hi[i] : mx;   // (values are non-negative)
@@ -78,7 +81,7 @@ __device__ __forceinline__ f16x8 h3_decode_lo(f16x8 hi, u32x2 bytes) {
   for (int i = 0; i < 8; ++i) {
     const unsigned w = bytes[i >> 2];
     const float q = (float)((w >> (8 * (i & 3))) & 255u) - 128.f;
-    lo[i] = (_Float16)(q * unit);   // exact while representable: |q| < 2^8 times a power of two
+    lo[i] = (_Float16)(q * unit);   // exact while representable: |q| <= 128 times a power of two
   }
   return lo;
 }
@@ -384,6 +387,200 @@ __global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict_
   }
 }
 
+// ---- attention x V as a two-set ping-pong (MI355X_MICROARCH.md, "Two waves per SIMD"). The timing ladder of
+// attn_v_kernel says its MFMA + LDS-read loop alone takes 339 of 362 us: every wave interleaves its own fragment reads,
+// decode VALU and loads with its own MFMAs, and both waves of a SIMD do the same thing at the same time. Here a block
+// is EIGHT waves (one strip each): waves 0-3 (set A) and 4-7 (set B) share the four SIMDs pairwise and alternate roles
+// every phase, separated by a barrier:
+//     phase 2q    : A multiplies chunk q (24 MFMAs back to back, every operand already in registers)
+//                   B does memory work: attention loads two chunks ahead, V^T fragments of chunk q from LDS into
+//                     registers, decode of the H3 residuals of chunk q (VALU beside A's MFMAs)
+//     phase 2q + 1: B multiplies chunk q
+//                   A does memory work: stages V^T chunk q + 2 into the LDS ring (three images), attention loads,
+//                     fragments + decode for chunk q + 1
+// so the matrix pipe of a SIMD always has one wave issuing MFMAs and nothing else, while its partner's LDS / VALU / VMEM
+// work runs beside it. Measured (H3, 8 pairs, same box): 4-wave kernel 372 us, ping-pong 315 us; without the attention
+// stream (zero operands) the MFMA + LDS loop alone takes 257 us here against 339 us in the 4-wave kernel.
+template <bool FAST, int FMT>
+__global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
+                                                        const AttnGeom g, const float* __restrict__ vT,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mf,
+                                                        float* __restrict__ out, const long sb, const int ld) {
+  constexpr int IMG = 128 * ROWB;      // V^T chunk: [128 channels][144 B]
+  constexpr int BLK = attn_blk_bytes(FMT);
+  constexpr bool H3 = FMT == AT_FMT_H3;
+  constexpr int D = 3;                 // attention chunks resident per wave (ring of register sets; 4 measured 2 % slower)
+  __shared__ __attribute__((aligned(16))) char lds[3 * IMG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool setA = wave < 4;
+  const int tiles = (g.RT + 7) >> 3;
+  const int id = xcd_remap(blockIdx.x, g.B * tiles);
+  const int b = id / tiles, tile = id - b * tiles;
+  const int strip = tile * 8 + wave;
+  const bool strip_ok = strip < g.RT;
+  const int r = lane & 31, h = lane >> 5;
+  const int m = strip * 32 + r;
+  const int Q = g.Q;
+
+  const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * BLK;
+  f16x8 ring[D][H3 ? 2 : 4];
+  u32x2 ringb[D][2];
+  auto loadP = [&](int q, int slot) __attribute__((always_inline)) {
+    const char* p = pblk + (long)min(q, Q - 1) * BLK;
+    if (H3) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ring[slot][t] = ld_frag_nt(p + t * 1024 + lane * 16);
+        ringb[slot][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ring[slot][u] = ld_frag_nt(p + u * 1024 + lane * 16);
+    }
+  };
+
+  // V^T staging (set A only: tid < 256): rows lr + 32 i, 16-byte slot ls; halves go to the bit-2/3-swapped positions
+  const int lr = (tid & 255) >> 3, ls = tid & 7;
+  const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
+  v4f breg[2][4];
+  auto fetchB = [&](int q, int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) breg[set][i] = *reinterpret_cast<const v4f*>(vrow + (long)(32 * i) * g.ldN + min(q, Q - 1) * 32);
+  };
+  const int sp = ls & 3;
+  const int boff = lr * ROWB + 64 * (ls >> 2) + 32 * (sp >> 1) + 8 * (sp & 1);
+  auto stashB = [&](int image, int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      char* d = lds + image * IMG + boff + 32 * i * ROWB;
+      *reinterpret_cast<float2*>(d) = make_float2(breg[set][i].x, breg[set][i].y);
+      *reinterpret_cast<float2*>(d + 16) = make_float2(breg[set][i].z, breg[set][i].w);
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  // operands of the chunk about to be multiplied, all in registers
+  f16x8 vh[2][4], vl[2][4], ph[2], pl[2];
+  const int foff = r * ROWB + 16 * h;
+  auto read_frags = [&](int image) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const char* vp = lds + image * IMG + foff + 32 * j * ROWB + 32 * t;
+        vh[t][j] = ld_frag(vp);
+        if (!FAST) vl[t][j] = ld_frag(vp + 64);
+      }
+  };
+  auto take_chunk = [&](int slot) __attribute__((always_inline)) {   // attention operands of a chunk out of the ring
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (H3) {
+        ph[t] = ring[slot][t];
+        if (!FAST) pl[t] = h3_decode_lo(ph[t], ringb[slot][t]);
+      } else {
+        ph[t] = ring[slot][2 * t];
+        pl[t] = ring[slot][2 * t + 1];
+      }
+    }
+  };
+  auto multiply = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!FAST) {
+          acc[j] = mfma(vl[t][j], ph[t], acc[j]);
+          acc[j] = mfma(vh[t][j], pl[t], acc[j]);
+        }
+        acc[j] = mfma(vh[t][j], ph[t], acc[j]);
+      }
+  };
+
+  constexpr int U = (D % 2) ? 2 * D : D;        // unroll: ring slots (D) x V^T register sets (2)
+  const int nq = (Q + U - 1) / U * U;           // surplus chunks multiply nothing (uniform branch), barriers still match
+  if (setA) {
+    // prologue: V^T chunks 0, 1 -> images 0, 1; chunks 2, 3 wait in the register sets; attention chunks 0..2
+    fetchB(0, 0);
+    fetchB(1, 1);
+#pragma unroll
+    for (int c = 0; c < D; ++c) loadP(c, c);
+    stashB(0, 0);
+    stashB(1, 1);
+    fetchB(2, 0);
+    fetchB(3, 1);
+    __syncthreads();                            // (1) images 0 and 1 published
+    read_frags(0);
+    take_chunk(0);
+    int image = 0;                              // LDS image of chunk q: q % 3
+    for (int q0 = 0; q0 < nq; q0 += U) {
+#pragma unroll
+      for (int d = 0; d < U; ++d) {
+        const int q = q0 + d;
+        const int image1 = image == 2 ? 0 : image + 1, image2 = image1 == 2 ? 0 : image1 + 1;
+        // phase 2q: multiply chunk q
+        __builtin_amdgcn_sched_barrier(0);
+        if (q < Q) multiply();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // phase 2q + 1: memory work. V^T chunk q + 2 (requested two iterations ago) -> image (q + 2) % 3, last read in
+        // phase 2q - 2; its register set takes chunk q + 4; the ring slot of chunk q takes chunk q + 3
+        stashB(image2, d & 1);
+        fetchB(q + 4, d & 1);
+        loadP(q + D, d % D);
+        read_frags(image1);                     // chunk q + 1: staged in phase 2q - 1, published by its barrier
+        take_chunk((d + 1) % D);
+        image = image1;
+        __syncthreads();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < D - 1; ++c) loadP(c, c);
+    __syncthreads();                            // (1)
+    int image = 0;
+    for (int q0 = 0; q0 < nq; q0 += U) {
+#pragma unroll
+      for (int d = 0; d < U; ++d) {
+        const int q = q0 + d;
+        // phase 2q: memory work: attention chunk q + 2 into the slot chunk q - 1 left, operands of chunk q
+        loadP(q + D - 1, (d + D - 1) % D);
+        read_frags(image);
+        take_chunk(d % D);
+        image = image == 2 ? 0 : image + 1;
+        __syncthreads();
+        // phase 2q + 1: multiply chunk q
+        __builtin_amdgcn_sched_barrier(0);
+        if (q < Q) multiply();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
+    }
+  }
+
+  if (strip_ok && m < g.N) {
+    const float rv = rinv[(long)b * g.Npad + m] * gamma[0];
+    const float* mfb = mf + (long)b * sb;
+    float* ob = out + (long)b * sb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int c = 32 * j + 8 * jj + 4 * h;
+        const float4 x = sf_load4(mfb, (long)m * ld, c);
+        const float4 o = make_float4(x.x + rv * acc[j][4 * jj], x.y + rv * acc[j][4 * jj + 1], x.z + rv * acc[j][4 * jj + 2],
+                                     x.w + rv * acc[j][4 * jj + 3]);
+        sf_store4(ob, (long)m * ld, c, o);
+      }
+  }
+}
+
 // one wave per (pair, strip, chunk) block: normalised probabilities as fp32 rows (tests / debug only)
 __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
                                                          const AttnGeom g, float* __restrict__ rows) {
@@ -438,12 +635,21 @@ void launch_qk_softmax(const float* qk, const AttnGeom& g, const float* rowmax, 
 void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const float* vT, const float* gamma,
                    const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st) {
   ATDN_CHECK(g.ldN % 32 == 0 && g.Q * 32 == g.ldN && ld % 32 == 0, "attention geometry");
-  const int nblk = g.B * ((g.RT + 3) / 4);
-  const dim3 gr(nblk), bl(256);
-#define ATDN_AV(FASTV, FMTV) hipLaunchKernelGGL((attn_v_kernel<FASTV, FMTV>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld)
-  if (g.fmt == AT_FMT_H3) { if (fast) ATDN_AV(true, AT_FMT_H3); else ATDN_AV(false, AT_FMT_H3); }
-  else { if (fast) ATDN_AV(true, AT_FMT_SF4); else ATDN_AV(false, AT_FMT_SF4); }
+  // ATDN_ATTN_PINGPONG=0: the 4-wave kernel (every wave interleaves its own memory work with its own MFMAs)
+  static const bool pingpong = !(getenv("ATDN_ATTN_PINGPONG") && getenv("ATDN_ATTN_PINGPONG")[0] == '0');
+  if (pingpong) {
+    const dim3 gr(g.B * ((g.RT + 7) / 8)), bl(512);
+#define ATDN_AV(FASTV, FMTV) hipLaunchKernelGGL((attn_v3_kernel<FASTV, FMTV>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld)
+    if (g.fmt == AT_FMT_H3) { if (fast) ATDN_AV(true, AT_FMT_H3); else ATDN_AV(false, AT_FMT_H3); }
+    else { if (fast) ATDN_AV(true, AT_FMT_SF4); else ATDN_AV(false, AT_FMT_SF4); }
 #undef ATDN_AV
+  } else {
+    const dim3 gr(g.B * ((g.RT + 3) / 4)), bl(256);
+#define ATDN_AV(FASTV, FMTV) hipLaunchKernelGGL((attn_v_kernel<FASTV, FMTV>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld)
+    if (g.fmt == AT_FMT_H3) { if (fast) ATDN_AV(true, AT_FMT_H3); else ATDN_AV(false, AT_FMT_H3); }
+    else { if (fast) ATDN_AV(true, AT_FMT_SF4); else ATDN_AV(false, AT_FMT_SF4); }
+#undef ATDN_AV
+  }
   ATDN_HIP(hipGetLastError());
 }
 
