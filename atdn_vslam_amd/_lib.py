@@ -63,7 +63,7 @@ SIGNATURES = {
 }
 
 GMA_STAGES = ("fnet", "corr", "pool", "cnet", "attention", "lookup", "motion_encoder", "aggregate", "gru_zr", "gru_q",
-              "flow_head", "mask", "gru_ctx", "attn_logits", "agg_vt", "convc1")
+              "flow_head", "mask", "gru_ctx", "attn_logits", "agg_vt", "convc1", "gru_zr_v", "gru_q_v")
 
 _lib = None
 

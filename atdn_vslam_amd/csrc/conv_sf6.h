@@ -525,8 +525,6 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
     for (int c : {128, 256})
       if (cdiv(s.N, c) * c <= best) { best = cdiv(s.N, c) * c; bn = c; }
   }
-  static const int cap = getenv("ATDN_SF6_MAX_BN") ? atoi(getenv("ATDN_SF6_MAX_BN")) : 256;   // diagnostic: widest block
-  while (bn > cap && bn > 64 && bn != 96) bn /= 2;
   // small grids: narrower blocks (more of them) until the chip is covered
   while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
   *th_out = 8;
@@ -548,9 +546,8 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   }
   if constexpr (KH == 3) {
     if (bn == 32) { *bn_out = 32; launch_conv_sf6<8, 32, 4, 1, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true; }
-    static const bool tall_ok = !(getenv("ATDN_NO_TALL_TILES") && getenv("ATDN_NO_TALL_TILES")[0] == '1');
     const long tiles12 = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
-    const bool tall = tall_ok && (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 &&
+    const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 &&
                       tiles12 * cdiv(s.N, bn) >= 512;
     if (tall) {
       *bn_out = bn; *th_out = 12;

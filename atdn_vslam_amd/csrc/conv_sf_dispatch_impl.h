@@ -25,8 +25,7 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
   // attention x V: the A operand (the attention matrix) is streamed once from HBM: three chunks of loads in flight
   // (measured per forward of 8 pairs: depth 1 5.16 ms, 2 5.03, 3 5.01, 4 5.55 — the fourth register set costs occupancy)
   if constexpr (std::is_same_v<Epi, SfAggregate>) {
-    static const int pf = getenv("ATDN_AGG_PREFETCH") ? atoi(getenv("ATDN_AGG_PREFETCH")) : 3;
-    if (pf > 1 && t.BM == 128 && t.BN == 128 && s.KH == 1 && s.KW == 1 && (s.C0 + s.C1) >= 2048) {
+    if (t.BM == 128 && t.BN == 128 && s.KH == 1 && s.KW == 1 && (s.C0 + s.C1) >= 2048) {
       if (sf_fast_mode()) launch_conv_sf<2, 2, 2, 2, Epi, true, 3>(s, wscale, ep, st);
       else launch_conv_sf<2, 2, 2, 2, Epi, false, 3>(s, wscale, ep, st);
       return t;

@@ -47,7 +47,7 @@ class GmaNet {
   // Eager (un-graphed) run on `st` with hipEvents at stage boundaries; ms[] receives the time of each Stage
   // summed over `reps` forwards. Inputs are whatever the last forward() left in the workspace.
   enum Stage { ST_FNET = 0, ST_CORR, ST_POOL, ST_CNET, ST_ATTN, ST_LOOKUP, ST_MOTION, ST_AGG, ST_GRU_ZR, ST_GRU_Q, ST_FLOWHEAD,
-               ST_MASK, ST_GRU_CTX, ST_ATTN_LOGITS, ST_AGG_VT, ST_CONVC1, ST_COUNT };
+               ST_MASK, ST_GRU_CTX, ST_ATTN_LOGITS, ST_AGG_VT, ST_CONVC1, ST_GRU_ZR_V, ST_GRU_Q_V, ST_COUNT };
   void profile(int B, int iters, int reps, float* ms, hipStream_t st);
 
   int H, W, H8, W8, N, ldN, maxB, precision;

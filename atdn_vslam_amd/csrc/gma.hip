@@ -369,10 +369,10 @@ void GmaNet::iteration(int B, hipStream_t st) {
     ConvShape g = conv_shape(gru_zr_[p], hin, 128, (long)N * 128, B, H8, W8, 1, ph, pw);
     g.C0 = 128; g.src1 = x_.p; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = XLD;
     conv_dispatch<MODE_TAP>(g, EpiGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128}, st);
-    mark(ST_GRU_ZR, st);
+    mark(p ? ST_GRU_ZR_V : ST_GRU_ZR, st);
     g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_dispatch<MODE_TAP>(g, EpiGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128}, st);
-    mark(ST_GRU_Q, st);
+    mark(p ? ST_GRU_Q_V : ST_GRU_Q, st);
   }
   // two passes: the state is back in h_[0]
 
@@ -533,13 +533,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   }
   s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
-  static const bool small = !(getenv("ATDN_SMALL_CONVS") && getenv("ATDN_SMALL_CONVS")[0] == '0');
-  if (small) {
-    launch_flow_conv7(flow4_.p, B, H8, W8, arena_.dev(convf1_vw_off_), convf1_.b, flo1_.p, st);
-  } else {
-    s = conv_shape(convf1_, flow4_.p, 4, (long)N * 4, B, H8, W8, 1, 3, 3);
-    conv_dispatch<MODE_ROW>(s, SfBias<ACT_RELU>{convf1_.b, flo1_.p, (long)N * 128, 128}, st);
-  }
+  launch_flow_conv7(flow4_.p, B, H8, W8, arena_.dev(convf1_vw_off_), convf1_.b, flo1_.p, st);
   s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
   s = conv_shape(convm_, corflo_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
@@ -573,21 +567,16 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
     g.C0 = 128; g.src1 = x_.p + 128; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = 256;  // [h | motion | motion_global]
     conv_sf_dispatch(g, gru_zr_[p].wscale,
                      SfGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128, pre_zr_[p].p, (long)N * 256}, st);
-    mark(ST_GRU_ZR, st);
+    mark(p ? ST_GRU_ZR_V : ST_GRU_ZR, st);
     g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_sf_dispatch(g, gru_q_[p].wscale, SfGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128, pre_q_[p].p}, st);
-    mark(ST_GRU_Q, st);
+    mark(p ? ST_GRU_Q_V : ST_GRU_Q, st);
   }
 
   s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, fh1_.wscale, SfBias<ACT_RELU>{fh1_.b, fh_.p, (long)N * 256, 256}, st);
   const SfFlowDelta fd{fh2_.b, coords1_.p, flow4_.p, x_.p, XLD, (long)N * XLD, 254, W8, (long)N};
-  if (small) {
-    launch_flow_head2(fh_.p, B, H8, W8, fh2_.w, fh2_.ldw, fh2_.wscale, fd, st);
-  } else {
-    s = conv_shape(fh2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
-    conv_sf_dispatch(s, fh2_.wscale, fd, st);
-  }
+  launch_flow_head2(fh_.p, B, H8, W8, fh2_.w, fh2_.ldw, fh2_.wscale, fd, st);
   mark(ST_FLOWHEAD, st);
 }
 

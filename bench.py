@@ -56,9 +56,12 @@ def kernel_table(stages, B):
         ("aggregate", "attention x V (gma.py:102-115): streams the [N x N] attention matrix of every pair once "
                       "(algorithmic bytes = fp32 storage, SURVEY 8d; the kernel stores 3 bytes per element)",
          "attn_v_kernel", ITERS, "hbm", nn * 4.0 * B),
-        ("gru_zr", "fused z|r ConvGRU convolution 1x5 / 5x1 (update.py:48-63), K = 5*384",
-         "SfGruZR", 2 * ITERS, "mfma", 2.0 * N8 * 256 * 1920 * B),
-        ("gru_q", "q ConvGRU convolution 1x5 / 5x1, K = 5*384", "SfGruQ", 2 * ITERS, "mfma", 2.0 * N8 * 128 * 1920 * B),
+        ("gru_zr", "fused z|r ConvGRU convolution, horizontal 1x5 pass (update.py:48-55), K = 5*384",
+         "1, 5, SfGruZR", ITERS, "mfma", 2.0 * N8 * 256 * 1920 * B),
+        ("gru_zr_v", "fused z|r ConvGRU convolution, vertical 5x1 pass (update.py:57-63), K = 5*384",
+         "5, 1, SfGruZR", ITERS, "mfma", 2.0 * N8 * 256 * 1920 * B),
+        ("gru_q", "q ConvGRU convolution, horizontal 1x5 pass, K = 5*384", "1, 5, SfGruQ", ITERS, "mfma", 2.0 * N8 * 128 * 1920 * B),
+        ("gru_q_v", "q ConvGRU convolution, vertical 5x1 pass, K = 5*384", "5, 1, SfGruQ", ITERS, "mfma", 2.0 * N8 * 128 * 1920 * B),
         ("lookup", "correlation-pyramid lookup fused with convc1 (corr.py:32-53 + update.py:76-78); bytes = SURVEY's "
                    "lookup figure (<=400 cells read + 324 samples per pixel)", "lookup_conv_kernel", ITERS, "hbm", LOOKUP_BYTES * B),
         ("corr", "all-pairs correlation volume, level 0 (corr.py:55-63), K = 256", "EpiScale", 1, "mfma", 2.0 * nn * 256 * B),

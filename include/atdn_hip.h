@@ -81,11 +81,14 @@ long atdn_gma_debug_read(atdn_gma* h, const char* name, float* host, long capaci
 
 /* Per-stage device time (ms, summed over `reps` eager forwards of batch B), measured with HIP events on
  * `stream`. ms_out has ATDN_GMA_STAGES entries: fnet, corr, pool, cnet, attention (row softmax), lookup, motion_encoder
- * (without convc1), aggregate (the attention x V kernel alone), gru_zr (fused z|r convolution), gru_q, flow_head, mask,
- * gru_ctx (once-per-pair context part of the GRU convolutions; split-f16 pipeline only), attn_logits (q,k projection +
- * Q K^T), agg_vt (the v^T projection in front of attention x V), convc1 (the 1x1 convolution behind the lookup).
- * Stages that hold launches of ONE kernel (aggregate, gru_zr, gru_q, lookup, corr) divide into per-launch times. */
-#define ATDN_GMA_STAGES 16
+ * (without convc1), aggregate (the attention x V kernel alone), gru_zr (fused z|r convolution, horizontal 1x5 pass),
+ * gru_q (horizontal pass), flow_head, mask, gru_ctx (once-per-pair context part of the GRU convolutions; split-f16
+ * pipeline only), attn_logits (q,k projection + first QK^T sweep), agg_vt (the v^T projection in front of attention x V),
+ * convc1 (the 1x1 convolution behind the lookup; zero when it is fused into the lookup), gru_zr_v / gru_q_v (the vertical
+ * 5x1 passes).
+ * Stages that hold launches of ONE kernel (aggregate, gru_zr, gru_zr_v, gru_q, gru_q_v, lookup, corr) divide into
+ * per-launch times. */
+#define ATDN_GMA_STAGES 18
 int atdn_gma_profile(atdn_gma* h, int B, int iters, int reps, float* ms_out, void* stream);
 
 size_t atdn_gma_workspace_bytes(atdn_gma* h);
