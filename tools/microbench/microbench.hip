@@ -248,3 +248,4 @@ extern "C" int atdn_microbench_mfma(int steps, int launches, float* tf_out) {
     return 1;
   }
 }
+#include "pp_probe.hip"
