@@ -54,6 +54,8 @@ class GmaNet {
   // feature network, split-f16 pipeline: conv2 of every residual block normalises conv1's raw output in its own
   // patch loader (conv_sf6.h NORM); ATDN_NORM_ON_LOAD=0 keeps the separate normalisation pass
   bool norm_on_load_ = false;
+  // ATDN_STEM_LEGACY=1: the 7x7 stems on the exact-fp32 ROW-mode engine (conv_mfma.h) instead of stem_sf.hip
+  bool stem_legacy_ = false;
   // split-f16 pipeline: pyramid level 1 = fmap1 x (2x2-pooled fmap2)^T, a quarter-size GEMM, instead of pooling the
   // 210 MB level-0 volume (correlation is linear in the target features); ATDN_POOL_FEATURES=0 pools the volume
   bool pool_features_ = false;

@@ -62,6 +62,7 @@ EncoderWeights pack_encoder(WeightArena& A, const StateDict& sd, const std::stri
   };
   if (batchnorm) { auto a = fold(p + "norm1"); E.stem = pack_conv(A, sd, {p + "conv1"}, MODE_ROW, 4, &a); }
   else E.stem = pack_conv(A, sd, {p + "conv1"}, MODE_ROW, 4);
+  if (sf) pack_stem_sf(A, E.stem);
   int bi = 0;
   for (int li = 1; li <= 3; ++li)
     for (int k = 0; k < 2; ++k, ++bi) {
@@ -137,6 +138,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
   pool_features_ = precision >= 1 && !(getenv("ATDN_POOL_FEATURES") && getenv("ATDN_POOL_FEATURES")[0] == '0');
+  stem_legacy_ = getenv("ATDN_STEM_LEGACY") && getenv("ATDN_STEM_LEGACY")[0] == '1';
   norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
   lookup_legacy_ = precision == 0 || (getenv("ATDN_LOOKUP_LEGACY") && getenv("ATDN_LOOKUP_LEGACY")[0] == '1');
   attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
@@ -454,7 +456,23 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
       launch_in_finalize_cnt(psum_.p, pm2_.p, nullptr, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p,
                              reinterpret_cast<double*>(fin_.p), st);
   };
-  if (instance) {
+  if (!stem_legacy_) {
+    // 7x7 stem on the split-f16 engine (stem_sf.hip); with InstanceNorm the conv runs twice (statistics, then
+    // normalise + ReLU -> sf) instead of materialising the raw tensor
+    if (instance) {
+      const int groups = stem_sf_groups(h, w);
+      ATDN_CHECK((long)nimg * groups * 64 <= psum_.n && (long)nimg * groups <= pcnt_.n, "statistics scratch too small");
+      launch_stem_sf(1, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, nullptr, psum_.p, pm2_.p, pcnt_.p, nullptr,
+                     nullptr, st);
+      launch_in_finalize_cnt(psum_.p, pm2_.p, pcnt_.p, nimg, groups, h * w, 64, 1e-5f, mean_[0].p, rstd_[0].p,
+                             reinterpret_cast<double*>(fin_.p), st);
+      launch_stem_sf(2, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, X, nullptr, nullptr, nullptr, mean_[0].p,
+                     rstd_[0].p, st);
+    } else {
+      launch_stem_sf(0, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, X, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, st);
+    }
+  } else if (instance) {
     ConvShape s = conv_shape(E.stem, images, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
     EpiBiasStats ep{E.stem.b, R, (long)h * w * 64, 64, psum_.p, pm2_.p, 0};
     TileChoice t = conv_dispatch<MODE_ROW>(s, ep, st);

@@ -15,6 +15,15 @@ struct PyramidLevels {  // correlation pyramid of ONE batch: level l is [B*N][H_
 // n2 = number of images taken from im2 (B for pair mode; 1 in sequence mode: only the clip's last frame)
 void launch_prep_images(const float* im1, const float* im2, int B, int H, int W, float* img4, hipStream_t st, int n2);
 
+// 7x7 / stride-2 stem of the GMA encoders on the split-f16 engine (stem_sf.hip). img4: NHWC4 fp32 frames; wfrag / wscale:
+// pack_stem_sf copy (weights.h). mode 0: relu(conv + bias) -> out_sf [nimg][Ho*Wo][64]; mode 1: InstanceNorm partials only
+// (part_* as launch_in_finalize_cnt reads them, stem_sf_groups(Ho, Wo) groups per image); mode 2: relu((conv + bias -
+// mean) * rstd) -> out_sf with mean / rstd [nimg][64]
+int stem_sf_groups(int Ho, int Wo);
+void launch_stem_sf(int mode, const float* img4, int nimg, int H, int W, const float* wfrag, float wscale,
+                    const float* bias, float* out_sf, float* part_sum, float* part_m2, float* part_cnt,
+                    const float* mean, const float* rstd, hipStream_t st);
+
 // InstanceNorm statistics from the conv epilogue's per-(32-row group) partials -> mean, rstd [nimg][C], merged with
 // Chan's formula in fp64 in two levels (8 slabs of groups per image, then one merge). part_cnt [nimg][groups] = valid
 // rows per group as the 2-D tiled conv kernels report them; nullptr for the 1-D tiled kernels (rows follow from the

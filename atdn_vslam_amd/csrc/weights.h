@@ -190,6 +190,33 @@ inline PackedConv pack_conv_sf(WeightArena& A, const StateDict& sd, const std::v
   return L;
 }
 
+// Split-f16 fragment-major copy of the 7x7 stem (ROW-packed fp32 rows [64][7 x 32], k = ky*32 + kx*4 + c) for
+// stem_sf.hip: [n-tile j = 0,1][K step q = 0..13][hi, lo][lane] x 16 B; lane (r, h) holds row 32 j + r, k = 16 q + 8 h .. + 7.
+// Weights are pre-multiplied by 2^p (maximum in [1,2)); L.wscale = 2^-p.
+inline void pack_stem_sf(WeightArena& A, PackedConv& L) {
+  ATDN_CHECK(L.mode == MODE_ROW && L.KH == 7 && L.KW == 7 && L.C == 4 && L.ldw == 224 && L.N == 64, "stem shape");
+  L.wf_off = A.alloc(2L * 14 * 2 * 256);
+  const float* w = A.at(L.w_off);  // (alloc may have moved the arena)
+  float mx = 0.f;
+  for (long i = 0; i < (long)L.N * L.ldw; ++i) mx = std::max(mx, std::fabs(w[i]));
+  int e = 0;
+  if (mx > 0.f) (void)std::frexp(mx, &e);
+  const int p = 1 - e;
+  L.wscale = std::ldexp(1.0f, -p);
+  _Float16* f = reinterpret_cast<_Float16*>(A.at(L.wf_off));
+  for (int nt = 0; nt < 2; ++nt)
+    for (int q = 0; q < 14; ++q)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, h = lane >> 5;
+        for (int m = 0; m < 8; ++m) {
+          const float v = std::ldexp(w[(long)(nt * 32 + r) * L.ldw + 16 * q + 8 * h + m], p);
+          const _Float16 hi = (_Float16)v;
+          f[(((long)(nt * 14 + q) * 2 + 0) * 64 + lane) * 8 + m] = hi;
+          f[(((long)(nt * 14 + q) * 2 + 1) * 64 + lane) * 8 + m] = (_Float16)(v - (float)hi);
+        }
+      }
+}
+
 // Stack several convs along Cout, keep only input channels in the given [begin,end) ranges (in that order), and pack
 // the result in sf form. Used to split the ConvGRU weights into the iteration-invariant context part and the rest.
 inline PackedConv pack_conv_sf_channels(WeightArena& A, const StateDict& sd, const std::vector<std::string>& names,

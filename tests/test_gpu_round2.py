@@ -236,6 +236,36 @@ def test_bricked_pyramid_and_fused_lookup_agree_with_the_separate_kernels(gsd, m
         assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4
 
 
+def test_split_f16_stem_agrees_with_the_exact_fp32_stem(gsd, monkeypatch):
+    """The 7x7 stems on the split-f16 engine (stem_sf.hip; InstanceNorm = statistics pass + recompute-and-normalise
+    pass, nothing raw in memory) against the exact-fp32 ROW-mode stem + separate normalisation they replaced
+    (ATDN_STEM_LEGACY=1): feature maps (fnet, InstanceNorm), hidden state / context (cnet, folded BatchNorm) and flow.
+    Sizes: the plumbing size, one whose half-resolution map has partial tiles in both directions (92 x 164: 92 % 8 = 4,
+    164 % 32 = 4), and KITTI (188 x 616)."""
+    sd = {"module." + k: v for k, v in gsd.items()}
+
+    def run(h, w):
+        m = RAFTGMA(max_batch=2, precision="split_f16")
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        fr = torch.from_numpy(syn.make_frames(3, h, w, seed=37)).to(DEV)
+        low, up = m.forward_sequence(fr, iters=2)
+        n = (h // 8) * (w // 8)
+        fmap = m.debug_read("fmap", (3 * n, 256), h, w)
+        x = m.debug_read("x", (2 * n, 384), h, w)[:, :128]      # relu half of the context network's output
+        return low.cpu(), up.cpu(), fmap, x
+
+    for (h, w) in ((160, 512), (184, 328), (376, 1232)):
+        new = run(h, w)
+        monkeypatch.setenv("ATDN_STEM_LEGACY", "1")
+        old = run(h, w)
+        monkeypatch.delenv("ATDN_STEM_LEGACY")
+        assert float(old[2].abs().max()) > 0.1 and float(old[3].abs().max()) > 0.01
+        assert _maxerr(new[2], old[2]) < 2e-5 * max(1.0, float(old[2].abs().max())), (h, w)
+        assert _maxerr(new[3], old[3]) < 2e-5 * max(1.0, float(old[3].abs().max())), (h, w)
+        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4, (h, w)
+
+
 def test_sequence_driver_from_host_uint8_matches_frame_by_frame(gsd, hsd):
     """The sequence driver on a 40-frame uint8 camera sequence in (pinned) host memory — ingest (H2D on the copy stream
     + convert + resize) clip by clip, continued clips, one ordered scan — against the reference's call pattern frame by
