@@ -225,7 +225,7 @@ void GmaNet::finalize() {
   if (sf && attn_legacy_) sim_.alloc((long)B * N * ldN);
   fmap_.alloc(2L * B * N * 256);
   const long groups = (long)cdiv(H2 * W2, 64) * 4 + 8;
-  psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128); pcnt_.alloc(2L * B * groups); fin_.alloc(2L * B * 8 * 128 * 3 * 2);
+  psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128); pcnt_.alloc(2L * B * groups); fin_.alloc(2L * B * 32 * 128 * 4 * 2);
   for (int i = 0; i < 2; ++i) { mean_[i].alloc(2L * B * 128); rstd_[i].alloc(2L * B * 128); }
   pyrH_[0] = H8; pyrW_[0] = W8;
   for (int l = 1; l < 4; ++l) { pyrH_[l] = pyrH_[l - 1] / 2; pyrW_[l] = pyrW_[l - 1] / 2; }

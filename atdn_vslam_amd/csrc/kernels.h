@@ -24,13 +24,13 @@ void launch_stem_sf(int mode, const float* img4, int nimg, int H, int W, const f
                     const float* bias, float* out_sf, float* part_sum, float* part_m2, float* part_cnt,
                     const float* mean, const float* rstd, hipStream_t st);
 
-// InstanceNorm statistics from the conv epilogue's per-(32-row group) partials -> mean, rstd [nimg][C], merged with
-// Chan's formula in fp64 in two levels (8 slabs of groups per image, then one merge). part_cnt [nimg][groups] = valid
-// rows per group as the 2-D tiled conv kernels report them; nullptr for the 1-D tiled kernels (rows follow from the
-// group index).
+// InstanceNorm statistics from the conv epilogue's per-(32-row group) partials -> mean, rstd [nimg][C], merged in fp64
+// in two levels (32 slabs of groups per image, then one merge in a fixed order).
+// part_cnt [nimg][groups] = valid rows per group as the 2-D tiled conv kernels report them; nullptr for the 1-D tiled
+// kernels (rows follow from the group index).
 void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const float* part_cnt, int nimg,
                             int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, double* scratch,
-                            hipStream_t st);  // scratch: nimg * 8 * C * 3 doubles
+                            hipStream_t st);  // scratch: nimg * 32 * C * 4 doubles
 // y = relu((x-mean)*rstd); optional residual: y = relu(r + y), r = res or (res-rmean)*rrstd when rmean given
 void launch_in_apply(float* x, const float* mean, const float* rstd, const float* res, const float* rmean,
                      const float* rrstd, int nimg, long HW, int C, hipStream_t st);

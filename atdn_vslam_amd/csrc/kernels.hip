@@ -51,24 +51,29 @@ void launch_prep_images(const float* im1, const float* im2, int B, int H, int W,
 }
 
 // ------------------------------------------------------------------ instance norm
-// One block per (image, 64-channel slab): lane = channel (coalesced partial reads), 16 waves stride over the
-// 32-row groups; every thread folds its groups with Chan's (count, mean, M2) merge in fp64, then the 16 partial
-// triples of a channel are merged in a fixed order through LDS (deterministic).
-// Two levels so that the merge of ~3700 (count, mean, M2) triples per channel is spread over the chip:
-// level 1: block (channel slab of 64, image, split z of FIN_SPLIT) folds its share of the groups (16 waves stride
-// over them, fp64 Chan merge) into one triple per channel; level 2: one thread per (image, channel) merges the
-// FIN_SPLIT triples in a fixed order and writes mean / rstd.
-constexpr int FIN_SPLIT = 8;
+// mean / rstd [nimg][C] from the conv epilogues' per-(32-row group, channel) partials (sum, M2 about the group mean,
+// valid rows), in two levels so that the ~3700 groups per channel are spread over the chip:
+// level 1: block (channel slab of 64, image, split z of FIN_SPLIT) folds its share of the groups in fp64 — lane =
+//   channel (coalesced partial reads), 16 waves stride over the groups, then merge through LDS in a fixed order — into
+//   (n, S1 = sum of sums, Sq = sum of sum_g^2 / n_g, M2 = sum of M2_g);
+// level 2: one thread per (image, channel) adds the FIN_SPLIT quadruples in a fixed order (deterministic) and writes
+//   mean = S1 / n,   var = (M2 + Sq - S1^2 / n) / HW.
+// The between-group term comes from the sum-of-squares identity: in fp64 its cancellation costs mean^2 / var * 1e-16,
+// and it needs no division per group. The pass is latency-bound (a thread walks its groups one dependent load pair at a
+// time): 32 slabs instead of 8 took level 1 from 17 to 8 us on the largest layer set. A single launch with a
+// last-block-merges counter was measured SLOWER (28 us): a device-scope release on this chip writes back the XCD's
+// whole L2.
+constexpr int FIN_SPLIT = 32;
 __global__ __launch_bounds__(1024) void in_finalize_cnt_kernel(const float* __restrict__ ps,
                                                                const float* __restrict__ pm2,
                                                                const float* __restrict__ pc, int groups, int C,
                                                                int HW, double* __restrict__ part) {
-  __shared__ double s_n[16][64], s_mu[16][64], s_m2[16][64];
+  __shared__ double s_n[16][64], s_s1[16][64], s_sq[16][64], s_m2[16][64];
   const int img = blockIdx.y, z = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const int per = (groups + FIN_SPLIT - 1) / FIN_SPLIT;
   const int g0 = z * per, g1 = min(groups, g0 + per);
-  double n = 0.0, mu = 0.0, m2 = 0.0;
+  double n = 0.0, s1 = 0.0, sq = 0.0, m2 = 0.0;
   if (c < C) {
     const float* s = ps + (long)img * groups * C + c;
     const float* m = pm2 + (long)img * groups * C + c;
@@ -76,31 +81,23 @@ __global__ __launch_bounds__(1024) void in_finalize_cnt_kernel(const float* __re
 #pragma unroll 8
     for (int g = g0 + wv; g < g1; g += 16) {
       // valid rows of the group: from the kernel's count, or (1-D M tiling) the rows of the image inside it
-      const double cnt = cn ? (double)cn[g] : (double)max(0, min(32, HW - g * 32));
-      if (cnt > 0.0) {
-        const double gmu = (double)s[(long)g * C] / cnt;
-        const double tot = n + cnt, d = gmu - mu;
-        mu += d * (cnt / tot);
-        m2 += (double)m[(long)g * C] + d * d * (n * cnt / tot);
-        n = tot;
+      const float cnt = cn ? cn[g] : (float)max(0, min(32, HW - g * 32));
+      if (cnt > 0.f) {
+        const double sg = (double)s[(long)g * C];
+        n += (double)cnt;
+        s1 += sg;
+        sq += sg * sg * (cnt == 32.f ? 0.03125 : 1.0 / (double)cnt);
+        m2 += (double)m[(long)g * C];
       }
     }
   }
-  s_n[wv][lane] = n; s_mu[wv][lane] = mu; s_m2[wv][lane] = m2;
+  s_n[wv][lane] = n; s_s1[wv][lane] = s1; s_sq[wv][lane] = sq; s_m2[wv][lane] = m2;
   __syncthreads();
   if (wv == 0 && c < C) {
-    n = 0.0; mu = 0.0; m2 = 0.0;
-    for (int k = 0; k < 16; ++k) {
-      const double cnt = s_n[k][lane];
-      if (cnt > 0.0) {
-        const double tot = n + cnt, d = s_mu[k][lane] - mu;
-        mu += d * (cnt / tot);
-        m2 += s_m2[k][lane] + d * d * (n * cnt / tot);
-        n = tot;
-      }
-    }
-    double* o = part + (((long)img * FIN_SPLIT + z) * C + c) * 3;
-    o[0] = n; o[1] = mu; o[2] = m2;
+    n = 0.0; s1 = 0.0; sq = 0.0; m2 = 0.0;
+    for (int k = 0; k < 16; ++k) { n += s_n[k][lane]; s1 += s_s1[k][lane]; sq += s_sq[k][lane]; m2 += s_m2[k][lane]; }
+    double* o = part + (((long)img * FIN_SPLIT + z) * C + c) * 4;
+    o[0] = n; o[1] = s1; o[2] = sq; o[3] = m2;
   }
 }
 __global__ void in_finalize_merge_kernel(const double* __restrict__ part, int nimg, int HW, int C, float eps,
@@ -108,19 +105,15 @@ __global__ void in_finalize_merge_kernel(const double* __restrict__ part, int ni
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nimg * C) return;
   const int img = i / C, c = i - img * C;
-  double n = 0.0, mu = 0.0, m2 = 0.0;
+  double n = 0.0, s1 = 0.0, sq = 0.0, m2 = 0.0;
   for (int z = 0; z < FIN_SPLIT; ++z) {
-    const double* p = part + (((long)img * FIN_SPLIT + z) * C + c) * 3;
-    const double cnt = p[0];
-    if (cnt > 0.0) {
-      const double tot = n + cnt, d = p[1] - mu;
-      mu += d * (cnt / tot);
-      m2 += p[2] + d * d * (n * cnt / tot);
-      n = tot;
-    }
+    const double* p = part + (((long)img * FIN_SPLIT + z) * C + c) * 4;
+    n += p[0]; s1 += p[1]; sq += p[2]; m2 += p[3];
   }
+  const double mu = n > 0.0 ? s1 / n : 0.0;
+  const double between = n > 0.0 ? fmax(sq - s1 * s1 / n, 0.0) : 0.0;
   mean[i] = (float)mu;
-  rstd[i] = (float)(1.0 / sqrt(m2 / (double)HW + (double)eps));
+  rstd[i] = (float)(1.0 / sqrt((m2 + between) / (double)HW + (double)eps));
 }
 void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const float* part_cnt, int nimg,
                             int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, double* scratch,
