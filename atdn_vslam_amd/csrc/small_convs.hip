@@ -9,7 +9,8 @@
 namespace atdn {
 
 // ---------------------------------------------------------------------------------------------- 7x7, 2 -> 128
-// block: 8x16 output pixels x 128 channels; thread: 4 pixels (along x) x 8 channels, twice (channels c and 64 + c)
+// block: 8x16 output pixels x 128 channels; thread: 8 pixels (half a tile row) x 8 channels. Every weight vector read
+// from LDS feeds 8 pixels (4 in the first version: its weight reads took as long as its FMAs)
 __global__ __launch_bounds__(256) void flow_conv7_kernel(const float4* __restrict__ flow4, int H, int W,
                                                          const float* __restrict__ wl /*[98][128]*/,
                                                          const float* __restrict__ bias, float* __restrict__ out, long ob,
@@ -32,47 +33,44 @@ __global__ __launch_bounds__(256) void flow_conv7_kernel(const float4* __restric
     ps[py][px] = v;
   }
   __syncthreads();
-  const int pg = tid & 31, cg = tid >> 5;
-  const int row = pg >> 2, xg = pg & 3;
+  const int pg = tid & 15, cg = tid >> 4;
+  const int row = pg >> 1, xg = pg & 1;
+  const int ch0 = cg * 8;
+  float acc[8][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
 #pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    const int ch0 = half * 64 + cg * 8;
-    float acc[4][8];
+  for (int ky = 0; ky < 7; ++ky) {
+    float2 in[14];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 14; ++i) in[i] = ps[row + ky][xg * 8 + i];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-#pragma unroll 1
-    for (int ky = 0; ky < 7; ++ky) {
-      float2 in[10];
+    for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
-      for (int i = 0; i < 10; ++i) in[i] = ps[row + ky][xg * 4 + i];
+      for (int c = 0; c < 2; ++c) {
+        const float4* wp = reinterpret_cast<const float4*>(ws + ((ky * 7 + kx) * 2 + c) * 128 + ch0);
+        const float4 w0 = wp[0], w1 = wp[1];
+        const float w8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int kx = 0; kx < 7; ++kx)
+        for (int j = 0; j < 8; ++j) {
+          const float v = c ? in[j + kx].y : in[j + kx].x;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const float4* wp = reinterpret_cast<const float4*>(ws + ((ky * 7 + kx) * 2 + c) * 128 + ch0);
-          const float4 w0 = wp[0], w1 = wp[1];
-          const float w8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float v = c ? in[j + kx].y : in[j + kx].x;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[j][e] += v * w8[e];
-          }
+          for (int e = 0; e < 8; ++e) acc[j][e] += v * w8[e];
         }
-    }
-    const float4 b0 = *reinterpret_cast<const float4*>(bias + ch0), b1 = *reinterpret_cast<const float4*>(bias + ch0 + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int oy = ty0 + row, ox = tx0 + xg * 4 + j;
-      if (oy < H && ox < W) {
-        const long off = (long)img * ob + ((long)oy * W + ox) * 128;
-        sf_store4(out, off, ch0, make_float4(fmaxf(acc[j][0] + b0.x, 0.f), fmaxf(acc[j][1] + b0.y, 0.f),
-                                             fmaxf(acc[j][2] + b0.z, 0.f), fmaxf(acc[j][3] + b0.w, 0.f)));
-        sf_store4(out, off, ch0 + 4, make_float4(fmaxf(acc[j][4] + b1.x, 0.f), fmaxf(acc[j][5] + b1.y, 0.f),
-                                                 fmaxf(acc[j][6] + b1.z, 0.f), fmaxf(acc[j][7] + b1.w, 0.f)));
       }
+  }
+  const float4 b0 = *reinterpret_cast<const float4*>(bias + ch0), b1 = *reinterpret_cast<const float4*>(bias + ch0 + 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int oy = ty0 + row, ox = tx0 + xg * 8 + j;
+    if (oy < H && ox < W) {
+      const long off = (long)img * ob + ((long)oy * W + ox) * 128;
+      sf_store4(out, off, ch0, make_float4(fmaxf(acc[j][0] + b0.x, 0.f), fmaxf(acc[j][1] + b0.y, 0.f),
+                                           fmaxf(acc[j][2] + b0.z, 0.f), fmaxf(acc[j][3] + b0.w, 0.f)));
+      sf_store4(out, off, ch0 + 4, make_float4(fmaxf(acc[j][4] + b1.x, 0.f), fmaxf(acc[j][5] + b1.y, 0.f),
+                                               fmaxf(acc[j][6] + b1.z, 0.f), fmaxf(acc[j][7] + b1.w, 0.f)));
     }
   }
 }
