@@ -32,9 +32,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int TP = 32;            // source pixels per block
 constexpr int NCH = 352;          // 4 * 81 samples padded to a multiple of 32
 constexpr int APITCH = 1424;      // bytes per pixel row of the A tile: 11 x 128 + 16 (144 mod 256: conflict-free b128 reads)
-constexpr int GW = 28, GH = 24;   // per-wave window grid: 3 x 4 bricks (24 x 16 cells); pitch 28: the 9 sample rows hit distinct banks.
-                                  // Rows 16-23 are a dump for the lanes without a brick / a sample: the unit body has NO branch
-                                  // (a branch around an LDS store made the compiler drain every prefetched load, vmcnt(0), per unit)
+constexpr int GW = 24, GH = 24;   // per-wave window grid: 3 x 4 bricks (24 x 16 cells). Pitch 24 dwords = -8 (mod 32 banks): the four
+                                  // rows x two 16-byte halves a brick's eight lanes write (ds_write_b128: groups of 8 lanes) are eight
+                                  // distinct bank quads, and a 32-lane group of sample reads (ds_read_b32) laid out as 8 x-positions x 4
+                                  // rows is 32 distinct banks. (Pitch 28 with samples in channel order: SQ_LDS_BANK_CONFLICT = 25 % of
+                                  // the kernel's LDS cycles.) Rows 16-23 are a dump for the lanes without a brick / a sample: the unit
+                                  // body has NO branch (a branch around an LDS store made the compiler drain every prefetched load,
+                                  // vmcnt(0), per unit)
 constexpr int DEPTH = 4;          // (pixel, level) units in flight per wave
 constexpr int NWAVE = 8;          // waves per block: level = wave & 3, pixels (wave >> 2) * 16 .. + 15
 constexpr int UPW = TP * 4 / NWAVE;   // units (pixels of its level) per wave
@@ -120,8 +124,12 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
     const int bi = 8 * k + (lane >> 3);   // bricks 12..15 do not exist: their lanes write zeros to rows 16..23
     const int byi = bi / 3, bxi = bi - 3 * byi, part = lane & 7;
     gofs[k] = (byi * 4 + (part >> 1)) * GW + bxi * 8 + (part & 1) * 4;
-    const int kk = min(lane + 64 * k, 80);
-    si[k] = kk / 9; sj[k] = 9 + (kk - si[k] * 9);
+    // sample (i, j) of this lane: pass 0 = the 8 x 8 block i, j < 8 (i = lane & 7: every 32-lane half reads 8 columns x 4
+    // rows); pass 1 = column i = 8 (lanes 0-8) and row j = 8 (lanes 9-16); lanes 17-63 of pass 1 write to the dump
+    const int i9 = k == 0 ? (lane & 7) : (lane < 9 ? 8 : min(lane - 9, 7));
+    const int j9 = k == 0 ? (lane >> 3) : (lane < 9 ? lane : 8);
+    const int kk = i9 * 9 + j9;
+    si[k] = i9; sj[k] = 9 + j9;
     const int c = lvl * 81 + kk;
     dofs[k] = (c >> 5) * 128 + (c & 31) * 2;
   }
