@@ -99,7 +99,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
   const int lane = tid & 63, wave = tid >> 6;
 
   // ---- patch loader role (registers, true zero padding)
-  const int s = tid & 7, r0 = tid >> 3;
+  // (NORM: its loader writes 8-byte halves, ds_write_b64 = groups of 16 lanes = two patch rows; with rows 4 apart —
+  // 4 x 36 dwords = 16 mod 32 banks — instead of adjacent the two rows' 16 banks do not overlap. SQ_LDS_BANK_CONFLICT of
+  // the normalise-on-load kernels was 11-15 % of their LDS cycles.)
+  const int s = tid & 7, r0 = NORM ? ((tid >> 6) << 3) + (((tid >> 3) & 7) >> 1) + 4 * ((tid >> 3) & 1) : tid >> 3;
   // per patch row of this thread: (pixel offset in the image + 1, 0 = zero padding) << 12 | LDS offset / 16
   static_assert((TH + KH - 1) * RS / 16 <= 4096, "LDS offset field");
   unsigned pmeta[NP];

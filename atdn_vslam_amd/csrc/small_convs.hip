@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void flow_conv7_kernel(const float4* __restric
                                                          const float* __restrict__ bias, float* __restrict__ out, long ob,
                                                          int tiles_x, int tiles_img) {
   __shared__ __attribute__((aligned(16))) float ws[98 * 128];
-  __shared__ float2 ps[14][24];
+  __shared__ float2 ps[14][33];   // pitch 66 dwords = 2 (mod 64 banks): the 8 rows x 2 column groups one ds_read_b64 touches are 16 distinct bank pairs (pitch 24: rows r and r + 4 collide)
   const int tid = threadIdx.x;
   const int img = blockIdx.x / tiles_img, tloc = blockIdx.x - img * tiles_img;
   const int ty0 = (tloc / tiles_x) * 8, tx0 = (tloc % tiles_x) * 16;
