@@ -160,10 +160,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ATDN_BENCH_REHEARSAL=1: the N > 1 code path on a ONE-GPU box — every rank on cuda:0, gloo instead of RCCL (which
+    # refuses two ranks on one device). Checks the sharding / gather / scan plumbing only; its numbers mean nothing.
+    rehearsal = os.environ.get("ATDN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -269,7 +277,7 @@ def main():
             "metric": "frame-pairs/sec, KITTI 1241x376 odometry inference at 1/2/4/8 MI355X",
             "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_LABEL[args.precision], "data": "synthetic",
+            "dtype": DTYPE_LABEL[args.precision], "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""),
             "config": {"workload": "KITTI seq-03-shaped 376x1241 uint8 frames (resident in HBM) resized to 376x1232, GMA flow "
                                    "12 GRU iters + CLVO head -> 6-DoF trajectory (BASELINE configs[1])",
                        "pairs_per_step_per_gpu": B, "streams_per_gpu": S, "gru_iters": ITERS, "parallelism": "pairs sharded x%d, one "
