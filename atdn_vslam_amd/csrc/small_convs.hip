@@ -114,9 +114,10 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const float* __restrict
   float acc0 = 0.f, acc1 = 0.f;
   // the patch of chunk c + 1 is fetched into registers while chunk c is multiplied (180 pixels x 8 slots = 1440
   // 16-byte pieces, 6 per thread)
+  // (TWO chunks ahead, in two register sets: with one, every chunk waited out most of an HBM round trip — SQ_WAIT_ANY 0.55)
   constexpr int NPF = (180 * 8 + 255) / 256;
-  float4 pre[NPF];
-  auto fetch = [&](int chunk) {
+  float4 pre[2][NPF];
+  auto fetch = [&](int chunk, int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
       const int i = tid + 256 * k;
@@ -125,10 +126,12 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const float* __restrict
       const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
       const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       const float4 v = *reinterpret_cast<const float4*>(simg + ((long)(ok ? iy : 0) * W + (ok ? ix : 0)) * 256 + chunk * 32 + slot * 4);
-      pre[k] = keep_if(ok, v);
+      pre[set][k] = keep_if(ok, v);
     }
   };
-  fetch(0);
+  fetch(0, 0);
+  fetch(1, 1);
+#pragma unroll
   for (int chunk = 0; chunk < 8; ++chunk) {
     __syncthreads();
 #pragma unroll
@@ -137,11 +140,11 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const float* __restrict
       if (i < 180 * 8) {
         const int slot = i & 7, prow = i >> 3;
         const int ry = prow / 18, rx = prow - ry * 18;
-        *reinterpret_cast<float4*>(patch + ry * FH_RS + rx * 144 + slot * 16) = pre[k];
+        *reinterpret_cast<float4*>(patch + ry * FH_RS + rx * 144 + slot * 16) = pre[chunk & 1][k];
       }
     }
     __syncthreads();
-    if (chunk + 1 < 8) fetch(chunk + 1);
+    if (chunk + 2 < 8) fetch(chunk + 2, chunk & 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const char* p = patch + (py + tap / 3) * FH_RS + (px + tap % 3) * 144 + half * 32;
