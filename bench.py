@@ -55,7 +55,7 @@ def kernel_table(stages, B):
         # (stage, label, rocprof fragment, launches, bound, algorithmic work per launch)
         ("aggregate", "attention x V (gma.py:102-115): streams the [N x N] attention matrix of every pair once "
                       "(algorithmic bytes = fp32 storage, SURVEY 8d; the kernel stores 3 bytes per element)",
-         "attn_v_kernel", ITERS, "hbm", nn * 4.0 * B),
+         "attn_v", ITERS, "hbm", nn * 4.0 * B),
         ("gru_zr", "fused z|r ConvGRU convolution, horizontal 1x5 pass (update.py:48-55), K = 5*384",
          "1, 5, SfGruZR", ITERS, "mfma", 2.0 * N8 * 256 * 1920 * B),
         ("gru_zr_v", "fused z|r ConvGRU convolution, vertical 5x1 pass (update.py:57-63), K = 5*384",
