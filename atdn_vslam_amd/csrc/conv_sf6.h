@@ -50,6 +50,8 @@ template <class E, class = void> struct epi_gen6 : std::integral_constant<int, 0
 template <class E> struct epi_gen6<E, std::void_t<decltype(E::kGen6)>> : std::integral_constant<int, E::kGen6> {};
 template <class E, class = void> struct EpiAux4 { struct type {}; };
 template <class E> struct EpiAux4<E, std::void_t<typename E::Aux4>> { using type = typename E::Aux4; };
+template <class E, class = void> struct epi_flowhead : std::false_type {};
+template <class E> struct epi_flowhead<E, std::void_t<decltype(E::kFlowHead)>> : std::bool_constant<E::kFlowHead> {};
 template <class E, class = void> struct epi_vec4 : std::false_type {};
 template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bool_constant<E::kVec4> {};
 
@@ -333,6 +335,78 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
       const int oy = ty0 + p / TW, ox = tx0 + p % TW;
       return (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
     };
+    if constexpr (epi_flowhead<Epi>::value) {
+      // ---- flow head: relu(conv1) x conv2's weights, reduced to 18 partial sums per pixel (epilogues_sf.h).
+      // Per (row tile, q) a lane holds 4 channels of one pixel: 9 packed FMAs x 4 give its share of the 9 taps x 2 outputs,
+      // three DPP adds per value (half-row mirror, quad swaps: no LDS, no selects — the first version's ds_bpermute
+      // reduce-scatter cost 21 us per launch) sum the pixel's 8 lanes, the lane at channel 0 writes the 18 sums into
+      // the wave's own (already consumed) transpose slab, and after a barrier the block adds the 8 waves in fixed order.
+      static_assert(!epi_flowhead<Epi>::value || (WM == 1 && TN == 1 && TW == 16), "one block holds all output channels of its pixels");
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      constexpr int RP = 20;                                    // floats per pixel row of the exchange (16-byte aligned rows)
+      static_assert(32 * RP <= 32 * LDS_LD, "the exchange rows live inside the wave's slab");
+      const int cl = n0 + wn * 32 + tcol;                       // this lane's 4 channels
+      const float4 bj = ep.bias4(min(cl, g.N - 4));
+      v2f w2r[9][4];                                            // [tap][channel] x (output 0, output 1)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float4 o0 = *reinterpret_cast<const float4*>(ep.w2 + (long)(2 * t) * g.N + min(cl, g.N - 4));
+        const float4 o1 = *reinterpret_cast<const float4*>(ep.w2 + (long)(2 * t + 1) * g.N + min(cl, g.N - 4));
+        w2r[t][0] = v2f{o0.x, o1.x}; w2r[t][1] = v2f{o0.y, o1.y}; w2r[t][2] = v2f{o0.z, o1.z}; w2r[t][3] = v2f{o0.w, o1.w};
+      }
+      auto dpp_sum8 = [](float v) __attribute__((always_inline)) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror: l <-> 7 - l
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        return v;
+      };
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {   // (unrolled: a run-time index into the accumulators would put them in scratch)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          *reinterpret_cast<float4*>(tb + r * LDS_LD + 8 * k + 4 * h) =
+              make_float4(acc[i][0][4 * k] * g.wscale, acc[i][0][4 * k + 1] * g.wscale, acc[i][0][4 * k + 2] * g.wscale,
+                          acc[i][0][4 * k + 3] * g.wscale);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(tb + (8 * q + trow) * LDS_LD + tcol);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();   // the slab is consumed: its rows now carry the partial sums
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v2f x0 = v2f{fmaxf(v[q].x + bj.x, 0.f), fmaxf(v[q].x + bj.x, 0.f)}, x1 = v2f{fmaxf(v[q].y + bj.y, 0.f), fmaxf(v[q].y + bj.y, 0.f)};
+          const v2f x2 = v2f{fmaxf(v[q].z + bj.z, 0.f), fmaxf(v[q].z + bj.z, 0.f)}, x3 = v2f{fmaxf(v[q].w + bj.w, 0.f), fmaxf(v[q].w + bj.w, 0.f)};
+          float a18[20];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const v2f a = ((x0 * w2r[t][0] + x1 * w2r[t][1]) + x2 * w2r[t][2]) + x3 * w2r[t][3];
+            a18[2 * t] = dpp_sum8(a.x);
+            a18[2 * t + 1] = dpp_sum8(a.y);
+          }
+          a18[18] = 0.f; a18[19] = 0.f;
+          if ((lane & 7) == 0) {
+            float* rp = tb + (8 * q + trow) * RP;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) *reinterpret_cast<float4*>(rp + 4 * k) = make_float4(a18[4 * k], a18[4 * k + 1], a18[4 * k + 2], a18[4 * k + 3]);
+          }
+        }
+        __syncthreads();   // every wave's partial sums of row tile i are in LDS
+        for (int idx = tid; idx < 32 * 18; idx += NT) {
+          const int px = idx / 18, u = idx - px * 18;
+          const float* rq = reinterpret_cast<const float*>(Pbytes) + px * RP + u;
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) sum += rq[w * (32 * LDS_LD)];   // fixed order: deterministic
+          const int p = i * 32 + px;
+          const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+          if (oy < g.Ho && ox < g.Wo) ep.G[((long)img * ep.npix + (long)oy * g.Wo + ox) * 18 + u] = sum;
+        }
+        __syncthreads();   // the slabs are rewritten by the next row tile
+      }
+      return;
+    }
     // Epilogues with operand loads (GRU gates, residual adds) are software-pipelined over the wave's tiles: the
     // operands of tile t + 1 are requested BEFORE the stores of tile t are issued. vmcnt retires in order, so a load
     // issued after a store can only be waited for together with that store; this way the wait before tile t + 1's
@@ -508,6 +582,22 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
   ATDN_HIP(hipGetLastError());
 }
 
+
+// block width the 3x3 dispatch below picks for a layer (the flow-head fusion needs one block to hold all channels)
+inline int conv_sf6_block_width_3x3(const ConvShape& s) {
+  const int Ho = conv_out(s.H, s.KH, 1, s.padH), Wo = conv_out(s.W, s.KW, 1, s.padW);
+  const long tiles = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
+  int bn = 64;
+  if (s.N <= 32) bn = 32;
+  else if (s.N == 96) bn = 96;
+  else {
+    int best = cdiv(s.N, 64) * 64;
+    for (int c : {128, 256})
+      if (cdiv(s.N, c) * c <= best) { best = cdiv(s.N, c) * c; bn = c; }
+  }
+  while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
+  return bn;
+}
 
 // Picks the block shape for N output channels and launches the fragment-major-weight kernel: 8x16-pixel tiles, or
 // 12x16 for the 64- and 96-wide blocks (3 MFMA row tiles per wave: less halo, fewer tile seams; measured

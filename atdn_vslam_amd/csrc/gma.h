@@ -95,6 +95,10 @@ class GmaNet {
   EncoderWeights fnet_, cnet_;
   PackedConv convc1_, convc2_, convf1_, convf2_, convm_, to_v_, to_qk_;
   long convf1_vw_off_ = -1;  // convf1 weights as [tap*2 + c][128] for small_convs.hip
+  long fh2_w32_off_ = -1;    // flow head conv2 weights as fp32 [tap*2 + output][256] for the fused flow head
+  DeviceBuf fhG_;            // conv2 partial sums [maxB * N][18]
+  // ATDN_FLOWHEAD_FUSED=0: conv1 -> sf tensor -> separate conv2 kernel (the path the fusion replaced)
+  bool flowhead_fused_ = true;
   PackedConv gru_zr_[2], gru_q_[2], fh1_, fh2_, mask0_, mask2_;
   PackedConv gru_zr_ctx_[2], gru_q_ctx_[2];  // sf mode: context-channel (inp) slices, applied once per pair
   const float* gamma_ = nullptr;

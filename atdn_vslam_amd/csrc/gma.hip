@@ -138,6 +138,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
   pool_features_ = precision >= 1 && !(getenv("ATDN_POOL_FEATURES") && getenv("ATDN_POOL_FEATURES")[0] == '0');
+  flowhead_fused_ = !(getenv("ATDN_FLOWHEAD_FUSED") && getenv("ATDN_FLOWHEAD_FUSED")[0] == '0');
   stem_legacy_ = getenv("ATDN_STEM_LEGACY") && getenv("ATDN_STEM_LEGACY")[0] == '1';
   norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
   lookup_legacy_ = precision == 0 || (getenv("ATDN_LOOKUP_LEGACY") && getenv("ATDN_LOOKUP_LEGACY")[0] == '1');
@@ -156,7 +157,7 @@ GmaNet::~GmaNet() {
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
                       &pre_zr_[1], &pre_q_[0], &pre_q_[1], &fpool_, &rowmax_, &rinv_,
-                      &fbrick_[0], &fbrick_[1], &fbrick_[2], &fbrick_[3], &fplain_[0], &fplain_[1], &fplain_[2], &coords_used_};
+                      &fbrick_[0], &fbrick_[1], &fbrick_[2], &fbrick_[3], &fplain_[0], &fplain_[1], &fplain_[2], &coords_used_, &fhG_};
   for (auto* b : all) b->release();
   arena_.release();
 }
@@ -204,6 +205,14 @@ void GmaNet::finalize() {
   }
   fh1_ = tap({u + "flow_head.conv1"});
   fh2_ = tap({u + "flow_head.conv2"});
+  if (sf) {   // conv2 once more, as fp32 rows [tap * 2 + output][256] (the fused flow head multiplies in fp32)
+    const HostTensor& w = sd_.get(u + "flow_head.conv2.weight");
+    ATDN_CHECK(w.shape.size() == 4 && w.shape[0] == 2 && w.shape[1] == 256 && w.shape[2] == 3 && w.shape[3] == 3, "flow head conv2 shape");
+    fh2_w32_off_ = arena_.alloc(18 * 256);
+    for (int o = 0; o < 2; ++o)
+      for (int c = 0; c < 256; ++c)
+        for (int t = 0; t < 9; ++t) arena_.at(fh2_w32_off_)[(t * 2 + o) * 256 + c] = w.data[((long)o * 256 + c) * 9 + t];
+  }
   mask0_ = tap({u + "mask.0"});
   mask2_ = tap({u + "mask.2"});
   gamma_off_ = pack_vector(arena_, sd_.get(u + "aggregator.gamma").data);
@@ -246,6 +255,7 @@ void GmaNet::finalize() {
   if (!attn_legacy_) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
   z_.alloc(n8 * 128); rh_.alloc(n8 * 128); fh_.alloc(n8 * 256); mask_.alloc(n8 * 576);
+  if (sf) fhG_.alloc(n8 * 18);
   coords1_.alloc(n8 * 2); flow4_.alloc(n8 * 4);
   if (sf) for (int p = 0; p < 2; ++p) { pre_zr_[p].alloc(n8 * 256); pre_q_[p].alloc(n8 * 128); }
   // pad lanes that kernels read but never write must be finite zeros
@@ -592,9 +602,15 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   }
 
   s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
-  conv_sf_dispatch(s, fh1_.wscale, SfBias<ACT_RELU>{fh1_.b, fh_.p, (long)N * 256, 256}, st);
   const SfFlowDelta fd{fh2_.b, coords1_.p, flow4_.p, x_.p, XLD, (long)N * XLD, 254, W8, (long)N};
-  launch_flow_head2(fh_.p, B, H8, W8, fh2_.w, fh2_.ldw, fh2_.wscale, fd, st);
+  if (flowhead_fused_ && flow_head_fusable(s)) {
+    // conv1 with conv2's partial sums in its epilogue, then the 3 x 3 gather (small_convs.h)
+    launch_flow_head_fused(s, fh1_.wscale, SfFlowHeadPartial{fh1_.b, arena_.dev(fh2_w32_off_), fhG_.p, (long)N}, st);
+    launch_flow_gather(fhG_.p, B, H8, W8, fd, st);
+  } else {
+    conv_sf_dispatch(s, fh1_.wscale, SfBias<ACT_RELU>{fh1_.b, fh_.p, (long)N * 256, 256}, st);
+    launch_flow_head2(fh_.p, B, H8, W8, fh2_.w, fh2_.ldw, fh2_.wscale, fd, st);
+  }
   mark(ST_FLOWHEAD, st);
 }
 

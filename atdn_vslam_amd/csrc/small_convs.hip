@@ -185,4 +185,34 @@ void launch_flow_head2(const float* fh_sf, int nimg, int H, int W, const float* 
   ATDN_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------- conv2 gather
+// out[p][o] = sum over taps t = (ty, tx) of G[p + (ty - 1, tx - 1)][t * 2 + o]   (conv2 3x3, pad 1: pixels outside
+// the map contribute nothing), then the flow update. One thread per pixel; G (4 MB at 8 pairs) is L2-resident.
+__global__ __launch_bounds__(256) void flow_gather_kernel(const float* __restrict__ G, int H, int W, long total,
+                                                          const SfFlowDelta ep) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long HW = (long)H * W;
+  const int img = (int)(i / HW), m = (int)(i - img * HW);
+  const int y = m / W, x = m - y * W;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int sy = y + t / 3 - 1, sx = x + t % 3 - 1;
+    if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+      const float2 g = *reinterpret_cast<const float2*>(G + ((long)img * HW + (long)sy * W + sx) * 18 + 2 * t);
+      s0 += g.x; s1 += g.y;
+    }
+  }
+  const SfFlowDelta::Aux a0 = ep.load(img, m, 0), a1 = ep.load(img, m, 1);
+  ep.apply(img, m, 0, s0, a0);
+  ep.apply(img, m, 1, s1, a1);
+}
+
+void launch_flow_gather(const float* G, int nimg, int H, int W, const SfFlowDelta& ep, hipStream_t st) {
+  const long total = (long)nimg * H * W;
+  hipLaunchKernelGGL(flow_gather_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, G, H, W, total, ep);
+  ATDN_HIP(hipGetLastError());
+}
+
 }  // namespace atdn

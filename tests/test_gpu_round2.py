@@ -266,6 +266,35 @@ def test_split_f16_stem_agrees_with_the_exact_fp32_stem(gsd, monkeypatch):
         assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4, (h, w)
 
 
+def test_fused_flow_head_agrees_with_the_two_convolutions(gsd, monkeypatch):
+    """Flow head with conv2 folded into conv1's epilogue (18 partial sums per pixel + a 3 x 3 gather; used when one
+    256-wide block holds all of conv1's channels, i.e. at B = 8 KITTI) against conv1 -> sf tensor -> conv2 kernel
+    (ATDN_FLOWHEAD_FUSED=0): coordinates after 1 and after 4 iterations, the flow channels of the GRU input and the
+    upsampled flow. Batch 8 at KITTI size selects the fused path; a ragged size with B = 8 checks partial tiles (the
+    map's border pixels get fewer than nine taps)."""
+    sd = {"module." + k: v for k, v in gsd.items()}
+
+    def run(h, w, iters):
+        m = RAFTGMA(max_batch=8, precision="split_f16")
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        fr = torch.from_numpy(syn.make_frames(9, h, w, seed=43)).to(DEV)
+        low, up = m.forward_sequence(fr, iters=iters)
+        n = (h // 8) * (w // 8)
+        c1 = m.debug_read("coords1", (8 * n, 2), h, w)
+        xf = m.debug_read("x", (8 * n, 384), h, w)[:, 254:256]
+        return low.cpu(), up.cpu(), c1, xf
+
+    for (h, w, iters) in ((376, 1232, 1), (376, 1232, 4), (360, 1000, 2)):
+        new = run(h, w, iters)
+        monkeypatch.setenv("ATDN_FLOWHEAD_FUSED", "0")
+        old = run(h, w, iters)
+        monkeypatch.delenv("ATDN_FLOWHEAD_FUSED")
+        assert float(old[0].abs().max()) > 1e-3
+        assert _maxerr(new[2], old[2]) < 1e-4 and _maxerr(new[3], old[3]) < 1e-4, (h, w, iters)
+        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4, (h, w, iters)
+
+
 def test_sequence_driver_from_host_uint8_matches_frame_by_frame(gsd, hsd):
     """The sequence driver on a 40-frame uint8 camera sequence in (pinned) host memory — ingest (H2D on the copy stream
     + convert + resize) clip by clip, continued clips, one ordered scan — against the reference's call pattern frame by
