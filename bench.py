@@ -35,6 +35,10 @@ H_KITTI, W_KITTI = 376, 1241
 H, W = 376, 1232
 N8 = (H // 8) * (W // 8)
 ITERS = 12
+# Frame pairs per step (clip length) per GPU. Measured on one box: 8 pairs 348.3 pairs/s, 12: 354.5, 16: 356.5 (a second
+# box: 16: 354.9, 24: 358.0, 32: 359.3) — longer clips fill the tails of every launch a little better and encode the
+# shared frame of consecutive clips less often. 16 takes most of that at half the step latency of 32.
+DEFAULT_BATCH = 16
 # Algorithmic work per frame pair (SURVEY §8d / BASELINE.md §3): mask head + upsampling counted once.
 FLOP_PER_PAIR = 0.951e12
 # ... of which the path no longer EXECUTES 70.6 GMAC per pair: one feature-network pass per pair (shared frames, 31.5 GMAC)
@@ -149,7 +153,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frame pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="frame pairs per step per GPU")
     ap.add_argument("--streams", type=int, default=2, help="independent clips in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed pass that ingests host frames")

@@ -26,6 +26,7 @@ def test_two_rank_bench_rehearsal_prints_one_valid_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["value"] > 0 and d["unit"] == "frame-pairs/s" and "REHEARSAL" in d["data"]
-    assert "x2" in d["config"]["parallelism"] and d["config"]["pairs_per_step_per_gpu"] == 8
-    # whole-job aggregate: 2 ranks x 2 steps x 8 pairs over the max-over-ranks time
-    assert abs(d["value"] - 2 * 2 * 8 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"] + 1e-3
+    B = d["config"]["pairs_per_step_per_gpu"]
+    assert "x2" in d["config"]["parallelism"] and B >= 8
+    # whole-job aggregate: 2 ranks x 2 steps x B pairs over the max-over-ranks time
+    assert abs(d["value"] - 2 * 2 * B / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"] + 1e-3

@@ -37,13 +37,14 @@ def _u8_sequence(n, seed):
 
 def test_bench_step_pattern_matches_pair_mode_and_oracle(gsd, hsd):
     """The launch pattern bench.py times: two OdometryPipelines on two HIP streams, each walking its own sequence in
-    clips of B = 8 pairs, continued clips reusing the shared frame's features, uint8 host frames ingested (H2D + resize)
+    clips of B = bench.DEFAULT_BATCH pairs, continued clips reusing the shared frame's features, uint8 host frames ingested (H2D + resize)
     inside the loop. Every clip's flow and features must equal pair mode on a fresh handle (up to kernel-selection
     rounding: the feature network sees 8 instead of 16 images), and two pairs — the first pair of a continued clip, whose
     image1 features are the reused ones, and the last pair of the last clip — must match the CPU oracle."""
     from oracle import clvo_ref, gma_ref
     from atdn_vslam_amd.pipeline import FrameIngest, OdometryPipeline, resize_frames
-    B, S, CLIPS = 8, 2, 3
+    import bench
+    B, S, CLIPS = bench.DEFAULT_BATCH, 2, 2
     pipes = [OdometryPipeline(gsd, hsd, device=DEV, max_batch=B, iters=12) for _ in range(S)]
     ingests = [FrameIngest((376, 1241), max_frames=B + 1, device=DEV) for _ in range(S)]
     streams = [torch.cuda.Stream(device=DEV) for _ in range(S)]

@@ -4,7 +4,7 @@ requests at 64 B for 16-B-per-lane loads, so the read side is doubled (guide §H
 
     python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_prefix> [batch]
 
-`batch` (pairs per launch of the profiled run, default 8 = bench.py's default) is recorded as `_batch`: bench.py only
+`batch` (pairs per launch of the profiled run, default bench.DEFAULT_BATCH) is recorded as `_batch`: bench.py only
 quotes a traffic figure measured at the batch it runs.
 """
 import collections
@@ -20,7 +20,15 @@ def load(path):
     return d
 
 
-def main(fetch_csv, write_csv, prefix, batch=8):
+def _default_batch():
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.DEFAULT_BATCH
+
+
+def main(fetch_csv, write_csv, prefix, batch=None):
+    batch = _default_batch() if batch is None else batch
     f, w = load(fetch_csv), load(write_csv)
     out = {}
     for k in sorted(set(f) | set(w)):
