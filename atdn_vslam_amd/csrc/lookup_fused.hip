@@ -108,7 +108,9 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
   bool bok[DEPTH][2];
   auto issue = [&](int pi, int slot) __attribute__((always_inline)) {
     const int pp = min(pbase + pi, np - 1);
-    const float cx = __shfl(cmine.x, pp), cy = __shfl(cmine.y, pp);
+    // (pp is wave-uniform: v_readlane, not a ds_bpermute whose wait would also sit behind the sampling phase's LDS traffic)
+    const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cmine.x), pp));
+    const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cmine.y), pp));
     un[slot] = unit_origin(cx, cy, inv);
     fetch_bricks(lvl_base + (p0 + pp) * NBl, BWl, BHl, un[slot], lane, bv[slot], bok[slot]);
   };
