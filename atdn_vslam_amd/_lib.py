@@ -22,6 +22,7 @@ SIGNATURES = {
     "atdn_gma_forward_sequence_continued": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "atdn_gma_debug_read": (C.c_long, [_vp, C.c_char_p, _vp, C.c_long, _vp]),
     "atdn_gma_profile": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f32p, _vp]),
+    "atdn_gma_profile_mode": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _vp]),
     "atdn_gma_workspace_bytes": (C.c_size_t, [_vp]),
     "atdn_gma_destroy": (None, [_vp]),
     "atdn_clvo_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),

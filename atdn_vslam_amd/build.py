@@ -1,6 +1,10 @@
 """Builds libatdn_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m atdn_vslam_amd.build [--force]
+    python -m atdn_vslam_amd.build [--force] [--microbench]
+
+--microbench also builds the diagnostic micro-benchmark library (tools/microbench/, ablation builds of the kernels): it is
+not part of the product and a break in it must not fail the product build, so it is only built on request
+(tools/microbench_*.py ask for it themselves).
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container;
 the resulting .so travels to the GPU box with the repository snapshot.
@@ -49,7 +53,7 @@ def _compile(src):
     return obj, True
 
 
-def build(force=False, jobs=None):
+def build(force=False, jobs=None, microbench=False):
     """Compile every HIP translation unit for gfx950 and link the shared library. Returns its path."""
     os.makedirs(OBJ, exist_ok=True)
     if force:
@@ -64,21 +68,24 @@ def build(force=False, jobs=None):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stdout)
-    _build_microbench()
+    if microbench:
+        build_microbench()
     return LIB
 
 
-def _build_microbench():
-    if not os.path.exists(MB_SRC):
-        return
+def build_microbench():
+    """The diagnostic library libatdn_microbench.so (links against libatdn_hip.so); returns its path."""
+    if not os.path.exists(LIB):
+        build()
     newest = max([_mtime(MB_SRC), _mtime(LIB)] + [_mtime(h) for h in _headers()])
     if _mtime(MB_LIB) >= newest:
-        return
+        return MB_LIB
     cmd = [HIPCC] + FLAGS + ["-shared", MB_SRC, "-o", MB_LIB, "-L" + HERE, "-latdn_hip", "-Wl,-rpath,$ORIGIN"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on the micro-benchmark library:\n%s" % r.stdout)
+    return MB_LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, microbench="--microbench" in sys.argv))

@@ -16,26 +16,23 @@ namespace atdn {
 // Values are e = exp(s - rowmax~) * 2^AT_SHIFT, NOT normalised: rinv[pair][row] = 1 / sum_k e is applied by the
 // consumer. rowmax~ comes from a cheap first pass (f16 x f16 logits); softmax is shift-invariant, so any shift close to
 // the true maximum gives the same probabilities and keeps e inside the f16 range (largest element of a row ~ 2^10).
-// Two element formats:
-//   AT_FMT_SF4  4 bytes: hi = f16(e), lo = f16(e - hi)                       block = [t][hi | lo][lane][16 B] = 4096 B
-//   AT_FMT_H3   3 bytes: hi = f16(e), residual as ONE BYTE in units of the group's ulp / 256 (group = a lane's eight
-//               values of one k-step): e = hi + (byte - 128) * 2^(E - 33), E = f16 exponent of the group's largest hi.
-//               block = [t][lane][16 B] hi, then [t][lane][8 B] residual bytes = 3072 B.
+// Element format H3, 3 bytes: hi = f16(e), residual as ONE BYTE in units of the group's ulp / 256 (group = a lane's eight
+//   values of one k-step): e = hi + (byte - 128) * 2^(E - 33), E = f16 exponent of the group's largest hi.
+//   block = [t][lane][16 B] hi, then [t][lane][8 B] residual bytes = 3072 B.
 //   H3 carries 19 significant bits of every value within 2^-8 of its group's maximum and an ABSOLUTE error below
-//   2^-20 of the group maximum everywhere — what matters for sum_k e_k v_k with fp32 accumulation (the sf residual of
-//   these values is an f16 subnormal for everything below 2^-4 of the row maximum, i.e. no better) — and moves 25 % fewer
-//   bytes through the kernel that is bound by exactly this stream. H3 is the default; ATDN_ATTN_FMT=sf4 selects SF4.
-constexpr int AT_FMT_SF4 = 0, AT_FMT_H3 = 1;
+//   2^-20 of the group maximum everywhere — what matters for sum_k e_k v_k with fp32 accumulation (the residual of a
+//   4-byte hi | lo pair is an f16 subnormal for everything below 2^-4 of the row maximum, i.e. no better) — and moves 25 %
+//   fewer bytes through the kernel that streams the matrix twelve times. (The 4-byte format was removed in round 3.)
+//   A value past the f16 range is clamped to 65504 and counted by the sf saturation counter (sf.h).
 constexpr int AT_SHIFT = 10;
-constexpr int attn_blk_bytes(int fmt) { return fmt == AT_FMT_H3 ? 3072 : 4096; }
+constexpr int AT_BLK_BYTES = 3072;
 struct AttnGeom {
   int B, N, ldN, RT, Q, Npad;   // Npad = 32 * RT: row count of rowmax / rinv per pair
-  int fmt;
 };
-inline AttnGeom attn_geom(int B, int N, int ldN, int fmt) {
-  return {B, N, ldN, (N + 31) / 32, ldN / 32, ((N + 31) / 32) * 32, fmt};
+inline AttnGeom attn_geom(int B, int N, int ldN) {
+  return {B, N, ldN, (N + 31) / 32, ldN / 32, ((N + 31) / 32) * 32};
 }
-inline long attn_floats(const AttnGeom& g) { return (long)g.B * g.RT * g.Q * (attn_blk_bytes(g.fmt) / 4); }
+inline long attn_floats(const AttnGeom& g) { return (long)g.B * g.RT * g.Q * (AT_BLK_BYTES / 4); }
 
 // qk: sf [B][N][256] = q (pre-scaled, channels 0..127) | k (channels 128..255)            (gma.py:57-60)
 // pass 1: rowmax[b][m] ~ max_n q_m . k_n  (f16 x f16 products)

@@ -7,16 +7,11 @@
 //       rowmax~); STATS = false recomputes the logits at full split-f16 precision, writes e = exp(s - rowmax~) in
 //       fragment-major order (1 KiB per wave store, non-temporal) and the row sums. The fp32 logits (1.68 GB at 8 pairs)
 //       never exist in memory; the separate softmax pass (read 1.68 GB, write 1.68 GB) is gone.
-//   attn_v_kernel              attention x V (gma.py:102-115). Every wave streams ITS strip of the attention matrix
-//       — one contiguous 0.7-0.9 MB run — straight into MFMA operand registers, three chunks ahead, 1 KiB per wave
-//       load; only V^T (L2-resident, shared by the block) goes through LDS, one barrier per chunk. The round-1 kernel
-//       staged both operands through LDS behind two barriers per 32-wide chunk.
-//       What bounds it (timing ladder of diagnostic builds, H3 operands, 8 pairs, MI355X, recorded in DESIGN.md): full
-//       kernel 362 us; attention loads + LDS reads without MFMAs and barriers 212 us = 5.9 TB/s (the stream itself is
-//       NOT the bound); MFMAs + LDS fragment reads without the stream 339 us: the 3-MFMA split makes this a matrix-pipe
-//       kernel (322 GFLOP executed per launch, 0.89 PF with the stream beside it). Two hand-scheduled variants were
-//       measured and dropped: all sixteen V^T fragments of a chunk requested up front (+2 %), and fragments read one
-//       MFMA group ahead across the chunk boundary with a ring of three LDS images (+5 %).
+//   attn_v3_kernel             attention x V (gma.py:102-115) as a two-set ping-pong, described at the kernel. Every wave
+//       streams ITS strip of the attention matrix — one contiguous 0.5-0.7 MB run — straight into MFMA operand registers,
+//       1 KiB per wave load; only V^T (L2-resident, shared by the block) goes through LDS. (The 4-wave kernel it replaced
+//       — every wave interleaving its own memory work with its own MFMAs — and the 4-byte SF4 element format were
+//       deleted in round 3 after their A/B tests; measurements in DESIGN.md 3.6.)
 #include "attention.h"
 
 #include "conv_mfma.h"
@@ -44,12 +39,15 @@ __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __bu
 // largest hi of the group of eight
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void h3_encode(const float* v, f16x8& hi, u32x2& bytes) {
+// (values past the f16 range — a full-precision logit more than ~4.16 above the first pass's f16 x f16 row maximum — are
+// clamped to 65504 and flagged: the caller reports them through the sf saturation counter, sf_report)
+__device__ __forceinline__ void h3_encode(const float* v, f16x8& hi, u32x2& bytes, bool& clamped) {
   float hf[8];
   float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    hi[i] = (_Float16)v[i];
+    clamped |= !(v[i] <= 65504.f);
+    hi[i] = (_Float16)fminf(v[i], 65504.f);
     hf[i] = (float)hi[i];
     mx = fmaxf(mx, hf[i]);
   }
@@ -61,7 +59,7 @@ __device__ __forceinline__ void h3_encode(const float* v, f16x8& hi, u32x2& byte
   for (int i = 0; i < 8; ++i) {
     // |v - hi| <= ulp(hi) / 2 <= ulp(group) / 2: the quotient lies in [-128, 128]; +128 (a tie rounded down) is
     // stored as 127, one unit = 2^-9 ulp off
-    const float q = fminf(rintf((v[i] - hf[i]) * inv_unit), 127.f) + 128.f;
+    const float q = fminf(rintf((fminf(v[i], 65504.f) - hf[i]) * inv_unit), 127.f) + 128.f;
     if (i < 4) w0 = __builtin_amdgcn_cvt_pk_u8_f32(q, i, w0); else w1 = __builtin_amdgcn_cvt_pk_u8_f32(q, i - 4, w1);
   }
   bytes[0] = w0;
@@ -87,7 +85,7 @@ __device__ __forceinline__ f16x8 h3_decode_lo(f16x8 hi, u32x2 bytes) {
 }
 
 // ------------------------------------------------------------------------------------------------ Q K^T + softmax
-template <bool STATS, bool FAST, int FMT>
+template <bool STATS, bool FAST>
 __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restrict__ qk, const AttnGeom g,
                                                            const float* __restrict__ rowmax_in,
                                                            float* __restrict__ rowmax_out, float* __restrict__ P,
@@ -96,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   constexpr int CH = KT * ROWB;        // one 32-channel chunk of the tile
   constexpr int IMG = 4 * CH;          // [4 channel chunks][64 keys][144 B]
   constexpr bool FULL = !STATS && !FAST;   // all three products of the split
-  constexpr int BLK = attn_blk_bytes(FMT);
+  constexpr int BLK = AT_BLK_BYTES;
   __shared__ __attribute__((aligned(16))) char lds[2 * IMG];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 
   const int NHT = (g.Q + 1) >> 1;
   float run = STATS ? -INFINITY : 0.f;   // running row maximum / running row sum of this lane's columns
-  bool clamped = false;                  // (SF4 stores) saturation, reported once after the sweep
+  bool clamped = false;                  // saturation of the f16 store, reported once after the sweep
   float c0 = 0.f;
   if (!STATS) c0 = (float)AT_SHIFT - rowmax_in[(long)b * g.Npad + min(m, g.Npad - 1)] * LOG2E;
   char* pdst = reinterpret_cast<char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * g.Q) * BLK;
@@ -216,23 +214,11 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
           char* d = pdst + (long)q * BLK;
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            if (FMT == AT_FMT_H3) {
-              f16x8 hi;
-              u32x2 bytes;
-              h3_encode(v + 8 * t, hi, bytes);
-              st_frag_nt(d + t * 1024 + lane * 16, hi);
-              __builtin_nontemporal_store(bytes, reinterpret_cast<u32x2*>(d + 2048 + t * 512 + lane * 8));
-            } else {
-              f16x8 hi, lo;
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const SfPair p = sf_split_flag(v[8 * t + i], clamped);
-                hi[i] = p.hi;
-                lo[i] = p.lo;
-              }
-              st_frag_nt(d + (2 * t) * 1024 + lane * 16, hi);
-              st_frag_nt(d + (2 * t + 1) * 1024 + lane * 16, lo);
-            }
+            f16x8 hi;
+            u32x2 bytes;
+            h3_encode(v + 8 * t, hi, bytes, clamped);
+            st_frag_nt(d + t * 1024 + lane * 16, hi);
+            __builtin_nontemporal_store(bytes, reinterpret_cast<u32x2*>(d + 2048 + t * 512 + lane * 8));
           }
         }
       }
@@ -250,146 +236,9 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ attention x V
-template <bool FAST, int FMT>
-__global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
-                                                       const AttnGeom g, const float* __restrict__ vT,
-                                                       const float* __restrict__ gamma, const float* __restrict__ mf,
-                                                       float* __restrict__ out, const long sb, const int ld) {
-  constexpr int D = 4;                 // chunks of the attention stream in flight per wave (4 KiB each)
-  constexpr int IMG = 128 * ROWB;      // V^T chunk: [128 channels][144 B]
-  __shared__ __attribute__((aligned(16))) char lds[2 * IMG];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles = (g.RT + 3) >> 2;
-  const int id = xcd_remap(blockIdx.x, g.B * tiles);
-  const int b = id / tiles, tile = id - b * tiles;
-  const int strip = tile * 4 + wave;
-  const bool strip_ok = strip < g.RT;
-  const int r = lane & 31, h = lane >> 5;
-  const int m = strip * 32 + r;
-  const int Q = g.Q;
-
-  // this wave's strip of the attention matrix: chunk q is the BLK bytes at pblk + q * BLK, in operand order
-  constexpr int BLK = attn_blk_bytes(FMT);
-  const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * BLK;
-  f16x8 ring[D][FMT == AT_FMT_H3 ? 2 : 4];   // SF4: [slot][2t + (hi | lo)]; H3: [slot][t] hi
-  u32x2 ringb[D][2];                          // H3: residual bytes of k-step t
-  auto loadP = [&](int q, int slot) __attribute__((always_inline)) {
-    const char* p = pblk + (long)q * BLK;
-    if (FMT == AT_FMT_H3) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ring[slot][t] = ld_frag_nt(p + t * 1024 + lane * 16);
-        ringb[slot][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ring[slot][u] = ld_frag_nt(p + u * 1024 + lane * 16);
-    }
-  };
-
-  // V^T chunk loader: thread -> channel rows lr + 32 i, 16-byte slot ls of the row's 128-byte [32 hi | 32 lo] chunk.
-  // The eight halves of a slot are columns 8s'..8s'+7 (s' = ls & 3); the attention fragments hold their columns with
-  // bits 2 and 3 of the in-chunk index swapped (accumulator order of the producer), so the two 8-byte halves of the
-  // slot go to the swapped positions of the LDS image.
-  const int lr = tid >> 3, ls = tid & 7;
-  const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
-  // two register sets: a V^T chunk is requested D - 1 iterations before it is multiplied, like the attention chunks.
-  // vmcnt retires in order, so a wait for an L2-hit V^T load also waits for every OLDER attention load: with the V^T
-  // loads issued later than the attention loads of the same distance the HBM look-ahead shrank to one iteration.
-  v4f breg[2][4];
-  auto fetchB = [&](int q, int set) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) breg[set][i] = *reinterpret_cast<const v4f*>(vrow + (long)(32 * i) * g.ldN + q * 32);
-  };
-  const int sp = ls & 3;
-  const int boff = lr * ROWB + 64 * (ls >> 2) + 32 * (sp >> 1) + 8 * (sp & 1);
-  auto stashB = [&](int buf, int set) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      char* d = lds + buf * IMG + boff + 32 * i * ROWB;
-      *reinterpret_cast<float2*>(d) = make_float2(breg[set][i].x, breg[set][i].y);
-      *reinterpret_cast<float2*>(d + 16) = make_float2(breg[set][i].z, breg[set][i].w);
-    }
-  };
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-
-  static_assert(D == 4, "the V^T register sets alternate with the parity of the chunk: D must be even");
-  // prologue: chunk 0 of V^T goes to LDS image 0 directly; chunks 1 and 2 wait in the two register sets
-  fetchB(0, 0);
-  loadP(0, 0);
-  fetchB(min(1, Q - 1), 1);
-  loadP(min(1, Q - 1), 1);
-  stashB(0, 0);
-  fetchB(min(2, Q - 1), 0);
-  loadP(min(2, Q - 1), 2);
-  __syncthreads();
-  // branch-free ring: the trip count is rounded up to a multiple of D, look-ahead loads past the end are clamped and a
-  // surplus chunk skips its MFMAs (uniform branch), so every slot index is a compile-time constant
-  const int nq = (Q + D - 1) / D * D;
-  for (int q0 = 0; q0 < nq; q0 += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int q = q0 + d;
-      // V^T chunk q + 1 (requested two iterations ago) goes into the LDS image last read in iteration q - 1 (every wave
-      // has passed the barrier since); its register set takes chunk q + 3; then the attention chunk q + 3
-      stashB((q + 1) & 1, (d + 1) & 1);
-      fetchB(min(q + 3, Q - 1), (d + 1) & 1);
-      loadP(min(q + D - 1, Q - 1), (d + D - 1) % D);
-      if (q < Q) {
-        const char* img = lds + (q & 1) * IMG + r * ROWB + 16 * h;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          f16x8 ph, pl;
-          if (FMT == AT_FMT_H3) {
-            ph = ring[d][t];
-            if (!FAST) pl = h3_decode_lo(ph, ringb[d][t]);
-          } else {
-            ph = ring[d][2 * t];
-            pl = ring[d][2 * t + 1];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const char* vp = img + 32 * j * ROWB + 32 * t;
-            const f16x8 vh = ld_frag(vp);
-            if (!FAST) {
-              const f16x8 vl = ld_frag(vp + 64);
-              acc[j] = mfma(vl, ph, acc[j]);
-              acc[j] = mfma(vh, pl, acc[j]);
-            }
-            acc[j] = mfma(vh, ph, acc[j]);
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-
-  if (strip_ok && m < g.N) {
-    const float rv = rinv[(long)b * g.Npad + m] * gamma[0];
-    const float* mfb = mf + (long)b * sb;
-    float* ob = out + (long)b * sb;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int c = 32 * j + 8 * jj + 4 * h;
-        const float4 x = sf_load4(mfb, (long)m * ld, c);
-        const float4 o = make_float4(x.x + rv * acc[j][4 * jj], x.y + rv * acc[j][4 * jj + 1], x.z + rv * acc[j][4 * jj + 2],
-                                     x.w + rv * acc[j][4 * jj + 3]);
-        sf_store4(ob, (long)m * ld, c, o);
-      }
-  }
-}
-
-// ---- attention x V as a two-set ping-pong (MI355X_MICROARCH.md, "Two waves per SIMD"). The timing ladder of
-// attn_v_kernel says its MFMA + LDS-read loop alone takes 339 of 362 us: every wave interleaves its own fragment reads,
-// decode VALU and loads with its own MFMAs, and both waves of a SIMD do the same thing at the same time. Here a block
+// ---- attention x V as a two-set ping-pong (MI355X_MICROARCH.md, "Two waves per SIMD"). The timing ladder of the 4-wave
+// kernel this replaced said its MFMA + LDS-read loop alone took 339 of 362 us: every wave interleaved its own fragment
+// reads, decode VALU and loads with its own MFMAs, and both waves of a SIMD did the same thing at the same time. Here a block
 // is EIGHT waves (one strip each): waves 0-3 (set A) and 4-7 (set B) share the four SIMDs pairwise and alternate roles
 // every phase, separated by a barrier:
 //     phase 2q    : A multiplies chunk q (24 MFMAs back to back, every operand already in registers)
@@ -401,14 +250,13 @@ __global__ __launch_bounds__(256, 2) void attn_v_kernel(const float* __restrict_
 // so the matrix pipe of a SIMD always has one wave issuing MFMAs and nothing else, while its partner's LDS / VALU / VMEM
 // work runs beside it. Measured (H3, 8 pairs, same box): 4-wave kernel 372 us, ping-pong 315 us; without the attention
 // stream (zero operands) the MFMA + LDS loop alone takes 257 us here against 339 us in the 4-wave kernel.
-template <bool FAST, int FMT>
+template <bool FAST>
 __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
                                                         const AttnGeom g, const float* __restrict__ vT,
                                                         const float* __restrict__ gamma, const float* __restrict__ mf,
                                                         float* __restrict__ out, const long sb, const int ld) {
   constexpr int IMG = 128 * ROWB;      // V^T chunk: [128 channels][144 B]
-  constexpr int BLK = attn_blk_bytes(FMT);
-  constexpr bool H3 = FMT == AT_FMT_H3;
+  constexpr int BLK = AT_BLK_BYTES;
   constexpr int D = 3;                 // attention chunks resident per wave (ring of register sets; 4 measured 2 % slower)
   __shared__ __attribute__((aligned(16))) char lds[3 * IMG];
 
@@ -424,19 +272,14 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   const int Q = g.Q;
 
   const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * BLK;
-  f16x8 ring[D][H3 ? 2 : 4];
+  f16x8 ring[D][2];
   u32x2 ringb[D][2];
   auto loadP = [&](int q, int slot) __attribute__((always_inline)) {
     const char* p = pblk + (long)min(q, Q - 1) * BLK;
-    if (H3) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ring[slot][t] = ld_frag_nt(p + t * 1024 + lane * 16);
-        ringb[slot][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ring[slot][u] = ld_frag_nt(p + u * 1024 + lane * 16);
+    for (int t = 0; t < 2; ++t) {
+      ring[slot][t] = ld_frag_nt(p + t * 1024 + lane * 16);
+      ringb[slot][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
     }
   };
 
@@ -481,13 +324,8 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   auto take_chunk = [&](int slot) __attribute__((always_inline)) {   // attention operands of a chunk out of the ring
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      if (H3) {
-        ph[t] = ring[slot][t];
-        if (!FAST) pl[t] = h3_decode_lo(ph[t], ringb[slot][t]);
-      } else {
-        ph[t] = ring[slot][2 * t];
-        pl[t] = ring[slot][2 * t + 1];
-      }
+      ph[t] = ring[slot][t];
+      if (!FAST) pl[t] = h3_decode_lo(ph[t], ringb[slot][t]);
     }
   };
   auto multiply = [&]() __attribute__((always_inline)) {
@@ -591,20 +429,13 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int m = strip * 32 + r;
   if (m >= g.N) return;
-  const int BLK = attn_blk_bytes(g.fmt);
-  const char* p = reinterpret_cast<const char*>(P) + blk * BLK;
+  const char* p = reinterpret_cast<const char*>(P) + blk * AT_BLK_BYTES;
   const float rv = rinv[(long)b * g.Npad + m];
   float* row = rows + ((long)b * g.N + m) * g.ldN + q * 32;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    f16x8 hi, lo;
-    if (g.fmt == AT_FMT_H3) {
-      hi = ld_frag(p + t * 1024 + lane * 16);
-      lo = h3_decode_lo(hi, *reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
-    } else {
-      hi = ld_frag(p + (2 * t) * 1024 + lane * 16);
-      lo = ld_frag(p + (2 * t + 1) * 1024 + lane * 16);
-    }
+    const f16x8 hi = ld_frag(p + t * 1024 + lane * 16);
+    const f16x8 lo = h3_decode_lo(hi, *reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
 #pragma unroll
     for (int i = 0; i < 8; ++i) row[16 * t + 8 * (i >> 2) + 4 * h + (i & 3)] = ((float)hi[i] + (float)lo[i]) * rv;
   }
@@ -614,7 +445,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict
 
 void launch_qk_rowmax(const float* qk, const AttnGeom& g, float* rowmax, hipStream_t st) {
   const int nblk = g.B * ((g.RT + 3) / 4);
-  hipLaunchKernelGGL((qk_softmax_kernel<true, false, AT_FMT_SF4>), dim3(nblk), dim3(256), 0, st, qk, g, nullptr, rowmax, nullptr, nullptr);
+  hipLaunchKernelGGL((qk_softmax_kernel<true, false>), dim3(nblk), dim3(256), 0, st, qk, g, nullptr, rowmax, nullptr, nullptr);
   ATDN_HIP(hipGetLastError());
 }
 
@@ -622,34 +453,17 @@ void launch_qk_softmax(const float* qk, const AttnGeom& g, const float* rowmax, 
                        hipStream_t st) {
   const int nblk = g.B * ((g.RT + 3) / 4);
   const dim3 gr(nblk), bl(256);
-  if (g.fmt == AT_FMT_H3) {
-    if (fast) hipLaunchKernelGGL((qk_softmax_kernel<false, true, AT_FMT_H3>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
-    else hipLaunchKernelGGL((qk_softmax_kernel<false, false, AT_FMT_H3>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
-  } else {
-    if (fast) hipLaunchKernelGGL((qk_softmax_kernel<false, true, AT_FMT_SF4>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
-    else hipLaunchKernelGGL((qk_softmax_kernel<false, false, AT_FMT_SF4>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
-  }
+  if (fast) hipLaunchKernelGGL((qk_softmax_kernel<false, true>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
+  else hipLaunchKernelGGL((qk_softmax_kernel<false, false>), gr, bl, 0, st, qk, g, rowmax, nullptr, P, rinv);
   ATDN_HIP(hipGetLastError());
 }
 
 void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const float* vT, const float* gamma,
                    const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st) {
   ATDN_CHECK(g.ldN % 32 == 0 && g.Q * 32 == g.ldN && ld % 32 == 0, "attention geometry");
-  // ATDN_ATTN_PINGPONG=0: the 4-wave kernel (every wave interleaves its own memory work with its own MFMAs)
-  static const bool pingpong = !(getenv("ATDN_ATTN_PINGPONG") && getenv("ATDN_ATTN_PINGPONG")[0] == '0');
-  if (pingpong) {
-    const dim3 gr(g.B * ((g.RT + 7) / 8)), bl(512);
-#define ATDN_AV(FASTV, FMTV) hipLaunchKernelGGL((attn_v3_kernel<FASTV, FMTV>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld)
-    if (g.fmt == AT_FMT_H3) { if (fast) ATDN_AV(true, AT_FMT_H3); else ATDN_AV(false, AT_FMT_H3); }
-    else { if (fast) ATDN_AV(true, AT_FMT_SF4); else ATDN_AV(false, AT_FMT_SF4); }
-#undef ATDN_AV
-  } else {
-    const dim3 gr(g.B * ((g.RT + 3) / 4)), bl(256);
-#define ATDN_AV(FASTV, FMTV) hipLaunchKernelGGL((attn_v_kernel<FASTV, FMTV>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld)
-    if (g.fmt == AT_FMT_H3) { if (fast) ATDN_AV(true, AT_FMT_H3); else ATDN_AV(false, AT_FMT_H3); }
-    else { if (fast) ATDN_AV(true, AT_FMT_SF4); else ATDN_AV(false, AT_FMT_SF4); }
-#undef ATDN_AV
-  }
+  const dim3 gr(g.B * ((g.RT + 7) / 8)), bl(512);
+  if (fast) hipLaunchKernelGGL((attn_v3_kernel<true>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld);
+  else hipLaunchKernelGGL((attn_v3_kernel<false>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld);
   ATDN_HIP(hipGetLastError());
 }
 

@@ -129,7 +129,14 @@ int atdn_gma_profile(atdn_gma* h, int B, int iters, int reps, float* ms_out, voi
   ATDN_API_BEGIN
   ATDN_CHECK(h && ms_out, "null argument");
   static_assert(GmaNet::ST_COUNT == ATDN_GMA_STAGES, "stage table out of sync with the header");
-  h->net.profile(B, iters, reps, ms_out, (hipStream_t)stream);
+  h->net.profile(B, iters, reps, ms_out, (hipStream_t)stream, 0);
+  ATDN_API_END
+}
+int atdn_gma_profile_mode(atdn_gma* h, int B, int iters, int reps, int mode, float* ms_out, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h && ms_out, "null argument");
+  ATDN_CHECK(mode >= 0 && mode <= 2, "mode must be 0 (pair), 1 (sequence) or 2 (continued sequence)");
+  h->net.profile(B, iters, reps, ms_out, (hipStream_t)stream, mode);
   ATDN_API_END
 }
 size_t atdn_gma_workspace_bytes(atdn_gma* h) { return h ? h->net.workspace_bytes() : 0; }

@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "weights.h"
 #include "gma.h"  // DeviceBuf
+#include <set>
 
 namespace atdn {
 
@@ -27,7 +28,6 @@ class ClvoNet {
                   long raw_w_off = -1, raw_b_off = -1; const float* raw_w = nullptr; const float* raw_b = nullptr; };
   struct Res { ConvBN a, b; PackedConv skip; long sc_off = -1, sh_off = -1; const float* sc = nullptr; const float* sh = nullptr;
                long skip_w_off = -1, skip_b_off = -1; const float* skip_w = nullptr; const float* skip_b = nullptr; };
-  bool conv16_ = true;   // ATDN_CLVO_CONV16=0: the 32x32x2 implicit-GEMM engine (earlier path, kept for comparison)
   ConvBN pack_convbn(const std::string& p);
 
   StateDict sd_;
@@ -40,16 +40,18 @@ class ClvoNet {
   Lin fc_, lstm1_ih_, lstm1_hh_, lstm_lin_, lstm2_ih_, lstm2_hh_, rot_[3], tr_[3];
   Lin pack_linear(const std::string& wkey, const std::string& bkey, const std::vector<int>* perm = nullptr);
 
-  DeviceBuf in4_, bufA_, bufB_, bufS_, flat_, gates_, x2_;
+  DeviceBuf in4_, bufA_, bufB_, bufS_, flat_;
   DeviceBuf pre_, hseq_, x2seq_;  // scan scratch, grown on demand: [T*Bs][2048], [(T+1)*Bs][512], [T*Bs][512]
   DeviceBuf hseq2_;               // [(T+1)*Bs][512]: the h2 sequence of the pipelined scan
-  bool pipe_ = true;              // ATDN_LSTM_PIPE=0: two scans of one launch per step each (earlier path)
   void ensure_scan(long rows, int Bs);
-  // the T + 2 dependent launches of the pipelined scan replay as ONE hipGraph per (T, Bs): the scan is bound by the rate
-  // of dependent launches (8.4 us per step issued eagerly, host-side), a graph replay leaves the ~1.3 us kernel boundary.
+  // the T + 2 dependent launches of the pipelined scan replay as ONE hipGraph per (T, Bs) once that shape has been seen
+  // before (first sight and T > kMaxGraphedSteps launch eagerly: clvo.hip, "Graph policy").
   // The graph only references library-owned buffers (the caller's state is copied in and out around it).
   DeviceBuf cstate_;              // [2][Bs][512]: c1, c2 of the scan in flight
   std::map<std::pair<int, int>, hipGraphExec_t> scan_graphs_;
+  std::set<std::pair<int, int>> scan_seen_;
+  static constexpr int kMaxGraphedSteps = 1024;
+  int dev_ = 0;                   // device the handle lives on (destructor)
   hipStream_t cap_stream_ = nullptr;
   bool scan_graph_ = true;        // ATDN_NO_GRAPH=1: eager launches
   void launch_scan_steps(int T, int Bs, hipStream_t st);

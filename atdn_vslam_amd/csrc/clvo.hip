@@ -6,9 +6,6 @@
 
 namespace atdn {
 
-extern template TileChoice conv_dispatch<MODE_ROW, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
-extern template TileChoice conv_dispatch<MODE_ROW, EpiMishBN>(const ConvShape&, EpiMishBN, hipStream_t);
-extern template TileChoice conv_dispatch<MODE_ROW, EpiMishBNSkipMishBN>(const ConvShape&, EpiMishBNSkipMishBN, hipStream_t);
 extern template TileChoice conv_dispatch<MODE_TAP, EpiBias<ACT_NONE>>(const ConvShape&, EpiBias<ACT_NONE>, hipStream_t);
 
 ClvoNet::ClvoNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) {
@@ -22,13 +19,15 @@ ClvoNet::ClvoNet(int H_, int W_, int max_batch) : H(H_), W(W_), maxB(max_batch) 
     snprintf(b, sizeof b, "ATDNVO needs a flow size that reduces to 16x4x13 (got 16x%dx%d from %dx%d)", h, w, H, W);
     throw Error(b);
   }
+  ATDN_HIP(hipGetDevice(&dev_));   // (after the argument checks: those must report without a device)
 }
 
 ClvoNet::~ClvoNet() {
+  DeviceGuard dg(dev_);           // the handle's device, not whichever is current
   (void)hipDeviceSynchronize();   // a scan graph of this handle may still be running on the caller's stream
   for (auto& kv : scan_graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &gates_, &x2_, &pre_, &hseq_, &x2seq_, &hseq2_, &cstate_}) b->release();
+  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &pre_, &hseq_, &x2seq_, &hseq2_, &cstate_}) b->release();
   arena_.release();
 }
 
@@ -102,8 +101,6 @@ void ClvoNet::finalize() {
     fix(r.a); fix(r.b); resolve(arena_, r.skip); r.sc = arena_.dev(r.sc_off); r.sh = arena_.dev(r.sh_off);
     r.skip_w = arena_.dev(r.skip_w_off); r.skip_b = arena_.dev(r.skip_b_off);
   }
-  conv16_ = !(getenv("ATDN_CLVO_CONV16") && getenv("ATDN_CLVO_CONV16")[0] == '0');
-  pipe_ = !(getenv("ATDN_LSTM_PIPE") && getenv("ATDN_LSTM_PIPE")[0] == '0');
   scan_graph_ = !(getenv("ATDN_NO_GRAPH") && getenv("ATDN_NO_GRAPH")[0] == '1');
   ATDN_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
   for (Lin* l : {&fc_, &lstm1_ih_, &lstm1_hh_, &lstm_lin_, &lstm2_ih_, &lstm2_hh_, &rot_[0], &rot_[1], &rot_[2],
@@ -117,8 +114,6 @@ void ClvoNet::finalize() {
   bufB_.alloc((long)maxB * h1 * w1 * 16);
   bufS_.alloc((long)maxB * h1 * w1 * 16 / 4 + 64);
   flat_.alloc((long)maxB * 832);
-  gates_.alloc((long)maxB * 2048);
-  x2_.alloc((long)maxB * 512);
   ready_ = true;
 }
 
@@ -126,16 +121,9 @@ void ClvoNet::encode(const float* flow, int B, float* feat, hipStream_t st) {
   ATDN_CHECK(ready_, "weights not finalized");
   ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
   launch_prep_flow(flow, B, H, W, arena_.dev(dw_w_off_), arena_.dev(dw_b_off_), in4_.p, st);
-  auto shape = [&](const PackedConv& L, const float* src, int h, int w, int stride, int pad) {
-    ConvShape s;
-    s.src0 = src; s.ld0 = L.C; s.sb0 = (long)h * w * L.C; s.C0 = L.C; s.H = h; s.W = w;
-    s.KH = L.KH; s.KW = L.KW; s.stride = stride; s.padH = pad; s.padW = pad;
-    s.w = L.w; s.ldw = L.ldw; s.N = L.N; s.nimg = B;
-    return s;
-  };
   int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
   float* x = bufA_.p; float* t = bufB_.p;
-  if (conv16_) {
+  {
     // every layer after the depthwise 1x1 is 16 channels wide: the 16x16x4 fp32 MFMA kernels (train_kernels.hip) hold
     // the whole weight tensor in operand registers and their N tile is exactly 16 columns — a 32x32x2 tile is a quarter
     // full on these layers. Eval-mode BatchNorm/Mish (and the residual tail) are fused into the store.
@@ -154,25 +142,7 @@ void ClvoNet::encode(const float* flow, int B, float* feat, hipStream_t st) {
     Conv16Tail tl; tl.sc = last_.sc; tl.sh = last_.sh;
     launch_conv16_eval(x, B, h, w, last_.raw_w, last_.raw_b, 3, 3, 0, tl, flat_.p, st);
     launch_linear(fc_.w, flat_.p, 832, 832, nullptr, nullptr, 0, 0, fc_.b, nullptr, 1, feat, 512, 512, B, st);
-    return;
   }
-  conv_dispatch<MODE_ROW>(shape(stem_.conv, in4_.p, H, W, 2, 3),
-                          EpiMishBN{stem_.conv.b, stem_.sc, stem_.sh, x, (long)h * w * 16, 16}, st);
-  for (int i = 0; i < 4; ++i) {
-    const Res& r = res_[i];
-    const int oh = conv_out(h, 3, 2, 1), ow = conv_out(w, 3, 2, 1);
-    conv_dispatch<MODE_ROW>(shape(r.a.conv, x, h, w, 1, 1), EpiMishBN{r.a.conv.b, r.a.sc, r.a.sh, t, (long)h * w * 16, 16}, st);
-    conv_dispatch<MODE_ROW>(shape(r.skip, x, h, w, 2, 0), EpiBias<ACT_NONE>{r.skip.b, bufS_.p, (long)oh * ow * 16, 16, 1.f}, st);
-    // x is dead after the skip conv: the block output overwrites it
-    conv_dispatch<MODE_ROW>(shape(r.b.conv, t, h, w, 2, 1),
-                            EpiMishBNSkipMishBN{r.b.conv.b, r.b.sc, r.b.sh, bufS_.p, (long)oh * ow * 16, 16, r.sc, r.sh, x,
-                                                (long)oh * ow * 16, 16}, st);
-    h = oh; w = ow;
-  }
-  const int fh = conv_out(h, 3, 3, 0), fw = conv_out(w, 3, 3, 0);
-  conv_dispatch<MODE_ROW>(shape(last_.conv, x, h, w, 3, 0),
-                          EpiMishBN{last_.conv.b, last_.sc, last_.sh, flat_.p, (long)fh * fw * 16, 16}, st);
-  launch_linear(fc_.w, flat_.p, 832, 832, nullptr, nullptr, 0, 0, fc_.b, nullptr, 1, feat, 512, 512, B, st);
 }
 
 void ClvoNet::ensure_scan(long rows, int Bs) {
@@ -225,24 +195,24 @@ void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, f
     s.w = L.w; s.ldw = 512; s.N = N; s.nimg = 1;
     conv_dispatch<MODE_TAP>(s, EpiBias<ACT_NONE>{L.b, y, 0, N, 1.f}, st);
   };
-  auto scan = [&](const Lin& hh, float* h, float* c) {  // hseq_[0] = incoming h, hseq_[t+1] = h after step t
-    ATDN_HIP(hipMemcpyAsync(hseq_.p, h, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
-    for (int t = 0; t < T; ++t)
-      launch_lstm_rec(pre_.p + (long)t * Bs * 2048, hh.w, hh.b, hseq_.p + t * sb, c, hseq_.p + (t + 1) * sb, Bs, 512, st);
-    ATDN_HIP(hipMemcpyAsync(h, hseq_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
-  };
   gemm(feat, lstm1_ih_, pre_.p, 2048);
   const MlpHead R{rot_[0].w, rot_[0].b, rot_[1].w, rot_[1].b, rot_[2].w};
   const MlpHead Tt{tr_[0].w, tr_[0].b, tr_[1].w, tr_[1].b, tr_[2].w};
-  if (pipe_) {
+  {
     // lstm1 (step s), lstm_linear (step s - 1) and lstm2 with its input projection (step s - 2) share ONE launch per
     // step: T + 2 dependent launches instead of 2T + 2, replayed as one hipGraph per (T, Bs)
     ATDN_HIP(hipMemcpyAsync(hseq_.p, h1, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     ATDN_HIP(hipMemcpyAsync(hseq2_.p, h2, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     ATDN_HIP(hipMemcpyAsync(cstate_.p, c1, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     ATDN_HIP(hipMemcpyAsync(cstate_.p + sb, c2, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (scan_graph_ && T >= 4) {
-      const auto key = std::make_pair(T, Bs);
+    // Graph policy: a (T, Bs) is graphed only when it is seen for the SECOND time and T is moderate. A one-off
+    // sequence (run_sequence scans all pairs of a KITTI sequence in one call, T ~ 4500) would pay capture + instantiation
+    // of a multi-thousand-node graph for a single replay; the step is bound by its dependent launches' L2 round trips
+    // either way, so eager launches lose nothing there. bench.py warms and repeats one length: it replays.
+    const auto key = std::make_pair(T, Bs);
+    const bool seen = scan_seen_.count(key) != 0;
+    if (!seen && scan_seen_.size() < 4096) scan_seen_.insert(key);
+    if (scan_graph_ && T >= 4 && T <= kMaxGraphedSteps && (seen || scan_graphs_.count(key))) {
       if (!scan_graphs_.count(key)) {
         hipGraph_t graph = nullptr;
         ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
@@ -273,14 +243,7 @@ void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, f
     ATDN_HIP(hipMemcpyAsync(h1, hseq_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     ATDN_HIP(hipMemcpyAsync(h2, hseq2_.p + (long)T * sb, sb * sizeof(float), hipMemcpyDeviceToDevice, st));
     launch_mlp_heads(hseq2_.p + sb, (int)rows, R, Tt, rot, tr, st);
-    return;
   }
-  scan(lstm1_hh_, h1, c1);
-  launch_linear(lstm_lin_.w, hseq_.p + sb, 512, 512, nullptr, nullptr, 0, 0, lstm_lin_.b, nullptr, 1, x2seq_.p, 512, 512,
-                (int)rows, st);
-  gemm(x2seq_.p, lstm2_ih_, pre_.p, 2048);
-  scan(lstm2_hh_, h2, c2);
-  launch_mlp_heads(hseq_.p + sb, (int)rows, R, Tt, rot, tr, st);
 }
 
 }  // namespace atdn

@@ -35,6 +35,19 @@ struct Error : std::runtime_error {
     }                                                                                       \
   } while (0)
 
+// makes `dev` current for a scope (destructors of handles that own memory on ONE device: the caller's current device
+// may be another one — multi-GPU processes)
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }

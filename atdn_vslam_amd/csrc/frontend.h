@@ -33,6 +33,7 @@ class FrameIngest {
   hipEvent_t copied_[2] = {nullptr, nullptr}, consumed_[2] = {nullptr, nullptr};
   bool used_[2] = {false, false};
   int next_ = 0;
+  int dev_ = 0;
   hipStream_t copy_stream_ = nullptr;
 };
 

@@ -174,6 +174,7 @@ void launch_pad_replicate(const float* src, int planes, int H, int W, int l, int
 FrameIngest::FrameIngest(int Hin_, int Win_, int Hout_, int Wout_, int max_frames_, int antialias_)
     : Hin(Hin_), Win(Win_), Hout(Hout_), Wout(Wout_), max_frames(max_frames_), antialias(antialias_) {
   ATDN_CHECK(Hin >= 1 && Win >= 1 && Hout >= 1 && Wout >= 1 && max_frames >= 1, "bad frame geometry");
+  ATDN_HIP(hipGetDevice(&dev_));
   (void)resize_plan(Hin, Win, Hout, Wout, antialias);   // builds the tables (and validates the ratio) now
   const size_t bytes = (size_t)max_frames * 3 * Hin * Win;
   for (int s = 0; s < 2; ++s) {
@@ -185,6 +186,7 @@ FrameIngest::FrameIngest(int Hin_, int Win_, int Hout_, int Wout_, int max_frame
 }
 
 FrameIngest::~FrameIngest() {
+  DeviceGuard dg(dev_);
   (void)hipDeviceSynchronize();
   for (int s = 0; s < 2; ++s) {
     if (stage_[s]) (void)hipFree(stage_[s]);
@@ -198,6 +200,9 @@ void FrameIngest::ingest(const unsigned char* host_frames, int n, float* dst, hi
   ATDN_CHECK(host_frames && dst && n >= 1 && n <= max_frames, "frame count exceeds max_frames of this handle");
   const int s = next_;
   next_ ^= 1;
+  // Host-buffer lifetime: the copy issued two calls ago (the previous user of this slot) has finished before this call
+  // returns, so a caller only has to keep the host buffers of its last TWO calls alive (include/atdn_hip.h).
+  if (used_[s]) ATDN_HIP(hipEventSynchronize(copied_[s]));
   // the slot's previous contents must have been read by the resize kernel that used them
   if (used_[s]) ATDN_HIP(hipStreamWaitEvent(copy_stream_, consumed_[s], 0));
   ATDN_HIP(hipMemcpyAsync(stage_[s], host_frames, (size_t)n * 3 * Hin * Win, hipMemcpyHostToDevice, copy_stream_));

@@ -48,17 +48,17 @@ class GmaNet {
   // summed over `reps` forwards. Inputs are whatever the last forward() left in the workspace.
   enum Stage { ST_FNET = 0, ST_CORR, ST_POOL, ST_CNET, ST_ATTN, ST_LOOKUP, ST_MOTION, ST_AGG, ST_GRU_ZR, ST_GRU_Q, ST_FLOWHEAD,
                ST_MASK, ST_GRU_CTX, ST_ATTN_LOGITS, ST_AGG_VT, ST_CONVC1, ST_GRU_ZR_V, ST_GRU_Q_V, ST_COUNT };
-  void profile(int B, int iters, int reps, float* ms, hipStream_t st);
+  void profile(int B, int iters, int reps, float* ms, hipStream_t st, int mode = 0);
 
   int H, W, H8, W8, N, ldN, maxB, precision;
+  int dev_ = 0;   // device the handle lives on
   // feature network, split-f16 pipeline: conv2 of every residual block normalises conv1's raw output in its own
   // patch loader (conv_sf6.h NORM); ATDN_NORM_ON_LOAD=0 keeps the separate normalisation pass
   bool norm_on_load_ = false;
   // ATDN_STEM_LEGACY=1: the 7x7 stems on the exact-fp32 ROW-mode engine (conv_mfma.h) instead of stem_sf.hip
   bool stem_legacy_ = false;
-  // split-f16 pipeline: pyramid level 1 = fmap1 x (2x2-pooled fmap2)^T, a quarter-size GEMM, instead of pooling the
-  // 210 MB level-0 volume (correlation is linear in the target features); ATDN_POOL_FEATURES=0 pools the volume
-  bool pool_features_ = false;
+  // split-f16 pipeline, row-major pyramid (ATDN_LOOKUP_LEGACY=1): level 1 = fmap1 x (2x2-pooled fmap2)^T, a quarter-size
+  // GEMM, instead of pooling the 210 MB level-0 volume (correlation is linear in the target features)
   DeviceBuf fpool_;
   // split-f16 pipeline: attention as QK^T with the softmax fused in + the streaming attention x V kernel (attention.hip);
   // ATDN_ATTN_LEGACY=1 keeps the round-1 path (logits GEMM, softmax pass, attention x V on the generic GEMM kernel)
@@ -70,7 +70,6 @@ class GmaNet {
   int brickBW_[4], brickBH_[4], brickNB_[4];
   BrickPyramid brick_pyramid() const;
   bool attn_legacy_ = false;
-  int attn_fmt_ = AT_FMT_H3;   // element format of the stored attention matrix (attention.h); ATDN_ATTN_FMT=sf4
   DeviceBuf rowmax_, rinv_;
 
  private:

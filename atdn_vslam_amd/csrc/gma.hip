@@ -105,10 +105,11 @@ void GmaNet::mark(int stage, hipStream_t st) {
   timer_->marks.emplace_back(stage, e);
 }
 
-void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st) {
+void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st, int mode) {
   ATDN_CHECK(ready_ && B >= 1 && B <= maxB && reps >= 1, "bad profile request");
+  ATDN_CHECK(mode == 0 || precision >= 1, "sequence modes are built for the split-f16 pipeline");
   for (int i = 0; i < ST_COUNT; ++i) ms[i] = 0.f;
-  seq_ = 0;
+  seq_ = mode;   // 0 pair, 1 sequence, 2 continued sequence (fmap_ slot 0 is read as it stands: timing only)
   last_frame_ = 0;   // fmap_ is overwritten: a continued sequence call must not read it
   for (int r = 0; r < reps; ++r) {
     Timer t;
@@ -137,18 +138,18 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   ATDN_CHECK(H % 8 == 0 && W % 8 == 0 && H >= 64 && W >= 64, "frame size must be a multiple of 8 (use the padder)");
   ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
-  pool_features_ = precision >= 1 && !(getenv("ATDN_POOL_FEATURES") && getenv("ATDN_POOL_FEATURES")[0] == '0');
   flowhead_fused_ = !(getenv("ATDN_FLOWHEAD_FUSED") && getenv("ATDN_FLOWHEAD_FUSED")[0] == '0');
   stem_legacy_ = getenv("ATDN_STEM_LEGACY") && getenv("ATDN_STEM_LEGACY")[0] == '1';
   norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
   lookup_legacy_ = precision == 0 || (getenv("ATDN_LOOKUP_LEGACY") && getenv("ATDN_LOOKUP_LEGACY")[0] == '1');
   attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
-  if (getenv("ATDN_ATTN_FMT") && std::string(getenv("ATDN_ATTN_FMT")) == "sf4") attn_fmt_ = AT_FMT_SF4;
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
+  (void)hipGetDevice(&dev_);   // (no throw: argument errors must be reportable without a device; finalize() needs one anyway)
 }
 
 GmaNet::~GmaNet() {
+  DeviceGuard dg(dev_);   // the handle's device, not whichever is current
   // a graph replay or kernel of this handle may still be running on the caller's stream
   (void)hipDeviceSynchronize();
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
@@ -250,7 +251,7 @@ void GmaNet::finalize() {
     coords_used_.alloc(n8 * 2);
   }
   h_[0].alloc(n8 * 128); h_[1].alloc(n8 * 128); x_.alloc(n8 * XLD);
-  const AttnGeom ag = attn_geom(B, N, ldN, attn_fmt_);
+  const AttnGeom ag = attn_geom(B, N, ldN);
   qk_.alloc(n8 * 256); attn_.alloc(std::max(n8 * ldN, attn_floats(ag))); vT_.alloc((long)B * 128 * ldN);
   if (!attn_legacy_) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
@@ -582,7 +583,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
     a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
     conv_sf_dispatch(a, 1.f, SfAggregate{gamma_, mf, (long)N * XLD, XLD, x_.p + 256, (long)N * XLD, XLD}, st);
   } else {
-    launch_attn_v(attn_.p, rinv_.p, attn_geom(B, N, ldN, attn_fmt_), vT_.p, gamma_, mf, x_.p + 256, (long)N * XLD, XLD,
+    launch_attn_v(attn_.p, rinv_.p, attn_geom(B, N, ldN), vT_.p, gamma_, mf, x_.p + 256, (long)N * XLD, XLD,
                   sf_fast_mode(), st);
   }
   mark(ST_AGG, st);
@@ -654,15 +655,13 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   } else {
   conv_sf_dispatch(c, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[0].p, (long)N * N, N}, st);
   mark(ST_CORR, st);
-  if (pool_features_) {
+  {
     const int N1 = pyrH_[1] * pyrW_[1];
     launch_pool_features_sf(c.w, B, H8, W8, 256, (long)N * 256, fpool_.p, (long)N1 * 256, st);
     ConvShape c1 = c;
     c1.w = fpool_.p; c1.wb = (long)N1 * 256; c1.N = N1;
     conv_sf_dispatch(c1, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[1].p, (long)N * N1, N1}, st);
     for (int l = 2; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
-  } else {
-    for (int l = 1; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
   }
   mark(ST_POOL, st);
   }
@@ -685,7 +684,7 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   } else {
     // Q K^T with the row softmax fused in (attention.hip): a cheap first sweep (f16 x f16 logits) for the row maxima,
     // then the full-precision sweep that writes exp(s - max) in MFMA-operand order and the row sums
-    const AttnGeom ag = attn_geom(B, N, ldN, attn_fmt_);
+    const AttnGeom ag = attn_geom(B, N, ldN);
     launch_qk_rowmax(qk_.p, ag, rowmax_.p, st);
     mark(ST_ATTN_LOGITS, st);
     launch_qk_softmax(qk_.p, ag, rowmax_.p, attn_.p, rinv_.p, sf_fast_mode(), st);
@@ -823,7 +822,7 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
     const long rows = (long)maxB * N * ldN;
     if (scratch_.n < rows) { scratch_.release(); scratch_.alloc(rows); }
     ATDN_HIP(hipMemsetAsync(scratch_.p, 0, (size_t)rows * sizeof(float), st));
-    launch_attn_decode(attn_.p, rinv_.p, attn_geom(maxB, N, ldN, attn_fmt_), scratch_.p, st);
+    launch_attn_decode(attn_.p, rinv_.p, attn_geom(maxB, N, ldN), scratch_.p, st);
     ATDN_HIP(hipStreamSynchronize(st));
     n = std::min(capacity, rows);
     ATDN_HIP(hipMemcpy(host, scratch_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));

@@ -63,12 +63,6 @@ void launch_prep_rgb(const float* images, int B, int H, int W, float* out4, hipS
 void launch_linear(const float* W0, const float* x0, int K0, int ldx0, const float* W1, const float* x1, int K1,
                    int ldx1, const float* b0, const float* b1, int act, float* y, int ldy, int N, int B,
                    hipStream_t st);
-// LSTMCell pointwise part, gate order i,f,g,o; gates [B][4*Hd]; c in/out, h out
-void launch_lstm_cell(const float* gates, float* c, float* h, int B, int Hd, hipStream_t st);
-// One recurrent LSTM step with the input projection already done: gates = pre[b] + (Whh·h_in[b] + b_hh), then the
-// pointwise cell update (gate order i,f,g,o). One wave per hidden unit; h_out must not alias h_in.
-void launch_lstm_rec(const float* pre, const float* Whh, const float* bhh, const float* h_in, float* c, float* h_out,
-                     int B, int Hd, hipStream_t st);
 // One time step of the recurrent tail as a three-stage pipeline (see lstm_pipe_kernel): stage 1 = lstm1 cell on
 // pre1 (= W_ih1 x + b_ih1, batched beforehand) and h1_in; stage 2 = lin_out = Mish(Wlin lin_in + blin); stage 3 = lstm2
 // cell on x2_in and h2_in with its input projection inline. Stages with do_* == 0 are skipped (pipeline fill / drain).

@@ -433,60 +433,6 @@ void launch_linear(const float* W0, const float* x0, int K0, int ldx0, const flo
   ATDN_HIP(hipGetLastError());
 }
 
-__global__ void lstm_cell_kernel(const float* __restrict__ gates, float* __restrict__ c, float* __restrict__ h, int B,
-                                 int Hd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * Hd) return;
-  const int b = i / Hd, j = i - b * Hd;
-  const float* g = gates + (long)b * 4 * Hd;
-  const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[Hd + j]), gg = tanhf(g[2 * Hd + j]), og = sigmoidf_(g[3 * Hd + j]);
-  const float cn = fg * c[i] + ig * gg;
-  c[i] = cn;
-  h[i] = og * tanhf(cn);
-}
-void launch_lstm_cell(const float* gates, float* c, float* h, int B, int Hd, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_cell_kernel, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, gates, c, h, B, Hd);
-  ATDN_HIP(hipGetLastError());
-}
-
-__global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__ pre, const float* __restrict__ Whh,
-                                                       const float* __restrict__ bhh, const float* __restrict__ h_in,
-                                                       float* __restrict__ c, float* __restrict__ h_out, int B, int Hd) {
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);  // hidden unit of this wave
-  if (j >= Hd) return;
-  const int lane = threadIdx.x & 63;
-  for (int b = 0; b < B; ++b) {
-    const float4* hv = reinterpret_cast<const float4*>(h_in + (long)b * Hd);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane; k < Hd / 4; k += 64) {
-      const float4 x = hv[k];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 w = reinterpret_cast<const float4*>(Whh + ((long)g * Hd + j) * Hd)[k];
-        acc[g] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = wave_sum(acc[g]);
-    if (lane == 0) {
-      const float* p = pre + (long)b * 4 * Hd;
-      const float gi = p[j] + (acc[0] + bhh[j]);
-      const float gf = p[Hd + j] + (acc[1] + bhh[Hd + j]);
-      const float gg = p[2 * Hd + j] + (acc[2] + bhh[2 * Hd + j]);
-      const float go = p[3 * Hd + j] + (acc[3] + bhh[3 * Hd + j]);
-      const float cn = sigmoidf_(gf) * c[(long)b * Hd + j] + sigmoidf_(gi) * tanhf(gg);
-      c[(long)b * Hd + j] = cn;
-      h_out[(long)b * Hd + j] = sigmoidf_(go) * tanhf(cn);
-    }
-  }
-}
-void launch_lstm_rec(const float* pre, const float* Whh, const float* bhh, const float* h_in, float* c, float* h_out,
-                     int B, int Hd, hipStream_t st) {
-  ATDN_CHECK(Hd % 4 == 0 && h_in != h_out, "lstm_rec: bad arguments");
-  hipLaunchKernelGGL(lstm_rec_kernel, dim3(cdiv(Hd, 4)), dim3(256), 0, st, pre, Whh, bhh, h_in, c, h_out, B, Hd);
-  ATDN_HIP(hipGetLastError());
-}
-
 // ---- the whole recurrent tail as a three-stage software pipeline, ONE launch per time step (the scan is bound by the
 // launch rate, ~5.5 us per dependent launch): launch s runs lstm1 for step s (blocks [0,G)), lstm_linear + Mish for step
 // s - 1 and lstm2 — input projection included — for step s - 2; every stage reads what the previous launch wrote.

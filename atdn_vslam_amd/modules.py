@@ -52,6 +52,10 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class SplitF16RangeError(RuntimeError):
+    """Activations left the range of the split-f16 format (|x| > 65504, or NaN): results are no longer fp32-grade."""
+
+
 def _require_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError("%s: the MI355X path needs tensors on a HIP device (got %s); there is no CPU fallback"
@@ -73,11 +77,18 @@ class _NativeModule(nn.Module):
             ent[2](ent[0])
         self._handles = {}
 
-    @staticmethod
-    def _key(H, W):
-        """Native handles own weights and workspace on ONE device: keyed by (device index, H, W), so a module moved
-        with .to(other_gpu) builds a new handle there instead of launching on the old device's memory."""
-        return (torch.cuda.current_device(), H, W)
+    def _device(self):
+        """The device the module's parameters live on (NOT torch's current device: on a multi-GPU rank the two can differ)."""
+        p = next(self.parameters(), None)
+        if p is None or not p.is_cuda:
+            raise RuntimeError("%s: move the module to a HIP device first (.to('cuda:N')); there is no CPU fallback"
+                               % type(self).__name__)
+        return p.device
+
+    def _key(self, H, W):
+        """Native handles own weights and workspace on ONE device: keyed by (device index of the module's parameters, H, W),
+        so a module moved with .to(other_gpu) builds a new handle there instead of launching on the old device's memory."""
+        return (self._device().index, H, W)
 
     def _apply(self, fn, *args, **kw):
         # .to() / .cuda() / .float(): parameters move, handles built from the old ones are stale
@@ -105,9 +116,17 @@ class RAFTGMA(_NativeModule):
 
     PRECISIONS = {"f32": 0, "split_f16": 1, "f16": 2}
 
-    def __init__(self, args=None, max_batch=1, precision=None):
+    def __init__(self, args=None, max_batch=1, precision=None, saturation_check_every=512):
+        """`saturation_check_every`: in the split-f16 modes the module reads the library's saturation counter after the
+        FIRST forward of a freshly loaded checkpoint (and whenever the weights changed), then every that many forwards
+        (0: never again), and `check_saturation()` can be called at any time (OdometryPipeline.run_sequence does, at the end
+        of a sequence). A non-zero count raises SplitF16RangeError."""
         super().__init__()
         self.args = args
+        self.saturation_check_every = int(saturation_check_every)
+        self.saturation_checks = 0      # how many times the counter has been read (tests)
+        self._sat_pending = True        # a checkpoint whose first forward has not been checked yet
+        self._sat_calls = 0
         self.precision = precision or os.environ.get("ATDN_PRECISION", "split_f16")
         if self.precision not in self.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
@@ -125,6 +144,42 @@ class RAFTGMA(_NativeModule):
         d = torch.arange(n).view(1, -1) - torch.arange(n).view(-1, 1)
         self.att.pos_emb.rel_ind.copy_(d + n - 1)
 
+    def _drop_handles(self):
+        super()._drop_handles()
+        self._sat_pending = True        # new weights (load_state_dict / .to()): the next forward is checked again
+
+    def check_saturation(self, raise_on_clamp=True):
+        """Reads (and resets) the split-f16 saturation counter of this module's device: the number of values that had to be
+        clamped to +-65504 (or were NaN) since the last read. Synchronises the current stream. The counter is per device, so
+        it covers every split-f16 handle of the process on that device."""
+        if self.precision == "f32" or not self._handles:
+            return 0
+        dev = self._device()
+        out = torch.empty(1, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            h = next(ent[0] for key, ent in self._handles.items() if key[0] == dev.index)
+            n = _lib.lib().atdn_gma_debug_read(h, b"sf_clamped", C.c_void_p(out.data_ptr()), 1, _stream())
+        if n < 0:
+            _lib.check(1)
+        self.saturation_checks += 1
+        self._sat_pending = False
+        self._sat_calls = 0
+        clamped = int(out[0])
+        if clamped and raise_on_clamp:
+            raise SplitF16RangeError(
+                "%d activation(s) of the flow network left the range of the split-f16 format (|x| > 65504, or NaN): with this "
+                "checkpoint the default arithmetic is not fp32-grade. Construct the module with precision=\"f32\" (or set "
+                "ATDN_PRECISION=f32; the C ABI calls this mode ATDN_PRECISION_F32) to run every GEMM on the exact-fp32 matrix "
+                "core instead." % clamped)
+        return clamped
+
+    def _after_forward(self):
+        if self.precision == "f32":
+            return
+        self._sat_calls += 1
+        if self._sat_pending or (self.saturation_check_every > 0 and self._sat_calls >= self.saturation_check_every):
+            self.check_saturation()
+
     def _handle(self, H, W, B):
         key = self._key(H, W)
         fp = self._fingerprint()
@@ -132,6 +187,7 @@ class RAFTGMA(_NativeModule):
         if ent is not None and (ent[1] != fp or ent[3] < B):
             ent[2](ent[0])
             ent = None
+            self._sat_pending = True
         if ent is None:
             L = _lib.lib()
             h = C.c_void_p()
@@ -165,6 +221,7 @@ class RAFTGMA(_NativeModule):
             h = self._handle(H, W, B)
             _lib.check(_lib.lib().atdn_gma_forward(h, _ptr(im1), _ptr(im2), B, int(iters), _ptr(fi), _ptr(flow_low),
                                                    _ptr(flow_up), _stream()))
+            self._after_forward()
         return flow_low, flow_up
 
     @torch.no_grad()
@@ -193,22 +250,28 @@ class RAFTGMA(_NativeModule):
             h = self._handle(H, W, B)
             fn = _lib.lib().atdn_gma_forward_sequence_continued if continued else _lib.lib().atdn_gma_forward_sequence
             _lib.check(fn(h, _ptr(fr), B, int(iters), _ptr(fi), _ptr(flow_low), _ptr(flow_up), _stream()))
+            self._after_forward()
         return flow_low, flow_up
 
     def debug_read(self, name, shape, H, W):
         """Copy an internal activation of the (H, W) handle to a CPU tensor (parity tests)."""
         out = torch.empty(shape, dtype=torch.float32)
-        h = self._handles[self._key(H, W)][0]
-        n = _lib.lib().atdn_gma_debug_read(h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), _stream())
+        with torch.cuda.device(self._device()):
+            h = self._handles[self._key(H, W)][0]
+            n = _lib.lib().atdn_gma_debug_read(h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), _stream())
         if n < 0:
             _lib.check(1)
         return out
 
-    def profile(self, H, W, B, iters=12, reps=1):
-        """Per-stage device milliseconds of one eager forward (HIP events on the current stream)."""
+    def profile(self, H, W, B, iters=12, reps=1, mode="pair"):
+        """Per-stage device milliseconds of one eager forward (HIP events on the current stream). `mode`: "pair" (two
+        feature-network passes per pair), "sequence" (B + 1 frames) or "continued" (B frames: what a continued clip of a
+        long sequence costs — the mode bench.py times)."""
         ms = (C.c_float * len(_lib.GMA_STAGES))()
-        h = self._handle(H, W, B)
-        _lib.check(_lib.lib().atdn_gma_profile(h, B, int(iters), int(reps), ms, _stream()))
+        with torch.cuda.device(self._device()):
+            h = self._handle(H, W, B)
+            _lib.check(_lib.lib().atdn_gma_profile_mode(h, B, int(iters), int(reps), {"pair": 0, "sequence": 1, "continued": 2}[mode],
+                                                        ms, _stream()))
         return {k: float(v) / reps for k, v in zip(_lib.GMA_STAGES, ms)}
 
     def freeze_bn(self):  # network.py:45-48; inference-only module: nothing to freeze

@@ -46,6 +46,11 @@ class FrameIngest:
         self.device = torch.device(device)
         self.in_size, self.size, self.max_frames = tuple(in_size), tuple(size), int(max_frames)
         self._h = C.c_void_p()
+        # host buffers of the copies that may still be in flight: one per staging slot. The native call waits (on the host)
+        # for the copy that last used the slot it is about to reuse, so the buffers of the last TWO calls are the only ones
+        # an asynchronous copy can still read (include/atdn_hip.h, LIFETIME).
+        self._keep = [None, None]
+        self._calls = 0
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().atdn_ingest_create(C.byref(self._h), self.in_size[0], self.in_size[1], self.size[0],
                                                      self.size[1], self.max_frames, int(bool(antialias))))
@@ -64,7 +69,8 @@ class FrameIngest:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().atdn_ingest_frames_u8(self._h, C.c_void_p(x.data_ptr()), n, C.c_void_p(out.data_ptr()),
                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        self._keep = x   # the copy is asynchronous: the host buffer must outlive it
+        self._keep[self._calls & 1] = x   # replaces the buffer of two calls ago, whose copy the native call just waited for
+        self._calls += 1
         return out
 
     def __del__(self):
@@ -115,31 +121,61 @@ class OdometryPipeline:
         return rot[:, 0], tr[:, 0]
 
     @torch.no_grad()
-    def run_sequence(self, frames, batch=4, group=None, antialias=True):
+    def run_sequence(self, frames, batch=4, group=None, antialias=True, lanes=None, timing=None):
         """A whole sequence -> absolute poses [T,4,4] float64 (identity first), identical on every rank of `group`.
 
         frames [T,3,Hin,Win]: uint8 in HOST memory (pinned for asynchronous copies; every rank needs at least its own
         shard + 1 frame: the camera sequence as `evaluate_odometry.py` / NeuralSLAM walk it, neural_slam.py:196-221), or a
-        tensor already on the device (uint8 or float). Each rank takes the contiguous shard `shard_range` gives it, walks it
-        in clips of `batch` pairs (host frames: H2D on the ingest's copy stream + convert + resize; device frames: resize),
-        reuses the features of the frame two clips share, and the ranks exchange one all-gather of 512-d features
-        before the replicated ordered scan (sharding.py)."""
+        tensor already on the device (uint8 or float); any object with `.shape`, `.dtype`, `.is_cuda` and slice indexing
+        that returns such tensors works (a memory-mapped or cyclic sequence). Each rank takes the contiguous shard
+        `shard_range` gives it, walks it in clips of `batch` pairs (host frames: H2D on the ingest's copy stream + convert +
+        resize; device frames: resize), reuses the features of the frame two clips share, and the ranks exchange one
+        all-gather of 512-d features before the replicated ordered scan (sharding.py).
+        lanes: further OdometryPipeline objects on the SAME device (own handles and workspaces). The rank's shard is then
+        cut into 1 + len(lanes) contiguous sub-ranges that are walked concurrently on separate HIP streams, one clip at a
+        time round-robin: the tails of one stream's kernels are filled by the other's (what bench.py's two streams do).
+        timing: dict receiving the host-clock seconds of encode / gather / scan (adds three device synchronisations)."""
         from .sharding import sharded_sequence
         T = frames.shape[0]
         host = not frames.is_cuda
         if host and frames.dtype != torch.uint8:
             raise RuntimeError("run_sequence: host frames must be uint8 (camera frames); move float frames to the device")
-        ingest = FrameIngest(tuple(frames.shape[-2:]), batch + 1, size=self.size, antialias=antialias,
-                             device=self.device) if host else None
+        pipes = [self] + list(lanes or [])
+        for p in pipes:
+            if p.device != self.device or tuple(p.size) != tuple(self.size) or p.iters != self.iters:
+                raise RuntimeError("run_sequence: every lane must be an OdometryPipeline on %s with the same size / iterations"
+                                   % (self.device,))
+        L = len(pipes)
+        with torch.cuda.device(self.device):
+            streams = [torch.cuda.current_stream()] if L == 1 else [torch.cuda.Stream(device=self.device) for _ in pipes]
+        ingests = [FrameIngest(tuple(frames.shape[-2:]), batch + 1, size=self.size, antialias=antialias, device=self.device)
+                   for _ in pipes] if host else None
+        main = torch.cuda.current_stream(self.device)
 
-        def encode_clip(s, e, continued):
-            clip = frames[s:e + 1]
-            fr = ingest(clip) if host else resize_frames(clip, self.size, antialias=antialias)
-            f, _ = self.features_clip(fr, continued=continued)
+        def encode_clip(s, e, continued, lane=0):
+            with torch.cuda.stream(streams[lane]):
+                clip = frames[s:e + 1]
+                fr = ingests[lane](clip) if host else resize_frames(clip, self.size, antialias=antialias)
+                f, _ = pipes[lane].features_clip(fr, continued=continued)
+                if L > 1:
+                    f.record_stream(main)
             return f
 
+        def join():
+            for st in streams:
+                main.wait_stream(st)
+
         encode_clip.device = self.device
-        rot, tr = sharded_sequence(T, encode_clip, self.scan, batch, group)
+        encode_clip.join = join
+        encode_clip.sync = lambda: torch.cuda.synchronize(self.device)
+        if L > 1:
+            for st in streams:
+                st.wait_stream(main)
+        rot, tr = sharded_sequence(T, encode_clip, self.scan, batch, group, lanes=L, timing=timing)
+        # split-f16 saturation guard: one counter read per sequence (the first forward of a fresh checkpoint was checked
+        # inside forward_sequence already); raises SplitF16RangeError if anything was clamped on this rank's shard
+        # (the counter is per device: it covers every lane)
+        self.flow_net.check_saturation()
         return transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
 
 

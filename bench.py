@@ -10,6 +10,10 @@ encoder -> 512-d feature. After the K steps the timed region also holds the sequ
 all-gather of the features and the ordered LSTM/MLP scan + rel2abs that turns them into the 6-DoF
 trajectory (every rank ends up with all N*K*B poses). The uint8 frames are resident in HBM before timing starts
 (`value`); a second timed pass ingests them from pinned host memory instead (`h2d_inclusive`, never the headline).
+Secondary legs in the same JSON line (none of them is `value`): `config3` = BASELINE configs[2] as a benchmark — ONE
+synthetic 4,541-frame uint8 sequence in pinned host memory, sharded over the N ranks, through
+OdometryPipeline.run_sequence (ingest, flow, head, one all-gather, replicated scan, rel2abs): 4540 / max-over-ranks wall;
+`f16_fast` = the opt-in plain-f16 mode with its measured flow error against the split-f16 output of the same clip.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
 """
@@ -50,6 +54,26 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: f16/bf16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 
 
+class CyclicSequence:
+    """A T-frame uint8 camera sequence in pinned host memory without T frames of memory: frame k of the sequence is frame
+    k mod `period` of a (2B + 1)-frame clip played forwards and backwards, laid out in sequence order with B + 1 extra
+    frames at the end, so that any window of at most B + 1 consecutive frames is ONE contiguous slice of the pinned buffer
+    (consecutive frames are always neighbours of the base clip: the flow between them is real motion, not a jump).
+    Duck-types what OdometryPipeline.run_sequence needs: .shape, .dtype, .is_cuda, slice indexing."""
+
+    def __init__(self, seq_host, period, T):
+        self.buf, self.period, self.T = seq_host, period, T
+        self.shape = (T,) + tuple(seq_host.shape[1:])
+        self.dtype, self.is_cuda = seq_host.dtype, False
+        self.window = seq_host.shape[0] - period
+
+    def __getitem__(self, sl):
+        a, b, step = sl.indices(self.T)
+        assert step == 1 and 0 < b - a <= self.window, "windows of at most %d consecutive frames" % self.window
+        k = a % self.period
+        return self.buf[k:k + (b - a)]
+
+
 def kernel_table(stages, B):
     """Per-kernel rows from the SAME-RUN per-stage HIP-event timing (atdn_gma_profile; stages that hold launches of one
     kernel only): name, rocprof name fragment, launches per forward, us per launch, bounding roofline, algorithmic bytes
@@ -82,10 +106,18 @@ def kernel_table(stages, B):
             ach, peak, unit = work / (us * 1e-6) / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
             ach, peak, unit = work / (us * 1e-6) / 1e12, PEAK_F16_MFMA_TFLOPS, "TFLOP/s"
-        rows.append({"stage": stage, "kernel": label, "rocprof_name_contains": frag, "launches_per_forward": launches,
-                     "us_per_launch": round(us, 2), "ms_per_forward": round(ms, 4), "bound": bound,
-                     "algorithmic_per_launch": work, "algorithmic_unit": "bytes" if bound == "hbm" else "FLOP",
-                     "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
+        row = {"stage": stage, "kernel": label, "rocprof_name_contains": frag, "launches_per_forward": launches,
+               "us_per_launch": round(us, 2), "ms_per_forward": round(ms, 4), "bound": bound,
+               "algorithmic_per_launch": work, "algorithmic_unit": "bytes" if bound == "hbm" else "FLOP",
+               "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak}
+        if stage == "aggregate":
+            # the kernel is co-bound by its own matrix loop: 3 f16 MFMAs per product of the [N x N] x [N x 128] GEMM
+            # (fast mode: 1), and it moves 3 bytes per element, not the 4 the algorithmic figure counts
+            row["mfma_executed_tflops"] = MFMA_PER_PRODUCT_NOW[0] * 2.0 * nn * 128 * B / (us * 1e-6) / 1e12
+            row["mfma_executed_frac"] = row["mfma_executed_tflops"] / PEAK_F16_MFMA_TFLOPS
+            row["stored_bytes_per_launch"] = nn * 3.0 * B
+            row["frac_stored_bytes"] = nn * 3.0 * B / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
+        rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_forward"])
     return rows
 
@@ -143,6 +175,7 @@ def cpu_baseline(gsd, hsd, frames, budget_s=25.0):
 
 
 MFMA_PER_PRODUCT = {"split_f16": 3, "f16": 1, "f32": 1}   # MFMAs the engine executes per algorithmic product
+MFMA_PER_PRODUCT_NOW = [3]                                 # ... of the precision this run's headline uses (set in main)
 DTYPE_LABEL = {"split_f16": "f32 via 3xf16 split MFMA (fp32 accumulate)",
                "f16": "f16 operands, fp32 accumulate (fast mode, own tolerance)",
                "f32": "f32 (exact fp32 MFMA)"}
@@ -159,6 +192,9 @@ def main():
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed pass that ingests host frames")
     ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f16", "f32"],
                     help="arithmetic of the flow network; the headline is split_f16 (fp32-grade). f16 = fast mode")
+    ap.add_argument("--no-config3", action="store_true", help="skip the sharded-sequence leg (BASELINE configs[2])")
+    ap.add_argument("--config3-frames", type=int, default=4541, help="frames of the synthetic sequence of the config3 leg")
+    ap.add_argument("--no-f16-leg", action="store_true", help="skip the secondary timed pass in the f16 fast mode")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,6 +216,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     B, K, Wm = args.batch, args.steps, args.warmup
+    MFMA_PER_PRODUCT_NOW[0] = MFMA_PER_PRODUCT[args.precision]
 
     gsd = syn.to_torch(syn.make_gma_state(seed=1))
     hsd = syn.to_torch(syn.make_clvo_state(seed=1))
@@ -203,8 +240,10 @@ def main():
     torch.cuda.synchronize()
 
     calls = [0] * S
+    active = [pipes]   # the pipelines step() drives (the f16 leg swaps in its own)
 
     def step(i, feats, slot=None, host=False):
+        pipes = active[0]
         p = i % S
         j = calls[p]
         calls[p] += 1
@@ -267,11 +306,59 @@ def main():
     dt, step_ms, tail_ms = timed(host=False)
     h2d = None if args.no_h2d_leg else timed(host=True)
 
+    # ---- config3: ONE long sequence sharded over the ranks (evaluate_odometry.py:60-75: the LSTM state is never reset
+    # inside a sequence), uint8 frames in pinned host memory, through the product's sequence driver; both streams of every
+    # GPU walk their own contiguous sub-shard (lanes). Timed host-clock, barrier + synchronize on both sides, max over ranks.
+    c3 = None
+    if not args.no_config3:
+        T3 = max(2, args.config3_frames)
+        cyc = CyclicSequence(seq_host, period, T3)
+        lanes = pipes[1:]
+        # warm every (clip length, continued) graph the plan needs, on every lane, outside the timed region
+        from atdn_vslam_amd.sharding import clip_plan, lane_ranges, shard_range
+        lo3, hi3 = shard_range(T3 - 1, rank, world)
+        for lane, (a, b) in enumerate(lane_ranges(lo3, hi3, B, S)):
+            need = sorted({(e - s, c) for (s, e, c) in clip_plan(a, b, B)}, key=lambda t: (t[1], -t[0]))
+            with torch.cuda.stream(streams[lane]):
+                for (n, cont) in need:
+                    pipes[lane].features_clip(resize_frames(seq_dev[:n + 1]), continued=cont)
+        join()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        timing = {}
+        t0 = time.perf_counter()
+        poses3 = pipe.run_sequence(cyc, batch=B, lanes=lanes, timing=timing)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt3 = time.perf_counter() - t0
+        assert tuple(poses3.shape) == (T3, 4, 4) and bool(torch.isfinite(poses3).all())
+        t3 = torch.tensor([dt3, timing["encode_s"], timing["gather_s"], timing["scan_s"]], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        c3 = [float(x) for x in t3.tolist()] + [T3]
+
+    # ---- f16 fast mode as a secondary leg: same steps, same frames, precision="f16" handles (never the headline)
+    f16 = None
+    if not args.no_f16_leg and args.precision == "split_f16":
+        fast = [OdometryPipeline(gsd, hsd, device=dev, max_batch=B, iters=ITERS, precision="f16") for _ in range(S)]
+        frames0 = resize_frames(seq_dev[:B + 1])
+        _, up_ref = pipe.features_clip(frames0)
+        _, up_fast = fast[0].features_clip(frames0)
+        d = (up_fast - up_ref).abs()
+        f16_err = (float(d.max()), float(d.mean()), float(up_ref.abs().max()))
+        active[0] = fast
+        f16 = timed(host=False) + (f16_err,)
+        active[0] = pipes
+        del fast
+
     if rank == 0:
         total_pairs = world * K * B
         # per-stage device time of the same forward in this run, eager with HIP events on the launch stream
         reps = 3
-        st = pipe.flow_net.profile(H, W, B, iters=ITERS, reps=reps)
+        # in the call form the timed loop uses: a CONTINUED clip (B feature-network passes, not the 2B of pair mode)
+        st = pipe.flow_net.profile(H, W, B, iters=ITERS, reps=reps, mode="continued")
         rows = kernel_table(st, B)
         top = rows[0]
         traffic, traffic_src = pmc_traffic(top["rocprof_name_contains"], B)
@@ -294,8 +381,13 @@ def main():
                          "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": top["us_per_launch"] / 1e3,
                          "algorithmic_per_launch": top["algorithmic_per_launch"],
-                         "algorithmic_unit": top["algorithmic_unit"], "share_of_forward": top["ms_per_forward"] / sum(st.values())},
+                         "algorithmic_unit": top["algorithmic_unit"],
+                         # share of the eager stage sum of one continued-clip forward (one stream, events between launches)
+                         # and of the timed step (two streams overlapping: completion-to-completion interval)
+                         "share_of_forward": top["ms_per_forward"] / sum(st.values()),
+                         "share_of_timed_step": top["ms_per_forward"] / fwd_ms},
             "kernels": rows[:5],
+            "stages_mode": "continued clip (B feature-network passes per B pairs): the call form the timed loop uses",
             "forward": {"ms_per_batch_median": fwd_ms,
                         "tflops_algorithmic_0.951_per_pair": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12,
                         "tflops_executed_work": FLOP_PER_PAIR_EXECUTED * B / (fwd_ms * 1e-3) / 1e12,
@@ -309,6 +401,25 @@ def main():
             "sequence_tail_ms": round(tail_ms, 3),
         }
         out["stages_ms_per_forward"]["attention_total"] = round(st["attention"] + st["attn_logits"], 4)
+        for k in ("mfma_executed_tflops", "mfma_executed_frac", "stored_bytes_per_launch", "frac_stored_bytes"):
+            if k in top:
+                out["roofline"][k] = top[k]
+        if traffic is not None and top["bound"] == "hbm":
+            # PMC bytes (committed profile) over this run's launch time: the fraction of the HBM peak in REAL bytes
+            out["roofline"]["frac_real_bytes"] = traffic / (top["us_per_launch"] * 1e-6) / 1e9 / PEAK_HBM_GBS
+        if c3 is not None:
+            out["config3"] = {"workload": "ONE synthetic KITTI-00-shaped sequence of %d uint8 frames (pinned host memory) sharded over %d "
+                                          "rank(s), OdometryPipeline.run_sequence: ingest + flow + head, one all-gather, replicated "
+                                          "scan, rel2abs (BASELINE configs[2])" % (c3[4], world),
+                              "pairs": c3[4] - 1, "value": (c3[4] - 1) / c3[0], "unit": "frame-pairs/s", "wall_s": c3[0],
+                              "encode_s": c3[1], "allgather_ms": c3[2] * 1e3, "scan_rel2abs_ms": c3[3] * 1e3,
+                              "lanes_per_gpu": S, "ratio_to_value": ((c3[4] - 1) / c3[0]) / (total_pairs / dt)}
+        if f16 is not None:
+            out["f16_fast"] = {"value": total_pairs / f16[0], "unit": "frame-pairs/s", "ms_per_step": f16[0] * 1e3 / K,
+                               "ratio_to_value": (total_pairs / f16[0]) / (total_pairs / dt),
+                               "dtype": DTYPE_LABEL["f16"],
+                               "flow_up_abs_diff_vs_split_f16_px": {"max": f16[3][0], "mean": f16[3][1], "max_abs_flow": f16[3][2],
+                                                                     "sample": "%d pairs of the bench clip, 12 iterations" % B}}
         if h2d is not None:
             # second timed pass of the same K steps with the uint8 frames in pinned HOST memory: H2D (copy stream,
             # double-buffered) + convert + resize inside the timed region. Never the headline `value`.

@@ -90,6 +90,10 @@ long atdn_gma_debug_read(atdn_gma* h, const char* name, float* host, long capaci
  * per-launch times. */
 #define ATDN_GMA_STAGES 18
 int atdn_gma_profile(atdn_gma* h, int B, int iters, int reps, float* ms_out, void* stream);
+/* The same for one of the three call forms: mode 0 = atdn_gma_forward (pair mode, 2B feature-network passes; what
+ * atdn_gma_profile times), 1 = atdn_gma_forward_sequence (B + 1 passes), 2 = atdn_gma_forward_sequence_continued (B passes:
+ * a continued clip of a long sequence, the form bench.py times). Split-f16 / f16 handles only for modes 1 and 2. */
+int atdn_gma_profile_mode(atdn_gma* h, int B, int iters, int reps, int mode, float* ms_out, void* stream);
 
 size_t atdn_gma_workspace_bytes(atdn_gma* h);
 void atdn_gma_destroy(atdn_gma* h);
@@ -195,6 +199,10 @@ int atdn_pad_frames(const float* src, int planes, int H, int W, int left, int ri
  * asynchronous H2D copy (pinned host memory; pageable memory works but serialises) on the handle's own copy stream
  * into one of two device staging slots, then resize + uint8->fp32 on `stream`. Consecutive calls alternate slots, so
  * the copy of the next clip overlaps the flow network of the current one.
+ * LIFETIME: the copy is asynchronous. `host_frames` must stay valid (and unmodified) until the copy has completed:
+ * that is guaranteed once the SECOND-NEXT call of atdn_ingest_frames_u8 on the same handle has returned (a call waits
+ * on the host for the copy that last used its staging slot), or once `stream` has been synchronised after this call.
+ * A caller that keeps the host buffers of its last two calls alive is safe (pipeline.FrameIngest does).
  *   host_frames [n_frames,3,Hin,Win] uint8 (HOST) -> dst [n_frames,3,Hout,Wout] fp32 (DEVICE), n_frames <= max_frames */
 typedef struct atdn_ingest atdn_ingest;
 int atdn_ingest_create(atdn_ingest** out, int Hin, int Win, int Hout, int Wout, int max_frames, int antialias);

@@ -63,6 +63,26 @@ def main():
     assert all(c == (s > lo) for (s, e, c) in seen) and (not seen or (seen[0][0] == lo and seen[-1][1] == hi))
     # (the CPU oracle's convolutions round differently for different batch sizes: equal to fp32 noise, not bit for bit)
     assert float((rot2 - rot).abs().max()) < 1e-6 and float((tr2 - tr).abs().max()) < 1e-6
+    # two lanes per rank (two HIP streams on a GPU): the shard is cut into contiguous sub-ranges walked round-robin; every
+    # lane's first clip is not continued, the concatenated features are in sequence order, results unchanged
+    from atdn_vslam_amd.sharding import lane_ranges
+    seen2, joined = [], []
+
+    def encode_clip_lane(s, e, continued, lane):
+        seen2.append((s, e, continued, lane))
+        return clvo_ref.clvo_encode(hsd, flows[s:e])
+
+    encode_clip_lane.join = lambda: joined.append(len(seen2))
+    timing = {}
+    rot3, tr3 = sharded_sequence(n_pairs + 1, encode_clip_lane, scan, 2, lanes=2, timing=timing)
+    ranges = lane_ranges(lo, hi, 2, 2)
+    for lane, (a, b) in enumerate(ranges):
+        mine = [(s, e, c) for (s, e, c, l) in seen2 if l == lane]
+        assert mine == clip_plan(a, b, 2)
+    assert sorted(p for (s, e, _, _) in seen2 for p in range(s, e)) == list(range(lo, hi))
+    assert joined == ([len(seen2)] if hi > lo else [0]) or (hi == lo and joined == [])
+    assert float((rot3 - rot).abs().max()) < 1e-6 and float((tr3 - tr).abs().max()) < 1e-6
+    assert timing["local_pairs"] == hi - lo and timing["encode_s"] >= 0 and timing["scan_s"] > 0
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rot=rot.numpy(), tr=tr.numpy())
     dist.barrier()
     dist.destroy_process_group()

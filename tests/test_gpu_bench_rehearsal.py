@@ -17,16 +17,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_two_rank_bench_rehearsal_prints_one_valid_line():
     env = dict(os.environ, ATDN_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg"]
+           "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--config3-frames", "44"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    # --steps 3 with two streams per GPU: a step count the streams do not divide
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["value"] > 0 and d["unit"] == "frame-pairs/s" and "REHEARSAL" in d["data"]
     B = d["config"]["pairs_per_step_per_gpu"]
     assert "x2" in d["config"]["parallelism"] and B >= 8
-    # whole-job aggregate: 2 ranks x 2 steps x B pairs over the max-over-ranks time
-    assert abs(d["value"] - 2 * 2 * B / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"] + 1e-3
+    # whole-job aggregate: 2 ranks x 3 steps x B pairs over the max-over-ranks time
+    assert abs(d["value"] - 2 * 3 * B / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"] + 1e-3
+    # config3 leg (BASELINE configs[2]): 43 pairs over 2 ranks = shards of 22 and 21 pairs: two lanes per rank, the second
+    # lane SHORTER than one clip of 16 (6 / 5 pairs); one all-gather, replicated scan
+    c3 = d["config3"]
+    assert c3["pairs"] == 43 and c3["lanes_per_gpu"] == 2 and c3["value"] > 0
+    assert abs(c3["value"] - 43 / c3["wall_s"]) < 1e-6 * c3["value"]
+    assert c3["encode_s"] > 0 and c3["allgather_ms"] >= 0 and c3["scan_rel2abs_ms"] > 0
+
+
+def test_bench_config3_with_a_shard_shorter_than_one_clip():
+    """A rank whose whole shard is shorter than one clip (9 pairs over 2 ranks: 5 and 4 pairs, clips of 16): one lane per
+    rank, a single short clip, the gather is ragged."""
+    env = dict(os.environ, ATDN_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--config3-frames", "10"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config3"]["pairs"] == 9 and d["config3"]["value"] > 0

@@ -43,6 +43,20 @@ def test_clip_plan_covers_a_shard_in_order():
         assert got == list(range(n))
 
 
+def test_lane_ranges_cut_a_shard_into_stream_sub_ranges():
+    from atdn_vslam_amd.sharding import clip_plan, lane_ranges
+    assert lane_ranges(5, 5, 4, 2) == []
+    assert lane_ranges(0, 10, 16, 2) == [(0, 10)]                      # a shard shorter than one clip: one lane
+    assert lane_ranges(0, 4540, 16, 2) == [(0, 2272), (2272, 4540)]    # KITTI-00 on one GPU, two streams
+    for lo, hi, batch, lanes in ((0, 33, 16, 3), (6, 11, 4, 2), (568, 1136, 16, 2), (0, 7, 2, 4)):
+        r = lane_ranges(lo, hi, batch, lanes)
+        assert r[0][0] == lo and r[-1][1] == hi and len(r) <= lanes
+        assert all(b == c for (_, b), (c, _) in zip(r, r[1:]))
+        assert all((b - a) % batch == 0 for (a, b) in r[:-1])          # only the last lane may end on a short clip
+        clips = [len(clip_plan(a, b, batch)) for a, b in r]
+        assert max(clips) - min(clips) <= 1
+
+
 def _single_process(n_pairs):
     hsd = syn.to_torch(syn.make_clvo_state(seed=1))
     flows = torch.from_numpy(syn.make_flow(n_pairs, 376, 1232, seed=31))

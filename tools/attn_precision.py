@@ -1,5 +1,5 @@
-"""Flow error against the CPU oracle for the attention storage variants (diagnostic):
-    ATDN_ATTN_LEGACY=1 | ATDN_ATTN_FMT=sf4 | default (H3)   x   cnet scale 1 / 16"""
+"""Flow error against the CPU oracle for the attention paths (diagnostic):
+    ATDN_ATTN_LEGACY=1 (logits GEMM + softmax pass + 4-byte matrix) | default (fused, H3 storage)   x   cnet scale 1 / 16"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,14 @@
-"""Diagnostic: stored attention probabilities (decoded) of the H3 and SF4 formats against the CPU oracle's softmax."""
+"""Diagnostics on the stored attention matrix (H3 format, decoded by atdn_gma_debug_read("attn")):
+
+1. decoded probabilities against the CPU oracle's softmax at the plumbing size (accuracy of the storage format);
+2. VERDICT r2 #6: how PEAKED the softmax rows are — the fraction of (32-row strip, 32-column chunk) blocks of the matrix in
+   which every element is below 2^-12 of its row's maximum (dropping such a block's residual term changes sum_k e_k v_k by
+   less than fp32 rounding of the sum), and the fraction of (128-row, chunk) groups in which all four strips qualify
+   (attn_v3_kernel multiplies four strips per SIMD set and phase: a skip only shortens a phase when all four agree).
+   Measured at the headline size (376x1232) on the synthetic checkpoint, at scale 1 and with att.to_qk x4.
+
+    python tools/attn_rows_check.py [--skip-accuracy]
+"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,16 +18,16 @@ from atdn_vslam_amd.modules import RAFTGMA
 from oracle import gma_ref
 
 gsd = syn.to_torch(syn.make_gma_state(seed=1))
-for scale in (1.0, 16.0):
-    sd = {k: v.clone() for k, v in gsd.items()}
-    sd["cnet.conv1.weight"] *= scale
-    sd["cnet.conv1.bias"] *= scale
-    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=71))
-    taps = {}
-    gma_ref.gma_forward(sd, fr[0:1], fr[1:2], iters=1, taps=taps)
-    ref = taps["attn"].reshape(1280, 1280).double()
-    for fmt in ("h3", "sf4"):
-        os.environ["ATDN_ATTN_FMT"] = fmt
+
+if "--skip-accuracy" not in sys.argv:
+    for scale in (1.0, 16.0):
+        sd = {k: v.clone() for k, v in gsd.items()}
+        sd["cnet.conv1.weight"] *= scale
+        sd["cnet.conv1.bias"] *= scale
+        fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=71))
+        taps = {}
+        gma_ref.gma_forward(sd, fr[0:1], fr[1:2], iters=1, taps=taps)
+        ref = taps["attn"].reshape(1280, 1280).double()
         net = RAFTGMA(max_batch=1)
         net.load_state_dict(sd)
         net = net.to("cuda:0").eval()
@@ -25,6 +35,34 @@ for scale in (1.0, 16.0):
         a = net.debug_read("attn", (1280, 1280), 160, 512).double()
         err = (a - ref).abs()
         rowmax = ref.max(dim=1, keepdim=True).values
-        print("scale %-4g %s: max abs err %.3e, max err / rowmax %.3e, row-sum err %.3e, peak prob %.3f, rel err of entries > 1e-3*rowmax: %.3e"
-              % (scale, fmt, float(err.max()), float((err / rowmax).max()), float((a.sum(1) - 1).abs().max()), float(ref.max()),
-                 float((err / ref.clamp_min(1e-30))[ref > 1e-3 * rowmax].max())))
+        print("accuracy, cnet scale %-4g: max abs err %.3e, max err / rowmax %.3e, row-sum err %.3e, peak prob %.3f, rel err of "
+              "entries > 1e-3*rowmax: %.3e" % (scale, float(err.max()), float((err / rowmax).max()), float((a.sum(1) - 1).abs().max()),
+                                               float(ref.max()), float((err / ref.clamp_min(1e-30))[ref > 1e-3 * rowmax].max())))
+
+H, W = 376, 1232
+N = (H // 8) * (W // 8)
+ldN = (N + 31) // 32 * 32
+fr = torch.from_numpy(syn.make_frames(2, H, W, seed=71))
+for label, f in (("scale 1", 1.0), ("att.to_qk x4", 4.0), ("att.to_qk x16", 16.0)):
+    sd = {k: v.clone() for k, v in gsd.items()}
+    sd["att.to_qk.weight"] *= f
+    net = RAFTGMA(max_batch=1, saturation_check_every=0)
+    net.load_state_dict(sd)
+    net = net.to("cuda:0").eval()
+    net(fr[0:1].cuda(), fr[1:2].cuda(), iters=1, test_mode=True)
+    a = net.debug_read("attn", (N, ldN), H, W).cuda()
+    rowmax = a.max(dim=1, keepdim=True).values.clamp_min(1e-30)
+    rel = a / rowmax                                             # e / max_e of the row
+    RT = (N + 31) // 32
+    pad = torch.zeros((RT * 32 - N, ldN), device=rel.device)
+    blk = torch.cat([rel, pad], 0).view(RT, 32, ldN // 32, 32)   # [strip][row][chunk][col]
+    bmax = blk.amax(dim=(1, 3))                                   # [strip][chunk]
+    for thr_exp in (12, 10, 8):
+        ok = bmax < 2.0 ** -thr_exp
+        RT4 = RT // 4 * 4
+        ok4 = ok[:RT4].view(RT4 // 4, 4, -1).all(dim=1)
+        print("%-14s blocks with every element < 2^-%d of its row maximum: %.1f %% of (strip, chunk) blocks, %.1f %% of "
+              "(4-strip group, chunk) groups" % (label, thr_exp, 100.0 * float(ok.float().mean()), 100.0 * float(ok4.float().mean())))
+    ent = -(a.clamp_min(1e-30) * a.clamp_min(1e-30).log()).sum(1)
+    print("%-14s peak probability median %.2e (uniform would be %.2e), row entropy median %.2f nats (uniform %.2f)"
+          % (label, float(a.max(1).values.median()), 1.0 / N, float(ent.median()), float(torch.log(torch.tensor(float(N))))))
