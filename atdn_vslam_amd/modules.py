@@ -81,8 +81,9 @@ class _NativeModule(nn.Module):
         """The device the module's parameters live on (NOT torch's current device: on a multi-GPU rank the two can differ)."""
         p = next(self.parameters(), None)
         if p is None or not p.is_cuda:
-            raise RuntimeError("%s: move the module to a HIP device first (.to('cuda:N')); there is no CPU fallback"
-                               % type(self).__name__)
+            # parameters still on the host (the native handle uploads its own copy): the device torch has current —
+            # every forward runs under torch.cuda.device(input.device), so that is the input's device
+            return torch.device("cuda", torch.cuda.current_device())
         return p.device
 
     def _key(self, H, W):

@@ -64,15 +64,16 @@ def test_saturation_guard_raises_through_the_product_path():
     exact-fp32 mode. The same checkpoint runs in precision="f32"."""
     bad = _scaled_state({"cnet.conv1": 3e5})   # BatchNorm is folded: every activation behind the stem grows by that factor
     hsd = syn.to_torch(syn.make_clvo_state(seed=1))
-    pipe = OdometryPipeline(bad, hsd, device=DEV, max_batch=1, iters=2, size=(160, 512))
-    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=3)).to(DEV)
+    # (the pose head only takes flows that reduce to 16x4x13: the pipeline runs at the KITTI size)
+    pipe = OdometryPipeline(bad, hsd, device=DEV, max_batch=1, iters=2)
+    fr = torch.from_numpy(syn.make_frames(2, 376, 1232, seed=3)).to(DEV)
     with pytest.raises(SplitF16RangeError) as ei:
         pipe.features(fr[0:1], fr[1:2])
     assert "precision=\"f32\"" in str(ei.value) and "ATDN_PRECISION" in str(ei.value)
     # the sequence driver checks too (end of run_sequence), on a module whose first-call check has been consumed
     good = syn.to_torch(syn.make_gma_state(seed=1))
-    pipe2 = OdometryPipeline(good, hsd, device=DEV, max_batch=2, iters=2, size=(160, 512))
-    seq = torch.from_numpy(syn.make_frames(5, 160, 512, seed=5)).to(DEV)
+    pipe2 = OdometryPipeline(good, hsd, device=DEV, max_batch=2, iters=2)
+    seq = torch.from_numpy(syn.make_frames(5, 376, 1232, seed=5)).to(DEV)
     poses = pipe2.run_sequence(seq, batch=2)
     assert tuple(poses.shape) == (5, 4, 4)
     assert pipe2.flow_net.saturation_checks >= 2          # first forward + end of the sequence

@@ -249,3 +249,139 @@ extern "C" int atdn_microbench_mfma(int steps, int launches, float* tf_out) {
   }
 }
 #include "pp_probe.hip"
+
+// ---- conv-like MFMA loop (round 3): the question behind VERDICT r2 #1-iv / #5 — does the 16x16x32 shape buy anything in a loop
+// that looks like conv_sf6's (pixel operands re-read from a conflict-free LDS image every step, weight operands in
+// registers, 8 waves per block = two per SIMD, 128 pixels x 32 channels per wave, split-f16: three MFMAs per product)?
+// SHAPE 0: v_mfma_f32_32x32x16_f16, pixel pitch 144 B (lane = (pixel & 31, k half)); SHAPE 1: v_mfma_f32_16x16x32_f16, pixel
+// pitch 160 B (lane = (pixel & 15, k quarter): the pitch that makes those ds_read_b128 conflict-free).
+namespace atdn {
+template <int SHAPE>
+__global__ __launch_bounds__(512) void mfma_convlike_kernel(const float* __restrict__ data, float* __restrict__ out, int steps) {
+  constexpr int PITCH = SHAPE == 0 ? 144 : 160;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 128 * PITCH];   // two images (stand-ins for two taps) of 128 pixels
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 2 * 128 * PITCH / 4; i += 512) reinterpret_cast<float*>(lds)[i] = data[i % (2 * 128 * 32)];
+  __syncthreads();
+  float total = 0.f;
+  // weight operands: 32 channels x K = 32, hi and lo
+  f16x8 wh[2], wl[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    wh[t] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(data) + ((tid * 2 + t) * 32) % (2 * 128 * 128 - 32));
+    wl[t] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(data) + ((tid * 2 + t) * 32 + 16) % (2 * 128 * 128 - 32));
+  }
+  if constexpr (SHAPE == 0) {
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    f16x8 ah[2][4], al[2][4];
+    auto rd = [&](int set, int img, int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* p = lds + img * 128 * PITCH + (i * 32 + r) * PITCH + 32 * t + 16 * h;
+        ah[set][i] = *reinterpret_cast<const f16x8*>(p);
+        al[set][i] = *reinterpret_cast<const f16x8*>(p + 64);
+      }
+    };
+    rd(0, 0, 0);
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+      for (int hs = 0; hs < 4; ++hs) {     // two taps x two half-steps
+        __builtin_amdgcn_sched_barrier(0);
+        rd((hs + 1) & 1, ((hs + 1) >> 1) & 1, (hs + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[hs & 1], al[hs & 1][i], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[hs & 1], ah[hs & 1][i], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[hs & 1], ah[hs & 1][i], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (k < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+    }
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) total += acc[i][e];
+  } else {
+    const int r = lane & 15, q = lane >> 4;
+    f32x4_t acc[8][2];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    f16x8 ah[2][4], al[2][4];
+    auto rd = [&](int set, int img, int half) __attribute__((always_inline)) {   // pixel blocks 4 half .. 4 half + 3
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* p = lds + img * 128 * PITCH + ((half * 4 + i) * 16 + r) * PITCH + 16 * q;
+        ah[set][i] = *reinterpret_cast<const f16x8*>(p);
+        al[set][i] = *reinterpret_cast<const f16x8*>(p + 64);
+      }
+    };
+    rd(0, 0, 0);
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+      for (int hs = 0; hs < 4; ++hs) {     // two taps x two halves of the wave's pixel blocks
+        __builtin_amdgcn_sched_barrier(0);
+        rd((hs + 1) & 1, ((hs + 1) >> 1) & 1, (hs + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[(hs & 1) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[hs & 1][i], acc[(hs & 1) * 4 + i][j], 0, 0, 0);
+            acc[(hs & 1) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[hs & 1][i], acc[(hs & 1) * 4 + i][j], 0, 0, 0);
+            acc[(hs & 1) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[hs & 1][i], acc[(hs & 1) * 4 + i][j], 0, 0, 0);
+          }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (k < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+    }
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) total += acc[i][j][e];
+  }
+  out[blockIdx.x * 512 + tid] = total;
+}
+
+template <int SHAPE>
+static float time_convlike(const float* data, float* out, int steps, int launches, hipStream_t st) {
+  hipEvent_t a, b;
+  ATDN_HIP(hipEventCreate(&a)); ATDN_HIP(hipEventCreate(&b));
+  for (int i = 0; i < launches / 4 + 1; ++i) hipLaunchKernelGGL((mfma_convlike_kernel<SHAPE>), dim3(256), dim3(512), 0, st, data, out, steps);
+  ATDN_HIP(hipEventRecord(a, st));
+  for (int i = 0; i < launches; ++i) hipLaunchKernelGGL((mfma_convlike_kernel<SHAPE>), dim3(256), dim3(512), 0, st, data, out, steps);
+  ATDN_HIP(hipEventRecord(b, st));
+  ATDN_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  ATDN_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  // per step and wave: 2 taps x (128 px x 32 ch x K 32) x 3 products
+  const double flop = 256.0 * 8 * steps * (2.0 * 128 * 32 * 32 * 2 * 3) * launches;
+  return (float)(flop / (ms * 1e-3) / 1e12);
+}
+}  // namespace atdn
+
+// tf_out[4]: {32x32x16, 16x16x32} x {random, zero} executed TFLOP/s of the conv-like loop
+extern "C" int atdn_microbench_mfma_convlike(int steps, int launches, float* tf_out) {
+  try {
+    hipStream_t st = nullptr;
+    float *rnd, *zero, *out;
+    const size_t n = 2 * 128 * 32;
+    ATDN_HIP(hipMalloc(&rnd, n * 4)); ATDN_HIP(hipMalloc(&zero, n * 4)); ATDN_HIP(hipMalloc(&out, 256 * 512 * 4));
+    std::vector<unsigned short> h(n * 2);
+    unsigned v = 777u;
+    for (auto& e : h) { v = v * 1664525u + 1013904223u; e = (unsigned short)(0x3000 + ((v >> 16) & 0x0FFF) + ((v >> 31) << 15)); }
+    ATDN_HIP(hipMemcpy(rnd, h.data(), n * 4, hipMemcpyHostToDevice));
+    ATDN_HIP(hipMemset(zero, 0, n * 4));
+    int k = 0;
+    for (const float* d : {(const float*)rnd, (const float*)zero}) {
+      tf_out[k++] = time_convlike<0>(d, out, steps, launches, st);
+      tf_out[k++] = time_convlike<1>(d, out, steps, launches, st);
+    }
+    (void)hipFree(rnd); (void)hipFree(zero); (void)hipFree(out);
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  }
+}

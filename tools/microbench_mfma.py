@@ -15,3 +15,10 @@ names = ["32x32x16 regs", "32x32x16 LDS re-read", "16x16x32 regs", "16x16x32 LDS
 for d, data in enumerate(("random", "zero")):
     for i, n in enumerate(names):
         print("%-7s %-22s %8.0f TF/s executed" % (data, n, out[d * 4 + i]))
+
+# round 3: the conv-like loop (pixel operands from a conflict-free LDS image, weights in registers, two waves per SIMD)
+out4 = (C.c_float * 4)()
+assert L.atdn_microbench_mfma_convlike(2000, 100, out4) == 0
+for d, data in enumerate(("random", "zero")):
+    for i, n in enumerate(("32x32x16 conv-like (pitch 144)", "16x16x32 conv-like (pitch 160)")):
+        print("%-7s %-32s %8.0f TF/s executed" % (data, n, out4[d * 2 + i]))
