@@ -399,6 +399,12 @@ int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const
                         void* stream) {
   ATDN_API_BEGIN
   ATDN_CHECK(src && weight_host && dst && nimg >= 1 && Cin % 32 == 0, "bad argument (Cin must be a multiple of 32)");
+  // MFMA shape of the halo kernels for this call (tests compare both): ATDN_CONV_M32=1 selects the 32x32x16 loop
+  struct ShapeGuard {
+    bool prev = sf_mfma16();
+    ShapeGuard() { const char* e = getenv("ATDN_CONV_M32"); sf_mfma16() = !(e && e[0] == '1'); }
+    ~ShapeGuard() { sf_mfma16() = prev; }
+  } shape_guard;
   StateDict sd;
   const int64_t ws[4] = {Cout, Cin, KH, KW};
   sd.put("c.weight", weight_host, ws, 4);
@@ -420,7 +426,7 @@ int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const
     s.KH = KH; s.KW = KW; s.stride = stride; s.padH = padH; s.padW = padW;
     s.w = L.w; s.ldw = L.ldw; s.N = Cout; s.nimg = nimg;
     const int Ho = conv_out(H, KH, stride, padH), Wo = conv_out(W, KW, stride, padW);
-    s.wfrag = L.wf;
+    s.wfrag = L.wf; s.wfrag16 = L.wf16;
     // ATDN_SF_CONV_EPILOGUE=sf (tests): write split-f16 through the SfBias epilogue, then unpack — exercises the
     // channel-vector sf store; needs Cout % 32 == 0. Default: fp32 output through EpiBias.
     const char* mode = getenv("ATDN_SF_CONV_EPILOGUE");

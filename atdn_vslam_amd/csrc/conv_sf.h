@@ -249,6 +249,10 @@ inline void launch_conv_sf(const ConvShape& s, float wscale, const Epi& ep, hipS
 // Plain-f16 arithmetic (precision mode 2) for the calling thread's sf convolutions: conv_sf_dispatch issues only the
 // hi x hi MFMA of every product while this is set (GmaNet sets it around its forward).
 bool& sf_fast_mode();
+// MFMA shape of the halo kernels (conv_sf6.h) for the calling thread: true = v_mfma_f32_16x16x32_f16 (default), false =
+// v_mfma_f32_32x32x16_f16, the loop round 3 replaced (a GmaNet built under ATDN_CONV_M32=1 sets it around its forward; kept
+// while tests/test_gpu_round3.py compares the two).
+bool& sf_mfma16();
 
 // Definitions are explicitly instantiated in conv_sf_inst_*.hip
 template <class Epi>

@@ -64,9 +64,32 @@ template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bo
 // pixel and 32-channel chunk); the patch loader applies relu((x - mean) * rstd) per (image, channel), splits to hi | lo and
 // writes the sf chunk image itself, one patch row per half-step over the last NP half-steps of a chunk — the separate
 // normalisation pass between the two convs of a residual block (read 4 B + write 4 B per element) disappears.
+// M16: the loop runs on v_mfma_f32_16x16x32_f16 (K = 32 per instruction: a whole 32-channel chunk of one tap) instead of
+// v_mfma_f32_32x32x16_f16. Same FLOP per cycle, same operand bytes per FLOP, but on random data the chip holds a higher
+// clock under this shape: the conv-like loop of tools/microbench (pixel operands from LDS, weights in registers, two
+// waves per SIMD) runs at 1914 instead of 1575 TF/s executed (profiles/r03_microbench_mfma.txt; equal on all-zero
+// operands: it is the clock, MI355X_MICROARCH.md "DVFS give-back" item 7). What changes:
+//   * operand lane map: lane (n = lane & 15, g = lane >> 4) holds, for row / column n of a 16-wide block, the 16-byte slot
+//     g of the chunk's [32 hi] (or [32 lo]) halves; a wave's 32-pixel row tile is two 16-pixel blocks = the two patch rows
+//     it covers (TW = 16), its 32-channel tile two 16-channel blocks;
+//   * the pixel pitch of the patch image is 160 B (144 B puts slot g + 1 of pixels 4-11 on the banks of slot g of pixels
+//     12-15 and 0-3 in the lane groups of ds_read_b128; 160 B = 10 slots is conflict-free for this lane map);
+//   * weights come from the fragment-major copy for this shape (weights.h: pack_fragment_major16): [N/16][K/32][hi | lo]
+//     [lane] x 16 B, one contiguous KiB per wave load as before;
+//   * a K step (tap, chunk) is still two half-steps — pixel half 0 (first patch row of every row tile) and half 1 — with the
+//     pixel fragments of the next half-step read during the current one; the weights of a K step (channel block 0 loaded in
+//     half-step 0, block 1 in half-step 1) stay in a ring of RT K-step slots, RT - 1 steps ahead;
+//   * accumulator: b[pixel half][channel block] of 4 registers: in SWAP mode (weights = row operand) lane (n, g) holds
+//     channels 16 cb + 4 g + 0..3 of pixel 16 half + n.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool M16> struct SfAcc;
+template <> struct SfAcc<false> { f32x16 v; };
+template <> struct SfAcc<true> { f32x4v b[2][2]; };
+
 template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2,
-          bool NORM = false>
+          bool NORM = false, bool M16 = false>
 __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2) ? 4 : 1)) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
+  static_assert(!M16 || (TW == 16 && FRAGW && ABL == 0), "the 16x16x32 loop is built for 16-pixel tile rows and fragment-major weights");
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = TH * TW / 32 / WM, TN = BN / 32 / WN;
   static_assert(TM * WM * 32 == TH * TW && TN * WN * 32 == BN, "wave grid must tile the block");
@@ -76,11 +99,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
   constexpr int PROWS = (TH + KH - 1) * (TW + KW - 1);
   constexpr int PW = TW + KW - 1;
   constexpr int NP = (PROWS + RSTEP - 1) / RSTEP;
-  constexpr int ROWB = LDS_LD * 4;
-  // LDS pitch between patch rows: a multiple of 256 B, so the two tile rows that one ds_read_b128 lane group
+  constexpr int ROWB = M16 ? 160 : LDS_LD * 4;   // pixel pitch of the patch image
+  // LDS pitch between patch rows. 32x32x16: a multiple of 256 B, so the two tile rows that one ds_read_b128 lane group
   // ({0-3,12-15,20-27}, ... : pixels x..x+3, x+12..x+15 of one row and x+4..x+11 of the next) touches land on
-  // 16 distinct 16-byte bank slots (pixel pitch 144 B = 9 slots, 9 odd); PW*144 alone gives 2-way conflicts
-  constexpr int RS = (PW * ROWB + 255) / 256 * 256;
+  // 16 distinct 16-byte bank slots (pixel pitch 144 B = 9 slots, 9 odd); PW*144 alone gives 2-way conflicts.
+  // 16x16x32: a fragment read stays inside one patch row, any pitch works
+  constexpr int RS = M16 ? PW * ROWB : (PW * ROWB + 255) / 256 * 256;
   constexpr bool SWAP = epi_vec4<Epi>::value;
   // two patch images: chunk c+1 is written (from the registers its loads landed in) during the last tap of chunk c,
   // so a chunk boundary costs one barrier, not two
@@ -104,7 +128,11 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
   // (NORM: its loader writes 8-byte halves, ds_write_b64 = groups of 16 lanes = two patch rows; with rows 4 apart —
   // 4 x 36 dwords = 16 mod 32 banks — instead of adjacent the two rows' 16 banks do not overlap. SQ_LDS_BANK_CONFLICT of
   // the normalise-on-load kernels was 11-15 % of their LDS cycles.)
-  const int s = tid & 7, r0 = NORM ? ((tid >> 6) << 3) + (((tid >> 3) & 7) >> 1) + 4 * ((tid >> 3) & 1) : tid >> 3;
+  // (pixel pitch 160 B = 40 dwords: rows TWO apart are 16 banks apart)
+  const int jrow = (tid >> 3) & 7;
+  const int s = tid & 7, r0 = !NORM ? tid >> 3
+                            : M16 ? ((tid >> 6) << 3) + 2 * (jrow & 1) + ((jrow >> 1) & 1) + 4 * (jrow >> 2)
+                                  : ((tid >> 6) << 3) + (jrow >> 1) + 4 * (jrow & 1);
   // per patch row of this thread: (pixel offset in the image + 1, 0 = zero padding) << 12 | LDS offset / 16
   static_assert((TH + KH - 1) * RS / 16 <= 4096, "LDS offset field");
   unsigned pmeta[NP];
@@ -161,157 +189,287 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
 
   // ---- MFMA roles
   const int wm = wave / WN, wn = wave % WN;
-  const int r = lane & 31, h = lane >> 5;
-  f32x16 acc[TM][TN];
+  SfAcc<M16> acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (M16) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j].b[e >> 3][(e >> 2) & 1][e & 3] = 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j].v[e] = 0.f;
+      }
+    }
+  if constexpr (!M16) {
+    const int r = lane & 31, h = lane >> 5;
+    int a_off[TM];
+  #pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int p = (wm * TM + i) * 32 + r;
+      a_off[i] = (p / TW) * RS + (p % TW) * ROWB + 16 * h;
+    }
+    const char* Pb = Pbytes;   // image of the current chunk
+    // weight fragment rows (clamped: accumulators of rows >= N are never stored)
+    const float* wrow[TN];
+  #pragma unroll
+    for (int j = 0; j < TN; ++j)
+      if constexpr (FRAGW)  // fragment-major weights: [n/32][q][t][hi|lo][lane] x 16 B, one contiguous KiB per wave load
+        wrow[j] = g.w + (long)min((n0 >> 5) + wn * TN + j, ((g.N + 31) >> 5) - 1) * (NTAP * nck) * 1024 + lane * 4;
+      else
+        wrow[j] = g.w + (long)min(n0 + (wn * TN + j) * 32 + r, g.N - 1) * g.ldw + 4 * h;
+
+    // Weight fragments live in a ring of R half-step slots (half-step = one 16-wide K sub-step of one tap). R divides
+    // the 2*NTAP half-steps of a chunk, so every slot index is a compile-time constant: no register rotation (copying
+    // w1 = w2 made the compiler wait for a load right after issuing it) and the load for half-step hs + R - 1 goes
+    // into the slot half-step hs - 1 just released. The chunk body is branch-free (the prefetches of the last chunk
+    // are clamped to valid, unused data), i.e. one scheduling region, and sched_group_barrier pins the interleave:
+    // one LDS read or global load behind every MFMA, reads for the NEXT half-step first.
+    constexpr int NH = 2 * NTAP;
+    // (the high-occupancy single-image variant keeps the ring short: its budget is 128 registers per lane)
+    constexpr int R = (NIMG == 1 && NH % 3 == 0) ? 3 : (NH % 5 == 0) ? 5 : (NH % 6 == 0) ? 6 : 4;
+    static_assert(NH % R == 0 && NH >= R, "ring size must divide the half-steps of a chunk");
+    struct HFrag { f16x8 hi[TN], lo[TN]; };
+    HFrag wr[R];
+    auto load_wh = [&](HFrag& f, int c, int hs) {
+      const int q = (hs >> 1) * nck + c;  // packed K order is [tap][channel chunk]
+      const int t = hs & 1;
+  #pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (FRAGW) {
+          f.hi[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512);
+          f.lo[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512 + 256);
+        } else {
+          f.hi[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t);
+          f.lo[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t + 16);
+        }
+      }
+    };
+
+    fetch_patch(0);
+    if constexpr (NORM) fetch_norm(0);
+  #pragma unroll
+    for (int hs = 0; hs < R - 1; ++hs) load_wh(wr[hs], 0, hs);
+    if (ABL & 1) load_wh(wr[R - 1], 0, R - 1);
+    if constexpr (NORM) {
+  #pragma unroll
+      for (int k = 0; k < NP; ++k) store_row_norm(0, k, nmu, nrs);
+    } else {
+      store_patch(0);
+    }
+    __syncthreads();
+    // activation fragments: two register sets, the ds_reads of half-step hs + 1 are issued among the MFMAs of hs
+    f16x8 ah[2][TM], al[2][TM];
+    auto read_a = [&](int set, int tap, int t) {
+      const char* arow = Pb + (tap / KW) * RS + (tap % KW) * ROWB;
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t);
+        al[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t + 64);
+      }
+    };
+    auto mfma_half = [&](int set, const HFrag& w) {
+  #pragma unroll
+      for (int i = 0; i < TM; ++i)
+  #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (SWAP) {
+            if constexpr (!FAST) {
+              acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[j], al[set][i], acc[i][j].v, 0, 0, 0);
+              acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo[j], ah[set][i], acc[i][j].v, 0, 0, 0);
+            }
+            acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[j], ah[set][i], acc[i][j].v, 0, 0, 0);
+          } else {
+            if constexpr (!FAST) {
+              acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][i], w.hi[j], acc[i][j].v, 0, 0, 0);
+              acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][i], w.lo[j], acc[i][j].v, 0, 0, 0);
+            }
+            acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][i], w.hi[j], acc[i][j].v, 0, 0, 0);
+          }
+        }
+    };
+    constexpr int NMF = (FAST ? 1 : 3) * TM * TN;   // MFMAs per half-step
+    read_a(0, 0, 0);
+    for (int c = 0; c < nck; ++c) {
+      const int cn = min(c + 1, nck - 1);   // clamped: the prefetches of the last chunk fetch valid, unused data
+  #pragma unroll
+      for (int hs = 0; hs < NH; ++hs) {
+        // every half-step is its own scheduling region: without this fence the interleave solver moves the LDS reads
+        // of half-step hs + 1 to just before their consumers
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 2) && hs == 0) { fetch_patch(cn); if constexpr (NORM) fetch_norm(cn); }  // lands during this chunk's taps
+        if (!(ABL & 1)) {
+          const int nhs = hs + R - 1;
+          if (nhs < NH) load_wh(wr[nhs % R], c, nhs); else load_wh(wr[nhs % R], cn, nhs - NH);
+        }
+        if (!(ABL & 4) && hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1, (hs + 1) & 1);
+        if constexpr (NORM) {   // one patch row per half-step: the conversion arithmetic spreads over NP half-steps
+          static_assert(!NORM || (NIMG == 2 && NH - 1 - NP >= 1), "normalise-on-load needs two patch images and NP < NH - 1");
+          if (hs >= NH - 1 - NP && hs <= NH - 2) store_row_norm((c + 1) & 1, hs - (NH - 1 - NP), nmu, nrs);
+        } else {
+          if (NIMG == 2 && !(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
+        }
+        mfma_half(hs & 1, wr[hs % R]);
+        // interleave: one memory instruction behind each MFMA — LDS reads first (they feed the next half-step), then
+        // the global loads, then the patch image writes
+        {
+          constexpr int nds = 2 * TM;
+          const int nvm = 2 * TN + (hs == 0 ? NP : 0);
+          const int ndw = NORM ? ((hs >= NH - 1 - NP && hs <= NH - 2) ? 2 : 0) : ((NIMG == 2 && hs == NH - 2) ? NP : 0);
+  #pragma unroll
+          for (int k = 0; k < NMF; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (hs + 1 < NH && k < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (k - ((hs + 1 < NH) ? nds : 0) < nvm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            else if (k - ((hs + 1 < NH) ? nds : 0) - nvm < ndw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+      }
+      // chunk boundary: publish the next patch image (one barrier)
+      if (!(ABL & 2)) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (NIMG == 2) {
+          Pb = Pbytes + ((c + 1) & 1) * PSZ;
+        } else if (c + 1 < nck) {   // single image: every wave is done reading it; rewrite in place and publish
+          store_patch(0);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+      }
+      if (!(ABL & 4)) read_a(0, 0, 0);
+    }
+
+  } else {
+    // ================================================================== 16x16x32 loop (see the note above the kernel)
+    const int n16 = lane & 15, g16 = lane >> 4;
+    int a_off[TM];   // first patch row (pixel half 0) of row tile i: pixel n16, slot g16; half 1 is the next patch row
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i] = ((wm * TM + i) * 2) * RS + n16 * ROWB + 16 * g16;
+    const char* Pb = Pbytes;
+    // weight fragments of channel block cb of column tile j: [n/16][q][hi | lo][lane] x 16 B
+    const int nblk16 = (g.N + 15) >> 4;
+    const float* wrow[TN][2];
+#pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  int a_off[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int p = (wm * TM + i) * 32 + r;
-    a_off[i] = (p / TW) * RS + (p % TW) * ROWB + 16 * h;
-  }
-  const char* Pb = Pbytes;   // image of the current chunk
-  // weight fragment rows (clamped: accumulators of rows >= N are never stored)
-  const float* wrow[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-    if constexpr (FRAGW)  // fragment-major weights: [n/32][q][t][hi|lo][lane] x 16 B, one contiguous KiB per wave load
-      wrow[j] = g.w + (long)min((n0 >> 5) + wn * TN + j, ((g.N + 31) >> 5) - 1) * (NTAP * nck) * 1024 + lane * 4;
-    else
-      wrow[j] = g.w + (long)min(n0 + (wn * TN + j) * 32 + r, g.N - 1) * g.ldw + 4 * h;
-
-  // Weight fragments live in a ring of R half-step slots (half-step = one 16-wide K sub-step of one tap). R divides
-  // the 2*NTAP half-steps of a chunk, so every slot index is a compile-time constant: no register rotation (copying
-  // w1 = w2 made the compiler wait for a load right after issuing it) and the load for half-step hs + R - 1 goes
-  // into the slot half-step hs - 1 just released. The chunk body is branch-free (the prefetches of the last chunk
-  // are clamped to valid, unused data), i.e. one scheduling region, and sched_group_barrier pins the interleave:
-  // one LDS read or global load behind every MFMA, reads for the NEXT half-step first.
-  constexpr int NH = 2 * NTAP;
-  // (the high-occupancy single-image variant keeps the ring short: its budget is 128 registers per lane)
-  constexpr int R = (NIMG == 1 && NH % 3 == 0) ? 3 : (NH % 5 == 0) ? 5 : (NH % 6 == 0) ? 6 : 4;
-  static_assert(NH % R == 0 && NH >= R, "ring size must divide the half-steps of a chunk");
-  struct HFrag { f16x8 hi[TN], lo[TN]; };
-  HFrag wr[R];
-  auto load_wh = [&](HFrag& f, int c, int hs) {
-    const int q = (hs >> 1) * nck + c;  // packed K order is [tap][channel chunk]
-    const int t = hs & 1;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      if constexpr (FRAGW) {
-        f.hi[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512);
-        f.lo[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512 + 256);
-      } else {
-        f.hi[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t);
-        f.lo[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t + 16);
-      }
-    }
-  };
-
-  fetch_patch(0);
-  if constexpr (NORM) fetch_norm(0);
-#pragma unroll
-  for (int hs = 0; hs < R - 1; ++hs) load_wh(wr[hs], 0, hs);
-  if (ABL & 1) load_wh(wr[R - 1], 0, R - 1);
-  if constexpr (NORM) {
-#pragma unroll
-    for (int k = 0; k < NP; ++k) store_row_norm(0, k, nmu, nrs);
-  } else {
-    store_patch(0);
-  }
-  __syncthreads();
-  // activation fragments: two register sets, the ds_reads of half-step hs + 1 are issued among the MFMAs of hs
-  f16x8 ah[2][TM], al[2][TM];
-  auto read_a = [&](int set, int tap, int t) {
-    const char* arow = Pb + (tap / KW) * RS + (tap % KW) * ROWB;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      ah[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t);
-      al[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t + 64);
-    }
-  };
-  auto mfma_half = [&](int set, const HFrag& w) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int cb = 0; cb < 2; ++cb)
+        wrow[j][cb] = g.w + (long)min(((n0 >> 4) + (wn * TN + j) * 2 + cb), nblk16 - 1) * (NTAP * nck) * 512 + lane * 4;
+    // ring of RT K-step slots; the chunk loop is unrolled over CU chunks so that every slot index is a compile-time constant
+    constexpr int RT = (NTAP % 3 == 0) ? 3 : 2;
+    constexpr int CU = (NTAP % RT == 0) ? 1 : RT;
+    constexpr int NS = CU * NTAP;            // K steps per iteration of the (unrolled) chunk loop
+    static_assert(NS % RT == 0, "ring size must divide the K steps of an unrolled iteration");
+    struct WFrag { f16x8 hi[TN][2], lo[TN][2]; };
+    WFrag wr[RT];
+    // K step `st` (0 .. NS-1 of the iteration that starts at chunk c0; st >= NS: the next iteration): chunk and tap
+    auto load_w = [&](WFrag& f, int c0, int st, int cb) __attribute__((always_inline)) {
+      const int cc = min(c0 + st / NTAP, nck - 1);   // clamped: the prefetches behind the last chunk fetch valid, unused data
+      const int q = (st % NTAP) * nck + cc;          // packed K order is [tap][channel chunk]
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (SWAP) {
-          if constexpr (!FAST) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[j], al[set][i], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo[j], ah[set][i], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[j], ah[set][i], acc[i][j], 0, 0, 0);
-        } else {
-          if constexpr (!FAST) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][i], w.hi[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][i], w.lo[j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][i], w.hi[j], acc[i][j], 0, 0, 0);
-        }
+        f.hi[j][cb] = *reinterpret_cast<const f16x8*>(wrow[j][cb] + (long)q * 512);
+        if constexpr (!FAST) f.lo[j][cb] = *reinterpret_cast<const f16x8*>(wrow[j][cb] + (long)q * 512 + 256);
       }
-  };
-  constexpr int NMF = (FAST ? 1 : 3) * TM * TN;   // MFMAs per half-step
-  read_a(0, 0, 0);
-  for (int c = 0; c < nck; ++c) {
-    const int cn = min(c + 1, nck - 1);   // clamped: the prefetches of the last chunk fetch valid, unused data
+    };
+    fetch_patch(0);
+    if constexpr (NORM) fetch_norm(0);
 #pragma unroll
-    for (int hs = 0; hs < NH; ++hs) {
-      // every half-step is its own scheduling region: without this fence the interleave solver moves the LDS reads
-      // of half-step hs + 1 to just before their consumers
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(ABL & 2) && hs == 0) { fetch_patch(cn); if constexpr (NORM) fetch_norm(cn); }  // lands during this chunk's taps
-      if (!(ABL & 1)) {
-        const int nhs = hs + R - 1;
-        if (nhs < NH) load_wh(wr[nhs % R], c, nhs); else load_wh(wr[nhs % R], cn, nhs - NH);
-      }
-      if (!(ABL & 4) && hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1, (hs + 1) & 1);
-      if constexpr (NORM) {   // one patch row per half-step: the conversion arithmetic spreads over NP half-steps
-        static_assert(!NORM || (NIMG == 2 && NH - 1 - NP >= 1), "normalise-on-load needs two patch images and NP < NH - 1");
-        if (hs >= NH - 1 - NP && hs <= NH - 2) store_row_norm((c + 1) & 1, hs - (NH - 1 - NP), nmu, nrs);
-      } else {
-        if (NIMG == 2 && !(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
-      }
-      mfma_half(hs & 1, wr[hs % R]);
-      // interleave: one memory instruction behind each MFMA — LDS reads first (they feed the next half-step), then
-      // the global loads, then the patch image writes
-      {
-        constexpr int nds = 2 * TM;
-        const int nvm = 2 * TN + (hs == 0 ? NP : 0);
-        const int ndw = NORM ? ((hs >= NH - 1 - NP && hs <= NH - 2) ? 2 : 0) : ((NIMG == 2 && hs == NH - 2) ? NP : 0);
+    for (int st = 0; st < RT - 1; ++st) { load_w(wr[st], 0, st, 0); load_w(wr[st], 0, st, 1); }
+    if constexpr (NORM) {
 #pragma unroll
-        for (int k = 0; k < NMF; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (hs + 1 < NH && k < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          else if (k - ((hs + 1 < NH) ? nds : 0) < nvm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          else if (k - ((hs + 1 < NH) ? nds : 0) - nvm < ndw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-      }
+      for (int k = 0; k < NP; ++k) store_row_norm(0, k, nmu, nrs);
+    } else {
+      store_patch(0);
     }
-    // chunk boundary: publish the next patch image (one barrier)
-    if (!(ABL & 2)) {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if constexpr (NIMG == 2) {
-        Pb = Pbytes + ((c + 1) & 1) * PSZ;
-      } else if (c + 1 < nck) {   // single image: every wave is done reading it; rewrite in place and publish
-        store_patch(0);
+    __syncthreads();
+    f16x8 ah[2][TM], al[2][TM];   // [pixel half][row tile]
+    auto read_a = [&](int half, int tap) __attribute__((always_inline)) {
+      const char* arow = Pb + (tap / KW + half) * RS + (tap % KW) * ROWB;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[half][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i]);
+        if constexpr (!FAST) al[half][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 64);
+      }
+    };
+    auto mfma_half = [&](int half, const WFrag& w) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            f32x4v c = acc[i][j].b[half][cb];
+            if constexpr (SWAP) {
+              if constexpr (!FAST) {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.hi[j][cb], al[half][i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.lo[j][cb], ah[half][i], c, 0, 0, 0);
+              }
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.hi[j][cb], ah[half][i], c, 0, 0, 0);
+            } else {
+              if constexpr (!FAST) {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[half][i], w.hi[j][cb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[half][i], w.lo[j][cb], c, 0, 0, 0);
+              }
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[half][i], w.hi[j][cb], c, 0, 0, 0);
+            }
+            acc[i][j].b[half][cb] = c;
+          }
+    };
+    constexpr int NMF = (FAST ? 1 : 3) * TM * TN * 2;   // MFMAs per half-step
+    constexpr int NH = 2 * NTAP;                        // half-steps per chunk
+    static_assert(!NORM || (NIMG == 2 && NH - 1 - NP >= 1), "normalise-on-load needs two patch images and NP < NH - 1");
+    static_assert(NIMG == 2, "the 16x16x32 loop keeps two patch images");
+    read_a(0, 0);
+    for (int c0 = 0; c0 < nck; c0 += CU) {
+#pragma unroll
+      for (int cu = 0; cu < CU; ++cu) {
+        const int c = c0 + cu;
+        const bool live = CU == 1 || c < nck;   // (CU > 1 and an odd chunk count: the surplus chunk multiplies nothing)
+        const int cn = min(c + 1, nck - 1);
+#pragma unroll
+        for (int hs = 0; hs < NH; ++hs) {
+          const int tap = hs >> 1, half = hs & 1;
+          const int st = cu * NTAP + tap;     // compile-time K step index inside the unrolled iteration
+          __builtin_amdgcn_sched_barrier(0);
+          if (hs == 0) { fetch_patch(cn); if constexpr (NORM) fetch_norm(cn); }   // lands during this chunk's taps
+          // weights of K step st + RT - 1: channel block `half` in this half-step, into the slot K step st - 1 released
+          load_w(wr[(st + RT - 1) % RT], c0, st + RT - 1, half);
+          if (hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1);
+          if constexpr (NORM) {
+            if (hs >= NH - 1 - NP && hs <= NH - 2) store_row_norm((c + 1) & 1, hs - (NH - 1 - NP), nmu, nrs);
+          } else {
+            if (hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c - 1
+          }
+          if (live) mfma_half(half, wr[st % RT]);
+          {
+            constexpr int nds = 2 * TM;
+            const int nvm = 2 * TN + (hs == 0 ? NP : 0);
+            const int ndw = NORM ? ((hs >= NH - 1 - NP && hs <= NH - 2) ? 2 : 0) : ((hs == NH - 2) ? NP : 0);
+#pragma unroll
+            for (int k = 0; k < NMF; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (hs + 1 < NH && k < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              else if (k - ((hs + 1 < NH) ? nds : 0) < nvm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              else if (k - ((hs + 1 < NH) ? nds : 0) - nvm < ndw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+          }
+        }
+        // chunk boundary: publish the next patch image (one barrier)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        Pb = Pbytes + ((c + 1) & 1) * PSZ;
+        read_a(0, 0);
       }
     }
-    if (!(ABL & 4)) read_a(0, 0, 0);
   }
 
-  if constexpr ((ABL & 8) != 0) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
+  if constexpr ((ABL & 8) != 0 && !M16) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
     float tot = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) tot += acc[i][j][e];
+        for (int e = 0; e < 16; ++e) tot += acc[i][j].v[e];
     if (tot == 1.2345e-30f) ep(img, 0, 0, tot);
     return;
   }
@@ -334,6 +492,22 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
       const int p = (wm * TM + i) * 32 + 8 * q + trow;
       const int oy = ty0 + p / TW, ox = tx0 + p % TW;
       return (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
+    };
+    // one 32-pixel x 32-channel accumulator tile -> the wave's slab [pixel][LDS_LD floats], scaled
+    auto slab_write = [&](const SfAcc<M16>& a) __attribute__((always_inline)) {
+      if constexpr (M16) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            *reinterpret_cast<float4*>(tb + (16 * hh + (lane & 15)) * LDS_LD + 16 * cb + 4 * (lane >> 4)) =
+                make_float4(a.b[hh][cb][0] * g.wscale, a.b[hh][cb][1] * g.wscale, a.b[hh][cb][2] * g.wscale, a.b[hh][cb][3] * g.wscale);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          *reinterpret_cast<float4*>(tb + (lane & 31) * LDS_LD + 8 * k + 4 * (lane >> 5)) =
+              make_float4(a.v[4 * k] * g.wscale, a.v[4 * k + 1] * g.wscale, a.v[4 * k + 2] * g.wscale, a.v[4 * k + 3] * g.wscale);
+      }
     };
     if constexpr (epi_flowhead<Epi>::value) {
       // ---- flow head: relu(conv1) x conv2's weights, reduced to 18 partial sums per pixel (epilogues_sf.h).
@@ -362,11 +536,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
       };
 #pragma unroll
       for (int i = 0; i < TM; ++i) {   // (unrolled: a run-time index into the accumulators would put them in scratch)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          *reinterpret_cast<float4*>(tb + r * LDS_LD + 8 * k + 4 * h) =
-              make_float4(acc[i][0][4 * k] * g.wscale, acc[i][0][4 * k + 1] * g.wscale, acc[i][0][4 * k + 2] * g.wscale,
-                          acc[i][0][4 * k + 3] * g.wscale);
+        slab_write(acc[i][0]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         float4 v[4];
@@ -428,11 +598,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
       for (int j = 0; j < TN; ++j) {
         const int nb = n0 + (wn * TN + j) * 32 + tcol;
         const float4 bj = ep.bias4(max(min(nb, g.N - 4), 0));   // this lane's 4 channels: one load per channel run
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          *reinterpret_cast<float4*>(tb + r * LDS_LD + 8 * k + 4 * h) =
-              make_float4(acc[i][j][4 * k] * g.wscale, acc[i][j][4 * k + 1] * g.wscale, acc[i][j][4 * k + 2] * g.wscale,
-                          acc[i][j][4 * k + 3] * g.wscale);
+        slab_write(acc[i][j]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         float4 v[4];
@@ -481,81 +647,97 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
     }
     return;
   }
-  // ---- pixel-major epilogue (TM x TN tiles per wave)
+  // ---- pixel-major epilogue (TM x TN tiles per wave). A lane owns NSET channel columns of a 32 x 32 tile with NPX pixels
+  // each: 32x32x16 -> one column (channel lane & 31), 16 pixels (e & 3) + 8 (e >> 2) + 4 (lane >> 5); 16x16x32 -> two columns
+  // (channel 16 cb + (lane & 15)), 8 pixels 16 half + 4 (lane >> 4) + k each.
+  constexpr int NSET = M16 ? 2 : 1, NPX = M16 ? 8 : 16;
+  auto col_of = [&](int cs) { return M16 ? 16 * cs + (lane & 15) : (lane & 31); };
+  auto pix_of = [&](int e) { return M16 ? 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); };
+  auto val_of = [&](const SfAcc<M16>& a, int cs, int e) __attribute__((always_inline)) {
+    if constexpr (M16) return a.b[e >> 2][cs][e & 3]; else return a.v[e];
+  };
   // per-column constants once per wave, before any store (a load issued after a store waits for that store too)
-  typename EpiCol<Epi>::type colj[TN];
-  float biasj[TN];
+  typename EpiCol<Epi>::type colj[TN][NSET];
+  float biasj[TN][NSET];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = min(n0 + (wn * TN + j) * 32 + r, g.N - 1);
-    biasj[j] = 0.f;
-    if constexpr (Epi::kStats) biasj[j] = ep.bias[n];
-    if constexpr (epi_bias_arg<Epi>::value) colj[j] = ep.col(n);
-  }
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int cs = 0; cs < NSET; ++cs) {
+      const int n = min(n0 + (wn * TN + j) * 32 + col_of(cs), g.N - 1);
+      biasj[j][cs] = 0.f;
+      if constexpr (Epi::kStats) biasj[j][cs] = ep.bias[n];
+      if constexpr (epi_bias_arg<Epi>::value) colj[j][cs] = ep.col(n);
+    }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int pbase = (wm * TM + i) * 32;
+    int mm[NPX];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + r;
-      const bool nok = n < g.N;
-      int mm[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int p = pbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int oy = ty0 + p / TW, ox = tx0 + p % TW;
-        mm[e] = (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
-      }
-      if constexpr (Epi::kStats) {
-        const float bias = nok ? biasj[j] : 0.f;
-        float v[16];
-        float sum = 0.f;
-        int cnt = 0;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          v[e] = acc[i][j][e] * g.wscale + bias;
-          if (mm[e] >= 0) { sum += v[e]; ++cnt; }
-        }
-        sum += __shfl_xor(sum, 32);
-        cnt += __shfl_xor(cnt, 32);
-        const float mean = sum / (float)(cnt > 0 ? cnt : 1);
-        float m2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (mm[e] >= 0) { const float d = v[e] - mean; m2 += d * d; }
-        m2 += __shfl_xor(m2, 32);
-        const int grp = tloc * (TH * TW / 32) + wm * TM + i;
-        if (h == 0 && nok) {
-          const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
-          ep.part_sum[o] = sum;
-          ep.part_m2[o] = m2;
-        }
-        if (lane == 0 && n == 0) ep.part_cnt[(long)img * ep.groups_per_img + grp] = (float)cnt;
-      }
-      if (nok) {
-        if constexpr (Epi::kPrefetch) {
-          typename Epi::Aux aux[16];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) aux[e] = ep.load(img, max(mm[e], 0), n);
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (mm[e] >= 0) ep.apply(img, mm[e], n, acc[i][j][e] * g.wscale, aux[e]);
-        } else if constexpr (epi_bias_arg<Epi>::value) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (mm[e] >= 0) ep.store_c(img, mm[e], n, acc[i][j][e] * g.wscale, colj[j]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (mm[e] >= 0) ep(img, mm[e], n, acc[i][j][e] * g.wscale);
-        }
-      }
+    for (int e = 0; e < NPX; ++e) {
+      const int p = pbase + pix_of(e);
+      const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+      mm[e] = (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
     }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int cs = 0; cs < NSET; ++cs) {
+        const int n = n0 + (wn * TN + j) * 32 + col_of(cs);
+        const bool nok = n < g.N;
+        if constexpr (Epi::kStats) {
+          // partial statistics of the tile's 32 pixels for this channel: lane-local over its NPX pixels, then across the
+          // lanes that hold the same channel (32x32x16: lane ^ 32; 16x16x32: lane ^ 16, lane ^ 32)
+          const float bias = nok ? biasj[j][cs] : 0.f;
+          float v[NPX];
+          float sum = 0.f;
+          int cnt = 0;
+#pragma unroll
+          for (int e = 0; e < NPX; ++e) {
+            v[e] = val_of(acc[i][j], cs, e) * g.wscale + bias;
+            if (mm[e] >= 0) { sum += v[e]; ++cnt; }
+          }
+          if constexpr (M16) { sum += __shfl_xor(sum, 16); cnt += __shfl_xor(cnt, 16); }
+          sum += __shfl_xor(sum, 32);
+          cnt += __shfl_xor(cnt, 32);
+          const float mean = sum / (float)(cnt > 0 ? cnt : 1);
+          float m2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < NPX; ++e)
+            if (mm[e] >= 0) { const float d = v[e] - mean; m2 += d * d; }
+          if constexpr (M16) m2 += __shfl_xor(m2, 16);
+          m2 += __shfl_xor(m2, 32);
+          const int grp = tloc * (TH * TW / 32) + wm * TM + i;
+          if ((M16 ? (lane >> 4) : (lane >> 5)) == 0 && nok) {
+            const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
+            ep.part_sum[o] = sum;
+            ep.part_m2[o] = m2;
+          }
+          if (lane == 0 && n == 0) ep.part_cnt[(long)img * ep.groups_per_img + grp] = (float)cnt;
+        }
+        if (nok) {
+          if constexpr (Epi::kPrefetch) {
+            typename Epi::Aux aux[NPX];
+#pragma unroll
+            for (int e = 0; e < NPX; ++e) aux[e] = ep.load(img, max(mm[e], 0), n);
+#pragma unroll
+            for (int e = 0; e < NPX; ++e)
+              if (mm[e] >= 0) ep.apply(img, mm[e], n, val_of(acc[i][j], cs, e) * g.wscale, aux[e]);
+          } else if constexpr (epi_bias_arg<Epi>::value) {
+#pragma unroll
+            for (int e = 0; e < NPX; ++e)
+              if (mm[e] >= 0) ep.store_c(img, mm[e], n, val_of(acc[i][j], cs, e) * g.wscale, colj[j][cs]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < NPX; ++e)
+              if (mm[e] >= 0) ep(img, mm[e], n, val_of(acc[i][j], cs, e) * g.wscale);
+          }
+        }
+      }
   }
 }
 
 template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2,
-          bool NORM = false>
+          bool NORM = false, bool M16 = false>
 inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
   constexpr int TW = 16;
   ATDN_CHECK(s.KH == KH && s.KW == KW && s.stride == 1, "kernel shape does not match the instantiation");
@@ -571,14 +753,14 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
   ATDN_CHECK((long)s.H * s.W < (1L << 20) - 1, "image too large for the packed patch descriptor");
   g.tiles_x = cdiv(g.Wo, TW); g.tiles_y = cdiv(g.Ho, TH);
   g.nimg = s.nimg; g.ntile_n = cdiv(s.N, BN);
-  g.w = FRAGW ? s.wfrag : s.w; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;
+  g.w = M16 ? s.wfrag16 : FRAGW ? s.wfrag : s.w; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;
   g.in_mean = s.in_mean; g.in_rstd = s.in_rstd;
   ATDN_CHECK(NORM == (s.in_mean != nullptr) && (!NORM || (s.in_rstd && s.C1 == 0 && s.ld0 == s.C0)),
              "normalise-on-load: one dense fp32 source with its mean / rstd");
   ATDN_CHECK(g.w != nullptr, "missing weight copy for this kernel");
   set_groups(ep, g.tiles_x * g.tiles_y * (TH * TW / 32));
   const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW, FAST, NIMG, NORM>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
+  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW, FAST, NIMG, NORM, M16>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
   ATDN_HIP(hipGetLastError());
 }
 
@@ -599,12 +781,20 @@ inline int conv_sf6_block_width_3x3(const ConvShape& s) {
   return bn;
 }
 
+// MFMA shape of the halo kernels: sf_mfma16() (conv_sf.h) picks the 16x16x32 loop (default) or the 32x32x16 one.
+template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST, bool NORM>
+inline void launch_conv_sf6_m(bool m16, const ConvShape& s, float wscale, const Epi& ep, hipStream_t st) {
+  if (m16) launch_conv_sf6<TH, BN, WM, WN, KH, KW, Epi, 0, true, FAST, 2, NORM, true>(s, wscale, ep, st);
+  else launch_conv_sf6<TH, BN, WM, WN, KH, KW, Epi, 0, true, FAST, 2, NORM, false>(s, wscale, ep, st);
+}
+
 // Picks the block shape for N output channels and launches the fragment-major-weight kernel: 8x16-pixel tiles, or
 // 12x16 for the 64- and 96-wide blocks (3 MFMA row tiles per wave: less halo, fewer tile seams; measured
 // 7-10 % faster on the encoder shapes and on N = 192) when the taller tiles pad the image no worse and still
 // cover the chip. Returns false when this path does not serve the shape (the caller falls back to the plain implicit GEMM).
 template <int KH, int KW, class Epi, bool FAST>
 inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out, int* th_out) {
+  const bool m16 = sf_mfma16() && s.wfrag16 != nullptr;
   const int Ho = conv_out(s.H, s.KH, 1, s.padH), Wo = conv_out(s.W, s.KW, 1, s.padW);
   const long tiles = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
   // block width: the one of {256, 128, 64} that pads N least (ties: the widest, it shares the patch among more
@@ -626,11 +816,11 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
       const long tiles12n = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
       const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 && tiles12n * cdiv(s.N, bn) >= 512;
       *bn_out = bn; *th_out = tall ? 12 : 8;
-      if (bn == 64 && tall) launch_conv_sf6<12, 64, 2, 2, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
-      else if (bn == 64) launch_conv_sf6<8, 64, 2, 2, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
-      else if (bn == 96 && tall) launch_conv_sf6<12, 96, 2, 3, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
-      else if (bn == 96) launch_conv_sf6<8, 96, 2, 3, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
-      else if (bn == 128) launch_conv_sf6<8, 128, 1, 4, KH, KW, Epi, 0, true, false, 2, true>(s, wscale, ep, st);
+      if (bn == 64 && tall) launch_conv_sf6_m<12, 64, 2, 2, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
+      else if (bn == 64) launch_conv_sf6_m<8, 64, 2, 2, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
+      else if (bn == 96 && tall) launch_conv_sf6_m<12, 96, 2, 3, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
+      else if (bn == 96) launch_conv_sf6_m<8, 96, 2, 3, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
+      else if (bn == 128) launch_conv_sf6_m<8, 128, 1, 4, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
       else return false;
       return true;
     } else {
@@ -638,26 +828,26 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
     }
   }
   if constexpr (KH == 3) {
-    if (bn == 32) { *bn_out = 32; launch_conv_sf6<8, 32, 4, 1, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true; }
+    if (bn == 32) { *bn_out = 32; launch_conv_sf6_m<8, 32, 4, 1, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true; }
     const long tiles12 = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
     const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 &&
                       tiles12 * cdiv(s.N, bn) >= 512;
     if (tall) {
       *bn_out = bn; *th_out = 12;
-      if (bn == 64) launch_conv_sf6<12, 64, 2, 2, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st);
-      else launch_conv_sf6<12, 96, 2, 3, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st);
+      if (bn == 64) launch_conv_sf6_m<12, 64, 2, 2, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st);
+      else launch_conv_sf6_m<12, 96, 2, 3, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st);
       return true;
     }
   }
   *bn_out = bn;
   switch (bn) {
-    case 64:  launch_conv_sf6<8, 64, 2, 2, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true;  // 4 waves of 64 px x 32 ch
-    case 128: launch_conv_sf6<8, 128, 1, 4, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true;
-    case 256: launch_conv_sf6<8, 256, 1, 8, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true;
+    case 64:  launch_conv_sf6_m<8, 64, 2, 2, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true;  // 4 waves of 64 px x 32 ch
+    case 128: launch_conv_sf6_m<8, 128, 1, 4, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true;
+    case 256: launch_conv_sf6_m<8, 256, 1, 8, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true;
     default: break;
   }
   if constexpr (KH == 3) {
-    if (bn == 96) { launch_conv_sf6<8, 96, 2, 3, KH, KW, Epi, 0, true, FAST>(s, wscale, ep, st); return true; }
+    if (bn == 96) { launch_conv_sf6_m<8, 96, 2, 3, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true; }
   }
   return false;
 }

@@ -55,6 +55,8 @@ class GmaNet {
   // feature network, split-f16 pipeline: conv2 of every residual block normalises conv1's raw output in its own
   // patch loader (conv_sf6.h NORM); ATDN_NORM_ON_LOAD=0 keeps the separate normalisation pass
   bool norm_on_load_ = false;
+  // halo-patch convolutions on v_mfma_f32_16x16x32_f16 (conv_sf6.h, M16); ATDN_CONV_M32=1 keeps the 32x32x16 loop
+  bool mfma16_ = true;
   // ATDN_STEM_LEGACY=1: the 7x7 stems on the exact-fp32 ROW-mode engine (conv_mfma.h) instead of stem_sf.hip
   bool stem_legacy_ = false;
   // split-f16 pipeline, row-major pyramid (ATDN_LOOKUP_LEGACY=1): level 1 = fmap1 x (2x2-pooled fmap2)^T, a quarter-size

@@ -36,9 +36,9 @@ namespace {
 
 // precision mode 2: the sf convolutions of this thread issue only the hi x hi MFMA while the guard lives (conv_sf.h)
 struct FastGuard {
-  bool prev;
-  explicit FastGuard(bool on) : prev(sf_fast_mode()) { sf_fast_mode() = on; }
-  ~FastGuard() { sf_fast_mode() = prev; }
+  bool prev, prev16;
+  explicit FastGuard(bool on, bool m16 = true) : prev(sf_fast_mode()), prev16(sf_mfma16()) { sf_fast_mode() = on; sf_mfma16() = m16; }
+  ~FastGuard() { sf_fast_mode() = prev; sf_mfma16() = prev16; }
 };
 
 constexpr int XLD = 384;       // GRU input x = [inp | motion(126) flow(2) | motion_global]  (update.py:130)
@@ -49,7 +49,7 @@ ConvShape conv_shape(const PackedConv& L, const float* src, int ld, long sb, int
   ConvShape s;
   s.src0 = src; s.ld0 = ld; s.sb0 = sb; s.C0 = L.C;
   s.H = H; s.W = W; s.KH = L.KH; s.KW = L.KW; s.stride = stride; s.padH = padH; s.padW = padW;
-  s.w = L.w; s.wfrag = L.wf; s.ldw = L.ldw; s.N = L.N; s.nimg = nimg;
+  s.w = L.w; s.wfrag = L.wf; s.wfrag16 = L.wf16; s.ldw = L.ldw; s.N = L.N; s.nimg = nimg;
   return s;
 }
 
@@ -118,7 +118,7 @@ void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st, int 
     else launch_init_coords(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
     ATDN_HIP(hipEventCreate(&t.start));
     ATDN_HIP(hipEventRecord(t.start, st));
-    try { if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, st); } else run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
+    try { if (precision >= 1) { FastGuard fg(precision == 2, mfma16_); run_body_sf(B, iters, st); } else run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
     timer_ = nullptr;
     ATDN_HIP(hipStreamSynchronize(st));
     hipEvent_t prev = t.start;
@@ -143,6 +143,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
   lookup_legacy_ = precision == 0 || (getenv("ATDN_LOOKUP_LEGACY") && getenv("ATDN_LOOKUP_LEGACY")[0] == '1');
   attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
+  mfma16_ = !(getenv("ATDN_CONV_M32") && getenv("ATDN_CONV_M32")[0] == '1');
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
   (void)hipGetDevice(&dev_);   // (no throw: argument errors must be reportable without a device; finalize() needs one anyway)
@@ -383,7 +384,7 @@ void GmaNet::iteration(int B, hipStream_t st) {
     g.C0 = 128; g.src1 = x_.p; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = XLD;
     conv_dispatch<MODE_TAP>(g, EpiGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128}, st);
     mark(p ? ST_GRU_ZR_V : ST_GRU_ZR, st);
-    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
+    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.wfrag16 = gru_q_[p].wf16; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_dispatch<MODE_TAP>(g, EpiGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128}, st);
     mark(p ? ST_GRU_Q_V : ST_GRU_Q, st);
   }
@@ -597,7 +598,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
     conv_sf_dispatch(g, gru_zr_[p].wscale,
                      SfGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128, pre_zr_[p].p, (long)N * 256}, st);
     mark(p ? ST_GRU_ZR_V : ST_GRU_ZR, st);
-    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
+    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.wfrag16 = gru_q_[p].wf16; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_sf_dispatch(g, gru_q_[p].wscale, SfGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128, pre_q_[p].p}, st);
     mark(p ? ST_GRU_Q_V : ST_GRU_Q, st);
   }
@@ -714,7 +715,7 @@ void GmaNet::capture(int B, int iters) {
   hipGraph_t graph = nullptr;
   ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
   try {
-    if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, cap_stream_); } else run_body(B, iters, cap_stream_);
+    if (precision >= 1) { FastGuard fg(precision == 2, mfma16_); run_body_sf(B, iters, cap_stream_); } else run_body(B, iters, cap_stream_);
   } catch (...) {
     (void)hipStreamEndCapture(cap_stream_, &graph);
     if (graph) (void)hipGraphDestroy(graph);
@@ -760,7 +761,7 @@ void GmaNet::launch_body(int B, int iters, hipStream_t st) {
     if (!graphs_.count(key)) capture(B, iters);
     ATDN_HIP(hipGraphLaunch(graphs_[key], st));
   } else {
-    if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, st); } else run_body(B, iters, st);
+    if (precision >= 1) { FastGuard fg(precision == 2, mfma16_); run_body_sf(B, iters, st); } else run_body(B, iters, st);
   }
 }
 

@@ -5,6 +5,7 @@
 namespace atdn {
 
 bool& sf_fast_mode();  // see conv_sf.h
+bool& sf_mfma16();     // see conv_sf.h
 
 struct PyramidLevels {  // correlation pyramid of ONE batch: level l is [B*N][H_l*W_l] fp32
   const float* base[4];

@@ -7,6 +7,10 @@ bool& sf_fast_mode() {
   static thread_local bool fast = false;
   return fast;
 }
+bool& sf_mfma16() {
+  static thread_local bool m16 = true;
+  return m16;
+}
 
 // ------------------------------------------------------------------ block reductions (deterministic)
 __device__ __forceinline__ float wave_sum(float v) {

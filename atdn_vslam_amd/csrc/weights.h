@@ -55,6 +55,9 @@ struct PackedConv {
   // sf packing of 3x3 / 1x5 / 5x1 kernels: a second copy in MFMA-fragment order (conv_sf6.h)
   long wf_off = -1;
   const float* wf = nullptr;
+  // ... and one in the operand order of v_mfma_f32_16x16x32_f16 (pack_fragment_major16)
+  long wf16_off = -1;
+  const float* wf16 = nullptr;
 };
 
 class WeightArena {
@@ -159,6 +162,26 @@ inline void pack_fragment_major(WeightArena& A, PackedConv& L) {
           }
 }
 
+// Fragment-major copy for the 16x16x32 loop of conv_sf6.h: [ceil(N/16)][K/32][hi, lo][lane] x 16 B. Lane (r = lane & 15,
+// g = lane >> 4) of the wave that multiplies output channels nb*16 .. nb*16+15 finds, for K chunk q, its hi operand (16-byte
+// slot g of row nb*16+r, chunk q: halves 8g .. 8g+7) at ((nb*nq + q)*2 + 0)*1024 + lane*16 bytes and its lo operand (slot
+// 4+g) 1024 bytes further: every wave load is one contiguous KiB. Rows >= N are zero.
+inline void pack_fragment_major16(WeightArena& A, PackedConv& L) {
+  const int nq = L.ldw / 32, nblk = (L.N + 15) / 16;
+  L.wf16_off = A.alloc((long)nblk * nq * 512);
+  const float* w = A.at(L.w_off);  // (alloc may have moved the arena: take the pointers after it)
+  float* f = A.at(L.wf16_off);
+  for (int nb = 0; nb < nblk; ++nb)
+    for (int q = 0; q < nq; ++q)
+      for (int hl = 0; hl < 2; ++hl)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int r = lane & 15, gq = lane >> 4, row = nb * 16 + r, slot = 4 * hl + gq;
+          float* d = f + ((((long)nb * nq + q) * 2 + hl) * 64 + lane) * 4;
+          if (row < L.N) std::memcpy(d, w + (long)row * L.ldw + q * 32 + slot * 4, 16);
+          else std::memset(d, 0, 16);
+        }
+}
+
 // Same as pack_conv(TAP) but in split-f16 form (sf.h): every 32-float K-chunk of a row becomes [32 hi | 32 lo]
 // halves; all weights of the layer are pre-multiplied by 2^p so that max|w| lands in [1,2) and L.wscale = 2^-p.
 inline PackedConv pack_conv_sf(WeightArena& A, const StateDict& sd, const std::vector<std::string>& names,
@@ -186,7 +209,10 @@ inline PackedConv pack_conv_sf(WeightArena& A, const StateDict& sd, const std::v
         hrow[q * 64 + 32 + j] = lo;
       }
   }
-  if ((L.KH == 3 && L.KW == 3) || (L.KH == 1 && L.KW == 5) || (L.KH == 5 && L.KW == 1)) pack_fragment_major(A, L);
+  if ((L.KH == 3 && L.KW == 3) || (L.KH == 1 && L.KW == 5) || (L.KH == 5 && L.KW == 1)) {
+    pack_fragment_major(A, L);
+    pack_fragment_major16(A, L);
+  }
   return L;
 }
 
@@ -259,6 +285,7 @@ inline void resolve(const WeightArena& A, PackedConv& L) {
   L.w = A.dev(L.w_off);
   L.b = A.dev(L.b_off);
   L.wf = L.wf_off >= 0 ? A.dev(L.wf_off) : nullptr;
+  L.wf16 = L.wf16_off >= 0 ? A.dev(L.wf16_off) : nullptr;
 }
 
 }  // namespace atdn

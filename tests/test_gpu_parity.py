@@ -115,12 +115,18 @@ HALO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mfma", [16, 32])
 @pytest.mark.parametrize("sf_out", [0, 1])
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_split_f16_halo_kernels_match_fp64(case, sf_out, monkeypatch):
+def test_split_f16_halo_kernels_match_fp64(case, sf_out, mfma, monkeypatch):
     """Generation-6 halo kernels, both epilogue orientations: fp32 output (EpiBias) and split-f16 output through
-    the channel-vector SfBias store (decoded again by from_sf), against an fp64 convolution."""
+    the channel-vector SfBias store (decoded again by from_sf), against an fp64 convolution; on both MFMA shapes (round 3:
+    v_mfma_f32_16x16x32_f16 is the default loop, ATDN_CONV_M32=1 the 32x32x16 loop it replaced)."""
     cin, cout, kh, kw, ph, pw, H, W, nimg = case
+    if mfma == 32:
+        monkeypatch.setenv("ATDN_CONV_M32", "1")
+    else:
+        monkeypatch.delenv("ATDN_CONV_M32", raising=False)
     if sf_out:
         monkeypatch.setenv("ATDN_SF_CONV_EPILOGUE", "sf")
     else:

@@ -64,7 +64,19 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
     us_out[5] = ATDN_MB_SF6(256, 1, 8, 13);   // ... and no LDS reads in the loop
     us_out[6] = ATDN_MB_SF6(256, 1, 8, 15);   // ... and no patch refresh: the bare MFMA stream of this tiling
 #undef ATDN_MB_SF6
-    for (int i = 7; i < 12; ++i) us_out[i] = 0.f;   // (generations 2-4 were removed in round 2)
+    // round 3: the same blocks on the 16x16x32 MFMA loop (weights: the same random bytes, order irrelevant for timing)
+    s.wfrag16 = wf;
+#define ATDN_MB_SF6M(BN, WM, WN)                                                                                      \
+    time_it([&]() {                                                                                                  \
+      if (KH == 3 && KW == 3) launch_conv_sf6<8, BN, WM, WN, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st);    \
+      else if (KH == 1 && KW == 5) launch_conv_sf6<8, BN, WM, WN, 1, 5, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); \
+      else launch_conv_sf6<8, BN, WM, WN, 5, 1, E, 0, true, false, 2, false, true>(s, 1.f, ep, st);                       \
+    })
+    us_out[7] = ATDN_MB_SF6M(256, 1, 8);
+    us_out[8] = ATDN_MB_SF6M(128, 1, 4);
+    us_out[9] = ATDN_MB_SF6M(64, 2, 2);
+#undef ATDN_MB_SF6M
+    for (int i = 10; i < 12; ++i) us_out[i] = 0.f;
     (void)hipFree(x); (void)hipFree(w); (void)hipFree(wf); (void)hipFree(y); (void)hipFree(bias);
     return 0;
   } catch (const std::exception& e) {
@@ -74,7 +86,8 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
 }
 
 // Thin-layer variant of the ladder (encoder shapes: few chunks per tile, so prologue/epilogue weigh more): the
-// 64-channel 2x2-wave block at tile heights 8 and 12, its ablations, and the single-patch-image variants. us_out[10].
+// 64-channel 2x2-wave block at tile heights 8 and 12, its ablations, the single-patch-image variants, and (entries 10, 11)
+// the 16x16x32 loop at tile heights 8 and 12. us_out[12].
 extern "C" int atdn_microbench_conv_thin(int nimg, int H, int W, int C, int N, int reps, float* us_out) {
   try {
     hipStream_t st = nullptr;
@@ -110,6 +123,9 @@ extern "C" int atdn_microbench_conv_thin(int nimg, int H, int W, int C, int N, i
       (void)hipEventDestroy(a); (void)hipEventDestroy(b);
       return ms * 1000.f / reps;
     };
+    s.wfrag16 = wf;
+    us_out[10] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
+    us_out[11] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
     us_out[0] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
     us_out[1] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
     us_out[2] = time_it([&]() { launch_conv_sf6<16, 64, 4, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });

@@ -12,7 +12,7 @@ L = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libatdn_microbench.so")
 out = (C.c_float * 12)()
 names = ["gen6 8x16 px x 256 ch (8 waves)", "gen6 8x16 px x 128 ch (4 waves)", "gen6 8x16 px x 64 ch (2x2 waves)",
          "  x256 minus epilogue", "  ... minus weight loads", "  ... minus LDS reads", "  ... minus patch refresh (bare MFMA)",
-         ]
+         "16x16x32 loop: 8x16 px x 256 ch (8 waves)", "16x16x32 loop: 8x16 px x 128 ch (4 waves)", "16x16x32 loop: 8x16 px x 64 ch (2x2 waves)"]
 for (nimg, H, W, Cc, N, KH, KW) in ((8, 47, 154, 384, 256, 1, 5), (8, 47, 154, 256, 192, 3, 3), (8, 47, 154, 128, 256, 3, 3)):
     torch.cuda.synchronize()
     rc = L.atdn_microbench_conv(nimg, H, W, Cc, N, KH, KW, 50, out)

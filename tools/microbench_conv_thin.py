@@ -8,10 +8,11 @@ import torch  # noqa: F401
 from atdn_vslam_amd import _lib
 _lib.lib()
 L = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libatdn_microbench.so"))
-out = (C.c_float * 10)()
+out = (C.c_float * 12)()
 names = ["8x16 px x 64 ch (2x2 waves)", "12x16 px x 64 ch (2x2 waves)", "16x16 px x 64 ch (4x2 waves)", "  8x16 minus epilogue",
          "  ... minus weight loads", "  ... minus LDS reads", "  ... minus patch refresh (bare MFMA)", "  12x16 minus epilogue",
-         "8x16 px x 64 ch, one patch image", "12x16 px x 64 ch, one patch image"]
+         "8x16 px x 64 ch, one patch image", "12x16 px x 64 ch, one patch image",
+         "16x16x32 loop: 8x16 px x 64 ch", "16x16x32 loop: 12x16 px x 64 ch"]
 for (nimg, H, W, Cc, N) in ((8, 188, 616, 64, 64), (8, 94, 308, 96, 96), (8, 47, 154, 128, 128), (8, 47, 154, 256, 192)):
     torch.cuda.synchronize()
     rc = L.atdn_microbench_conv_thin(nimg, H, W, Cc, N, 30, out)
