@@ -43,32 +43,25 @@ constexpr int DEPTH = 4;          // (pixel, level) units in flight per wave
 constexpr int NWAVE = 8;          // waves per block: level = wave & 3, pixels (wave >> 2) * 16 .. + 15
 constexpr int UPW = TP * 4 / NWAVE;   // units (pixels of its level) per wave
 
-struct Unit { float xc, yc; bool sane; int wx0, wy0, bx0, by0; };
+// One (pixel, level) unit. Everything here is wave-uniform: the integers are forced into scalar registers
+// (v_readfirstlane), so the brick range, the grid origin and the buffer descriptor of the unit are computed on the scalar
+// unit and cost the vector pipe nothing (SQ counters of the round-3 kernel: the sampling phase is VALU-issue bound,
+// ~180 vector instructions per unit; this and the chain table below took it to ~95).
+struct Unit { float xc, yc; int sane; int wx0, wy0, bx0, by0; };
 
 __device__ __forceinline__ Unit unit_origin(float cx, float cy, float inv) {
   Unit u;
   u.xc = cx * inv; u.yc = cy * inv;
-  u.sane = (fabsf(u.xc) < 1.0e6f) && (fabsf(u.yc) < 1.0e6f);   // also rejects NaN
-  u.wx0 = u.sane ? (int)floorf(u.xc) - 5 : -(1 << 24);
-  u.wy0 = u.sane ? (int)floorf(u.yc) - 5 : -(1 << 24);
+  const bool sane = (fabsf(u.xc) < 1.0e6f) && (fabsf(u.yc) < 1.0e6f);   // also rejects NaN
+  u.sane = __builtin_amdgcn_readfirstlane((int)sane);
+  const int fx = __builtin_amdgcn_readfirstlane((int)floorf(u.xc)), fy = __builtin_amdgcn_readfirstlane((int)floorf(u.yc));
+  u.wx0 = u.sane ? fx - 5 : -(1 << 24);
+  u.wy0 = u.sane ? fy - 5 : -(1 << 24);
   u.bx0 = u.wx0 >> 3; u.by0 = u.wy0 >> 2;                       // arithmetic shifts: floor for negative origins
   return u;
 }
 
-// lane -> brick bi = 8k + (lane >> 3) of the 3 x 4 block of bricks (bi < 12), 16-byte part lane & 7 of its line
-__device__ __forceinline__ void fetch_bricks(const float* __restrict__ map, int BWl, int BHl, const Unit& u, int lane,
-                                             v4f* v, bool* ok) {
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int bi = 8 * k + (lane >> 3);
-    const int byi = bi / 3, bxi = bi - 3 * byi;
-    const int bx = u.bx0 + bxi, by = u.by0 + byi;
-    // only the bricks the 12 x 12 window really touches: 2-3 columns, 3-4 rows of bricks
-    const int nbx = (((u.wx0 & 7) + 11) >> 3) + 1, nby = (((u.wy0 & 3) + 11) >> 2) + 1;
-    ok[k] = (bxi < nbx) & (byi < nby) & ((unsigned)bx < (unsigned)BWl) & ((unsigned)by < (unsigned)BHl);
-    v[k] = *reinterpret_cast<const v4f*>(map + (ok[k] ? ((long)by * BWl + bx) * 32 : 0) + (lane & 7) * 4);
-  }
-}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // FUSED: multiply the sampled tile with convc1 and store relu(. + bias) as sf rows [pixel][256];
 // !FUSED: store the sampled tile itself as sf rows [pixel][352] (debug reads, the unfused comparison path)
@@ -80,7 +73,10 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
   __shared__ __attribute__((aligned(16))) char atile[TP * APITCH];
   __shared__ __attribute__((aligned(16))) float grid[NWAVE][GH * GW];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lvl = wave & 3, pbase = (wave >> 2) * UPW;
+  __shared__ __attribute__((aligned(16))) float2 ctab[NWAVE][2][64];   // per wave, two units: (weight, grid index) of the 18 chains
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (tells the compiler what the hardware guarantees: wave-uniform)
+  const int lvl = wave & 3, pbase = (wave >> 2) * UPW;
   const long p0 = (long)blockIdx.x * TP;
   const int np = (int)min((long)TP, npix - p0);
 
@@ -105,89 +101,138 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
 
   Unit un[DEPTH];
   v4f bv[DEPTH][2];
-  bool bok[DEPTH][2];
+  // lane -> brick bi = 8k + (lane >> 3) of the 3 x 4 block of bricks (bi < 12), 16-byte part lane & 7 of its line
+  int bxi[2], byi[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { const int bi = 8 * k + (lane >> 3); byi[k] = bi / 3; bxi[k] = bi - 3 * byi[k]; }
   auto issue = [&](int pi, int slot) __attribute__((always_inline)) {
     const int pp = min(pbase + pi, np - 1);
     // (pp is wave-uniform: v_readlane, not a ds_bpermute whose wait would also sit behind the sampling phase's LDS traffic)
     const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cmine.x), pp));
     const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cmine.y), pp));
     un[slot] = unit_origin(cx, cy, inv);
-    fetch_bricks(lvl_base + (p0 + pp) * NBl, BWl, BHl, un[slot], lane, bv[slot], bok[slot]);
+    const Unit& u = un[slot];
+    // only the bricks the 12 x 12 window really touches: 2-3 columns, 3-4 rows of bricks (scalar arithmetic)
+    const int nbx = (((u.wx0 & 7) + 11) >> 3) + 1, nby = (((u.wy0 & 3) + 11) >> 2) + 1;
+    // the pixel's map of this level as a buffer: a lane whose brick is outside the window or outside the map gets an offset
+    // past the end, and the load returns zeros by itself (they ARE grid_sample's zero padding): no select on the data
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lvl_base + (p0 + pp) * NBl), 0,
+                                                                           (int)NBl * 4, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int bx = u.bx0 + bxi[k], by = u.by0 + byi[k];
+      const bool ok = (bxi[k] < nbx) & (byi[k] < nby) & ((unsigned)bx < (unsigned)BWl) & ((unsigned)by < (unsigned)BHl);
+      const int off = ok ? (by * BWl + bx) * 128 + (lane & 7) * 16 : 0x7FFFFFF0;
+      bv[slot][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
   };
 #pragma unroll
   for (int d = 0; d < DEPTH - 1; ++d) issue(d, d);
   float* gw = grid[wave];
   bool clamped = false;   // saturation of the sf format, reported once after the loop (sf.h)
-  // per-lane constants of the unit body: grid slot of this lane's two brick parts, its two samples (i, j) and where
-  // they go in a pixel's row of the A tile (the 17 lanes past the 81st sample write to the dump rows of the grid)
-  int gofs[2], si[2], sj[2], dofs[2];
+  // Round 3: the unit body has no lane permutes (eight ds_bpermute per unit before) and never drains the LDS queue (twice per
+  // unit before): it relies on what the hardware guarantees — the LDS instructions of ONE wave execute in issue order, so a
+  // read issued after a write of the same wave sees it, and the next unit's grid writes cannot overtake this unit's reads.
+  // The 9 + 9 coordinate chains of a unit (x offsets -4..4, y offsets -4..4; the reference's arithmetic, corr.py:43-49 and
+  // utils.py:63-70) are evaluated ONCE, by lanes 0-17, one unit ahead, and left in a 64-entry table of the wave; a sample
+  // lane picks up the (weight, grid index) pairs of its two samples with four ds_read_b64 — LDS instructions, while the
+  // vector pipe, which bounds this phase, does the arithmetic of the current unit.
+  // per-lane constants: grid slot of this lane's two brick parts; its two samples (i, j), their table entries and where they
+  // go in a pixel's row of the A tile (the 47 lanes past the 81st sample compute sample (8, 8) again into the dump rows)
+  int gofs[2], dofs[2], ex[2], ey[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int bi = 8 * k + (lane >> 3);   // bricks 12..15 do not exist: their lanes write zeros to rows 16..23
-    const int byi = bi / 3, bxi = bi - 3 * byi, part = lane & 7;
-    gofs[k] = (byi * 4 + (part >> 1)) * GW + bxi * 8 + (part & 1) * 4;
+    const int part = lane & 7;   // bricks 12..15 do not exist: their lanes load zeros and write them to rows 16..23
+    gofs[k] = (byi[k] * 4 + (part >> 1)) * GW + bxi[k] * 8 + (part & 1) * 4;
     // sample (i, j) of this lane: pass 0 = the 8 x 8 block i, j < 8 (i = lane & 7: every 32-lane half reads 8 columns x 4
-    // rows); pass 1 = column i = 8 (lanes 0-8) and row j = 8 (lanes 9-16); lanes 17-63 of pass 1 write to the dump
-    const int i9 = k == 0 ? (lane & 7) : (lane < 9 ? 8 : min(lane - 9, 7));
+    // rows); pass 1 = column i = 8 (lanes 0-8) and row j = 8 (lanes 9-16)
+    const int i9 = k == 0 ? (lane & 7) : (lane < 9 ? 8 : (lane < 17 ? lane - 9 : 8));
     const int j9 = k == 0 ? (lane >> 3) : (lane < 9 ? lane : 8);
-    const int kk = i9 * 9 + j9;
-    si[k] = i9; sj[k] = 9 + j9;
-    const int c = lvl * 81 + kk;
+    ex[k] = i9; ey[k] = 9 + j9;
+    const int c = lvl * 81 + i9 * 9 + j9;
     dofs[k] = (c >> 5) * 128 + (c & 31) * 2;
   }
   char* const dump = reinterpret_cast<char*>(gw + 22 * GW) + (lane & 15) * 2;
-  static_assert(UPW % DEPTH == 0, "units per wave must be a multiple of the prefetch depth");
+  // chain constants of THIS lane's table entry: lanes 0-8 x offset lane - 4, lanes 9-17 y offset lane - 13 (the rest: unused entries)
+  const bool isx = lane < 9;
+  const float cfd = (float)((isx ? lane : min(lane - 9, 8)) - 4);
+  const float csz = isx ? wm1 : hm1, crs = 1.0f / csz, chs = csz / 2.f;   // (IEEE division, once per wave)
+  float2* const tab = ctab[wave][0];
+  // pos = c + d; g = 2 pos / (S - 1) - 1; u = (g + 1) * ((S - 1) / 2); weight = u - floor(u);
+  // grid index = clamp(floor(u) - window origin, 0, 10) + origin in the grid. The division is a multiplication by the correctly
+  // rounded reciprocal plus one FMA correction (Markstein): the correctly rounded quotient, the same bits as the division.
+  auto chain_to_table = [&](const Unit& u, int buf) __attribute__((always_inline)) {
+#pragma clang fp contract(off)   // the same roundings in every unrolled copy (results must not depend on a pixel's slot)
+    const float c0 = isx ? u.xc : u.yc;
+    const int org = isx ? u.wx0 : u.wy0, gorg = isx ? u.wx0 - 8 * u.bx0 : u.wy0 - 4 * u.by0;
+    const float t = 2.f * (c0 + cfd);
+    float q = t * crs;
+    q = __builtin_fmaf(__builtin_fmaf(-q, csz, t), crs, q);          // = t / csz, correctly rounded
+    const float uu = ((q - 1.f) + 1.f) * chs;
+    const float fl = floorf(uu);
+    // (a unit that is not sane has its origin at -2^24: the clamp alone keeps the index inside the grid)
+    const int idx = min(max((int)fl - org, 0), 10) + gorg;
+    tab[buf * 64 + lane] = make_float2(uu - fl, __int_as_float(idx));
+  };
+  struct Taps { float ww[2], nn[2]; int off[2]; };   // per pass: x weight, y weight, grid offset (floats) of the top-left tap
+  auto read_table = [&](int buf, Taps& tp) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float2 x = tab[buf * 64 + ex[t]], y = tab[buf * 64 + ey[t]];
+      tp.ww[t] = x.x; tp.nn[t] = y.x;
+      tp.off[t] = __float_as_int(y.y) * GW + __float_as_int(x.y);
+    }
+  };
+  static_assert(UPW % DEPTH == 0 && DEPTH % 2 == 0, "units per wave: a multiple of the (even) prefetch depth");
+  Taps tcur, tnext;
+  chain_to_table(un[0], 0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();   // (compiler only: no instruction)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  read_table(0, tcur);
   // the unit loop is unrolled by DEPTH so that the register slots are compile-time constants
   for (int pi0 = 0; pi0 < UPW; pi0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int pi = pi0 + d;
-      {
-        issue(pi + DEPTH - 1, (d + DEPTH - 1) % DEPTH);
-        const Unit u = un[d];
-        // window bricks -> grid (the previous unit's reads are complete: LDS operations of one wave execute in order)
+      issue(pi + DEPTH - 1, (d + DEPTH - 1) % DEPTH);
+      const Unit u = un[d];
+      // window bricks -> grid. No wait: these writes come after the previous unit's sample reads and before this unit's
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const bool ok = bok[d][k];
-          const v4f val = {ok ? bv[d][k].x : 0.f, ok ? bv[d][k].y : 0.f, ok ? bv[d][k].z : 0.f, ok ? bv[d][k].w : 0.f};
-          *reinterpret_cast<v4f*>(gw + gofs[k]) = val;
-        }
-        // lanes 0-8 / 9-17 evaluate the 9 x / 9 y coordinate chains (with the reference's divisions) once; every
-        // sample lane then takes its two weights and two grid indices from them by lane permutation
-        float mywgt = 0.f;
-        int myidx = 0;
-        {
-          const bool isx = lane < 9;
-          const int dd = isx ? lane : lane - 9;
-          const float c0 = isx ? u.xc : u.yc, sz1 = isx ? wm1 : hm1;
-          const float pos = c0 + (float)(dd - 4);
-          const float gg = 2.f * pos / sz1 - 1.f;
-          const float uu = (gg + 1.f) * (sz1 / 2.f);
-          const float fl = floorf(uu);
-          mywgt = uu - fl;
-          const int org = isx ? u.wx0 : u.wy0, gorg = isx ? u.wx0 - 8 * u.bx0 : u.wy0 - 4 * u.by0;
-          myidx = u.sane ? min(max((int)fl - org, 0), 10) + gorg : 0;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's grid writes
-        __builtin_amdgcn_wave_barrier();
-        char* arow = atile + (pbase + pi) * APITCH;
+      for (int k = 0; k < 2; ++k) *reinterpret_cast<v4f*>(gw + gofs[k]) = bv[d][k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float q00[2], q01[2], q10[2], q11[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const float ww = __shfl(mywgt, si[t]), nn = __shfl(mywgt, sj[t]);
-          const int ix = __shfl(myidx, si[t]), iy = __shfl(myidx, sj[t]);
-          const float ee = 1.f - ww, ss = 1.f - nn;
-          const float* q = gw + iy * GW + ix;
-          float v = ((q[0] * (ee * ss) + q[1] * (ww * ss)) + q[GW] * (ee * nn)) + q[GW + 1] * (ww * nn);
-          v = u.sane ? v : 0.f;
-          const SfPair sp = sf_split_flag(v, clamped);
-          // (no branch around the store: lanes past the 81st sample write to the dump rows)
-          _Float16* dst = reinterpret_cast<_Float16*>((t == 0 || lane < 17) ? arow + dofs[t] : dump);
-          dst[0] = sp.hi;
-          dst[32] = sp.lo;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();   // all reads of the grid done before the next unit overwrites it
+      for (int t = 0; t < 2; ++t) {
+        const float* q = gw + tcur.off[t];
+        q00[t] = q[0]; q01[t] = q[1]; q10[t] = q[GW]; q11[t] = q[GW + 1];
       }
+      // the next unit's chains -> the other half of the table, and this lane's entries of it back (its coordinates arrived
+      // DEPTH - 2 units ago); both behind the sample reads in the LDS queue
+      chain_to_table(un[(d + 1) % DEPTH], (d + 1) & 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      read_table((d + 1) & 1, tnext);
+      char* arow = atile + (pbase + pi) * APITCH;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // explicit FMAs: left to itself the compiler fused these products differently in different copies of the unrolled
+        // loop, and a pixel's samples depended on its position in the block (the batch-invariance test caught it)
+#pragma clang fp contract(off)
+        const float ww = tcur.ww[t], nn = tcur.nn[t];
+        const float ee = 1.f - ww, ss = 1.f - nn;
+        float v = __builtin_fmaf(q11[t], ww * nn, __builtin_fmaf(q10[t], ee * nn, __builtin_fmaf(q01[t], ww * ss, q00[t] * (ee * ss))));
+        v = u.sane ? v : 0.f;
+        const SfPair sp = sf_split_flag(v, clamped);
+        // (no branch around the store: lanes past the 81st sample write to the dump rows)
+        _Float16* dst = reinterpret_cast<_Float16*>((t == 0 || lane < 17) ? arow + dofs[t] : dump);
+        dst[0] = sp.hi;
+        dst[32] = sp.lo;
+      }
+      tcur = tnext;
     }
   }
   sf_report(clamped);
