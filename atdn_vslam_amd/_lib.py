@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libatdn_hip.so")
+# (ATDN_LIB_PATH: another build of the same library, for A/B timing of two builds inside one GPU job; diagnostics only)
+LIB_PATH = os.environ.get("ATDN_LIB_PATH") or os.path.join(_HERE, "libatdn_hip.so")
 
 _f32p = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)

@@ -75,6 +75,17 @@ __device__ __forceinline__ float4 keep_if(bool ok, float4 v) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate functions of the split-f16 ConvGRU epilogues: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the library expf / tanhf
+// and an IEEE division (~20 and ~35 vector instructions per value: 768 values per pixel and iteration, in an epilogue that no
+// MFMA overlaps). sigmoid: relative error <= ~3e-7. tanh = sign(x) (1 - 2 / (1 + e^(2|x|))): ABSOLUTE error <= ~1.5e-7 (near
+// zero the subtraction cancels; the value enters h' = (1 - z) h + z q, where only the absolute error counts).
+__device__ __forceinline__ float sigmoid_fast_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ float tanh_fast_(float x) {
+  const float t = __builtin_amdgcn_exp2f(fabsf(x) * 2.8853900817779268f);
+  return copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + t), x);
+}
 __device__ __forceinline__ float mishf_(float x) {
   const float sp = (x > 20.0f) ? x : log1pf(expf(x));
   return x * tanhf(sp);

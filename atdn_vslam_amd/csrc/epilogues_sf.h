@@ -127,7 +127,7 @@ struct SfGruZR {
     return {sf_load(h, (long)img * ob + (long)m * 128, n & 127), pre[(long)img * pb + (long)m * 256 + n]};
   }
   __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
-    const float v = sigmoidf_((a + x.p) + bias[n]);
+    const float v = sigmoid_fast_((a + x.p) + bias[n]);
     const long o = (long)img * ob + (long)m * 128;
     if (n < 128) z[o + n] = v;
     else sf_store(rh, o, n - 128, v * x.h);
@@ -142,10 +142,10 @@ struct SfGruZR {
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
   __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b) const {
     float4 v;
-    v.x = sigmoidf_((a.x + x.p.x) + b.x);
-    v.y = sigmoidf_((a.y + x.p.y) + b.y);
-    v.z = sigmoidf_((a.z + x.p.z) + b.z);
-    v.w = sigmoidf_((a.w + x.p.w) + b.w);
+    v.x = sigmoid_fast_((a.x + x.p.x) + b.x);
+    v.y = sigmoid_fast_((a.y + x.p.y) + b.y);
+    v.z = sigmoid_fast_((a.z + x.p.z) + b.z);
+    v.w = sigmoid_fast_((a.w + x.p.w) + b.w);
     const long o = (long)img * ob + (long)m * 128;
     if (n < 128) *reinterpret_cast<float4*>(z + o + n) = v;
     else sf_store4(rh, o, n - 128, make_float4(v.x * x.h.x, v.y * x.h.y, v.z * x.h.z, v.w * x.h.w));
@@ -167,7 +167,7 @@ struct SfGruQ {
     return {sf_load(h, o, n), z[o + n], pre[o + n]};
   }
   __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
-    const float q = tanhf((a + x.p) + bias[n]);
+    const float q = tanh_fast_((a + x.p) + bias[n]);
     sf_store(hout, (long)img * ob + (long)m * 128, n, (1.f - x.z) * x.h + x.z * q);
   }
   static constexpr bool kVec4 = true;
@@ -180,10 +180,10 @@ struct SfGruQ {
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
   __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b) const {
     float4 o;
-    o.x = (1.f - x.z.x) * x.h.x + x.z.x * tanhf((a.x + x.p.x) + b.x);
-    o.y = (1.f - x.z.y) * x.h.y + x.z.y * tanhf((a.y + x.p.y) + b.y);
-    o.z = (1.f - x.z.z) * x.h.z + x.z.z * tanhf((a.z + x.p.z) + b.z);
-    o.w = (1.f - x.z.w) * x.h.w + x.z.w * tanhf((a.w + x.p.w) + b.w);
+    o.x = (1.f - x.z.x) * x.h.x + x.z.x * tanh_fast_((a.x + x.p.x) + b.x);
+    o.y = (1.f - x.z.y) * x.h.y + x.z.y * tanh_fast_((a.y + x.p.y) + b.y);
+    o.z = (1.f - x.z.z) * x.h.z + x.z.z * tanh_fast_((a.z + x.p.z) + b.z);
+    o.w = (1.f - x.z.w) * x.h.w + x.z.w * tanh_fast_((a.w + x.p.w) + b.w);
     sf_store4(hout, (long)img * ob + (long)m * 128, n, o);
   }
 };
