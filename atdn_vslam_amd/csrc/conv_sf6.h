@@ -810,6 +810,10 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   }
   // small grids: narrower blocks (more of them) until the chip is covered
   while (bn > 64 && bn != 96 && tiles * cdiv(s.N, bn) < 300) bn /= 2;
+  // ConvGRU convolutions (1x5 / 5x1): 128-wide blocks even for N = 256. Their epilogue is heavy (gate operands, sigmoids,
+  // two stores per value: ~20 % of a block's time) and no MFMA overlaps it inside a block; three 4-wave blocks fit a CU
+  // where one 8-wave block does, so one block's epilogue runs under the others' main loops (z|r, 16 pairs: 295 -> 286 us).
+  if constexpr (KH != 3) bn = std::min(bn, 128);
   *th_out = 8;
   if (s.in_mean) {   // normalise-on-load: statistics convs of the feature network (3x3, 64 / 96 / 128 channels)
     if constexpr (Epi::kStats && KH == 3 && !FAST) {
