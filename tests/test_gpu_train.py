@@ -95,3 +95,45 @@ def test_gradient_buffer_all_reduces_through_rccl(golden_dir):
             assert torch.equal(tr.parameter(k), ref.parameter(k)), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_training_iteration_at_the_baseline_shape_matches_the_oracle():
+    """BASELINE configs[3]: batch 24 x sequence 6 at 376x1232 (the golden fixture is B = 2, T = 3; this shape only ran in
+    tools/bench_train.py before). One iteration on the HIP path against the CPU oracle (torch autograd on the same
+    restatement that the golden vectors pin): loss, every prediction, the gradient norm of every parameter, and the
+    weights after the AdamW step."""
+    from oracle import clvo_train_ref as ref
+    B, T = 24, 6
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sd = syn.to_torch(syn.make_clvo_state(seed=3))
+    flows = torch.from_numpy(syn.make_flow(B * T, 376, 1232, seed=77)).view(B, T, 2, 376, 1232)
+    r = np.random.RandomState(5)
+    true_rot = torch.from_numpy(r.normal(0, 0.01, (B, T, 3)).astype(np.float32))
+    true_tr = torch.from_numpy(r.normal(0, 0.5, (B, T, 3)).astype(np.float32))
+    hp = dict(lr=1e-3, weight_decay=1e-3, eps=1e-8, total_steps=100, eta_min=1e-9)
+    tr = CLVOTrainer(sd, B, T, device=DEV, **hp)
+    loss, pr, pt = tr.forward_backward(flows.to(DEV), true_rot, true_tr)
+    P, S = ref.split_state(sd)
+    ref_loss, ref_pr, ref_pt = ref.train_iteration(P, S, flows, true_rot, true_tr)
+    assert abs(loss - float(ref_loss)) < 1e-4 * max(1.0, float(ref_loss)), (loss, float(ref_loss))
+    np.testing.assert_allclose(pr.cpu().numpy(), ref_pr.numpy(), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(pt.cpu().numpy(), ref_pt.numpy(), rtol=0, atol=5e-5)
+    worst = 0.0
+    for k, p in P.items():
+        if p.grad is None:
+            continue
+        ref_n = float(p.grad.double().norm())
+        got_n = float(tr.gradient(k).flatten().double().norm())
+        rel = abs(got_n - ref_n) / (ref_n + 1e-12)
+        worst = max(worst, rel)
+        assert rel < 3e-3, (k, got_n, ref_n)
+    # one AdamW step (the oracle's single-tensor update at the trainer's learning rate)
+    lr0 = tr.current_lr()
+    tr.optimizer_step()
+    for k in ("lstm1.weight_hh", "encoder_CNN.1.conv.weight", "encoder_CNN.3.conv.1.conv.weight", "rotation_regressor.2.weight"):
+        p = P[k].detach().clone()
+        ref.adamw_step(p, P[k].grad, torch.zeros_like(p), torch.zeros_like(p), 1, lr0, hp["weight_decay"], hp["eps"])
+        got = tr.parameter(k).cpu()
+        assert float((got - p).abs().max()) <= 2e-5 * float(p.abs().max()) + 2e-6, k
+    print("24x6 iteration: loss %.6f (oracle %.6f), worst gradient-norm deviation %.2e" % (loss, float(ref_loss), worst))
