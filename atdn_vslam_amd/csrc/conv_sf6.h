@@ -817,8 +817,10 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   *th_out = 8;
   if (s.in_mean) {   // normalise-on-load: statistics convs of the feature network (3x3, 64 / 96 / 128 channels)
     if constexpr (Epi::kStats && KH == 3 && !FAST) {
-      const long tiles12n = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
-      const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 && tiles12n * cdiv(s.N, bn) >= 512;
+      // (statistics convolutions: the tile height fixes which 32 pixels form a statistics group, so it must follow from
+      // the layer's geometry alone, never from the number of images in the launch — a clip, a continued clip and single
+      // pairs then produce bit-identical InstanceNorm statistics)
+      const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103;
       *bn_out = bn; *th_out = tall ? 12 : 8;
       if (bn == 64 && tall) launch_conv_sf6_m<12, 64, 2, 2, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
       else if (bn == 64) launch_conv_sf6_m<8, 64, 2, 2, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
@@ -835,7 +837,7 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
     if (bn == 32) { *bn_out = 32; launch_conv_sf6_m<8, 32, 4, 1, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true; }
     const long tiles12 = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
     const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 &&
-                      tiles12 * cdiv(s.N, bn) >= 512;
+                      (Epi::kStats || tiles12 * cdiv(s.N, bn) >= 512);   // (statistics: geometry only, see above)
     if (tall) {
       *bn_out = bn; *th_out = 12;
       if (bn == 64) launch_conv_sf6_m<12, 64, 2, 2, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st);

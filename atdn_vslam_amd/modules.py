@@ -232,7 +232,8 @@ class RAFTGMA(_NativeModule):
         exactly as `forward(frames[:-1], frames[1:], test_mode=True)` does.
         `continued=True`: frames[0] is the frame that was frames[-1] of the previous call on this module (the next
         clip of the same sequence); its features are reused and only frames[1:] go through the feature network.
-        Same results up to rounding (the feature network sees one image less and may pick another tile shape)."""
+        Same bits as the non-continued call and as pair mode (round 3: the kernels' statistics grouping no longer depends on
+        how many images share a launch; tests/test_gpu_round3.py)."""
         _require_gpu(frames, "RAFTGMA.forward_sequence")
         if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[0] < 2:
             raise RuntimeError("expected frames [B+1,3,H,W] with B >= 1, got %s" % (tuple(frames.shape),))

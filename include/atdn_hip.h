@@ -68,7 +68,8 @@ int atdn_gma_forward_sequence(atdn_gma* h, const float* frames, int B, int iters
 /* The same for the NEXT clip of one sequence on this handle: frames[0] must be the frame that was frames[B] of the
  * previous atdn_gma_forward_sequence(_continued) call; its features are reused (device-side copy) and the feature
  * network runs on frames[1..B] only, so every frame of a long sequence passes through it exactly once. Results equal
- * the non-continued call's up to kernel-selection rounding (the feature network sees one image less). */
+ * the non-continued call's (and atdn_gma_forward's) bit for bit: no kernel's summation order depends on how many images
+ * share a launch. */
 int atdn_gma_forward_sequence_continued(atdn_gma* h, const float* frames, int B, int iters, const float* flow_init,
                                         float* flow_low, float* flow_up, void* stream);
 

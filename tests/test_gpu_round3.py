@@ -191,3 +191,24 @@ def test_mfma_16x16x32_loop_agrees_with_the_32x32x16_loop(monkeypatch):
         old = run(h, w, iters)
         assert float((new[2] - old[2]).abs().max()) < 1e-5              # feature maps (statistics + normalise-on-load convs)
         assert float((new[0] - old[0]).abs().max()) < 1e-4 and float((new[1] - old[1]).abs().max()) < 5e-4
+
+
+def test_clip_modes_are_bit_identical_to_pair_mode():
+    """VERDICT r2 ("continued clips equal pair mode only up to kernel-selection rounding"): the statistics convolutions of
+    the feature network now pick their tile height — which fixes the 32-pixel groups of the InstanceNorm partial sums — from
+    the layer's geometry alone, so a clip (B + 1 feature passes), a continued clip (B passes), pair mode (2B passes) and
+    single pairs produce the same bits: the path the benchmark times is bit-reproducible against the frame-by-frame path."""
+    gsd = syn.to_torch(syn.make_gma_state(seed=1))
+    net = RAFTGMA(max_batch=3)
+    net.load_state_dict(gsd)
+    net = net.to(DEV).eval()
+    fr = torch.from_numpy(syn.make_frames(5, 376, 1232, seed=41)).to(DEV)
+    low_p, up_p = net(fr[0:3], fr[1:4], iters=4, test_mode=True)                       # pair mode, 3 pairs
+    low_s, up_s = net.forward_sequence(fr[0:4], iters=4)                               # one clip
+    assert torch.equal(up_s, up_p) and torch.equal(low_s, low_p)
+    net.forward_sequence(fr[0:2], iters=4)                                             # clip of one pair ...
+    low_c, up_c = net.forward_sequence(fr[1:4], iters=4, continued=True)               # ... continued by a clip of two
+    assert torch.equal(up_c, up_p[1:3]) and torch.equal(low_c, low_p[1:3])
+    for b in range(3):                                                                  # single pairs
+        low_1, up_1 = net(fr[b:b + 1], fr[b + 1:b + 2], iters=4, test_mode=True)
+        assert torch.equal(up_1, up_p[b:b + 1]), b
