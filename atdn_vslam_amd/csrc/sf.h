@@ -91,8 +91,25 @@ __device__ __forceinline__ void sf_store(float* base, long off, int c, float v) 
 }
 // four consecutive channels c..c+3 (c % 4 == 0): one 8-byte access for the hi parts, one for the lo parts
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// (one saturation test for the four values — on the SUM of their magnitudes: it bounds every one of them, a NaN makes it a
+// NaN and fails the `<=`, and a false alarm only takes the slower per-value path, which counts exactly — instead of four
+// tests with a branch each; in range, the split is three conversions and a subtraction per value, no clamp)
+__device__ __forceinline__ SfPair sf_split_nocheck_(float v) {
+  SfPair p;
+  p.hi = (_Float16)v;
+  p.lo = (_Float16)(v - (float)p.hi);
+  return p;
+}
 __device__ __forceinline__ void sf_store4(float* base, long off, int c, float4 v) {
-  const SfPair a = sf_split(v.x), b = sf_split(v.y), d = sf_split(v.z), e = sf_split(v.w);
+  const float m = (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+  if (__builtin_expect(!(m <= 65504.f), 0)) {   // rare, counted: per value, as sf_split does
+    const SfPair a = sf_split(v.x), b = sf_split(v.y), d = sf_split(v.z), e = sf_split(v.w);
+    _Float16* q = sf_ptr(base, off, c);
+    *reinterpret_cast<f16x4*>(q) = f16x4{a.hi, b.hi, d.hi, e.hi};
+    *reinterpret_cast<f16x4*>(q + 32) = f16x4{a.lo, b.lo, d.lo, e.lo};
+    return;
+  }
+  const SfPair a = sf_split_nocheck_(v.x), b = sf_split_nocheck_(v.y), d = sf_split_nocheck_(v.z), e = sf_split_nocheck_(v.w);
   _Float16* q = sf_ptr(base, off, c);
   *reinterpret_cast<f16x4*>(q) = f16x4{a.hi, b.hi, d.hi, e.hi};
   *reinterpret_cast<f16x4*>(q + 32) = f16x4{a.lo, b.lo, d.lo, e.lo};
