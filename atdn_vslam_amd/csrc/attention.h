@@ -9,16 +9,17 @@ namespace atdn {
 // Geometry of the stored attention matrix of one batch.
 //   strips  RT = ceil(N / 32) 32-row strips per pair, chunks Q = ldN / 32 32-column chunks per row
 //   block (pair, strip, chunk) = 32 rows x 32 columns, strip-major: ((pair*RT + strip)*Q + chunk) * blk bytes
-//   lane (m = lane & 31, h = lane >> 5) owns row 32*strip + m and, for k-step t = 0,1, the eight columns
-//   32*chunk + 16t + 8*(i >> 2) + 4h + (i & 3), i = 0..7 — the accumulator order of the producing MFMA, so the producer
-//   stores and the consumer loads whole KiB per wave instruction with no shuffle; the V^T operand is brought into the
-//   same column order when it is written to LDS.
+//   a block holds two ROW BLOCKS rb = 0, 1 of 16 rows each; lane (n = lane & 15, g = lane >> 4) owns, in row block rb, row
+//   32*strip + 16*rb + n and the eight columns 32*chunk + 4*(g >> 1) + 16*(g & 1) + (i & 3) + 8*(i >> 2), i = 0..7 — the B
+//   operand of v_mfma_f32_16x16x32_f16 (round 3; K = 32 = the whole chunk), with the columns of a key group in the
+//   accumulator order of the producing 32x32x16 MFMA, so producer stores and consumer loads need no shuffle; the V^T
+//   operand is brought into the same column order when it is written to LDS.
 // Values are e = exp(s - rowmax~) * 2^AT_SHIFT, NOT normalised: rinv[pair][row] = 1 / sum_k e is applied by the
 // consumer. rowmax~ comes from a cheap first pass (f16 x f16 logits); softmax is shift-invariant, so any shift close to
 // the true maximum gives the same probabilities and keeps e inside the f16 range (largest element of a row ~ 2^10).
 // Element format H3, 3 bytes: hi = f16(e), residual as ONE BYTE in units of the group's ulp / 256 (group = a lane's eight
 //   values of one k-step): e = hi + (byte - 128) * 2^(E - 33), E = f16 exponent of the group's largest hi.
-//   block = [t][lane][16 B] hi, then [t][lane][8 B] residual bytes = 3072 B.
+//   block = [rb][lane][16 B] hi, then [rb][lane][8 B] residual bytes = 3072 B.
 //   H3 carries 19 significant bits of every value within 2^-8 of its group's maximum and an ABSOLUTE error below
 //   2^-20 of the group maximum everywhere — what matters for sum_k e_k v_k with fp32 accumulation (the residual of a
 //   4-byte hi | lo pair is an f16 subnormal for everything below 2^-4 of the row maximum, i.e. no better) — and moves 25 %

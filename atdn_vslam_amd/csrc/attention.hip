@@ -24,6 +24,7 @@ constexpr int ROWB = 144;   // LDS row pitch (128 B of operands + 16): 32 consec
 constexpr float LOG2E = 1.4426950408889634f;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f16x8 ld_frag(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
 __device__ __forceinline__ f16x8 ld_frag_nt(const char* p) {
@@ -212,13 +213,15 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
         const int q = 2 * j + nt;
         if (strip_ok && q < g.Q) {
           char* d = pdst + (long)q * BLK;
+          // consumer entry (attention.h): row block rb = r >> 4, lane' = (r & 15) + 16 g with key group g = 2 h + t
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             f16x8 hi;
             u32x2 bytes;
             h3_encode(v + 8 * t, hi, bytes, clamped);
-            st_frag_nt(d + t * 1024 + lane * 16, hi);
-            __builtin_nontemporal_store(bytes, reinterpret_cast<u32x2*>(d + 2048 + t * 512 + lane * 8));
+            const int lp = (r & 15) + 16 * (2 * h + t), rb = r >> 4;
+            st_frag_nt(d + rb * 1024 + lp * 16, hi);
+            __builtin_nontemporal_store(bytes, reinterpret_cast<u32x2*>(d + 2048 + rb * 512 + lp * 8));
           }
         }
       }
@@ -255,7 +258,13 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
                                                         const AttnGeom g, const float* __restrict__ vT,
                                                         const float* __restrict__ gamma, const float* __restrict__ mf,
                                                         float* __restrict__ out, const long sb, const int ld) {
-  constexpr int IMG = 128 * ROWB;      // V^T chunk: [128 channels][144 B]
+  // Round 3: the multiply runs on v_mfma_f32_16x16x32_f16 (K = 32 = one whole chunk of keys per instruction; same FLOP per
+  // cycle, but the chip holds a higher clock under this shape on random operands: §3.10 of DESIGN.md). A = V^T (16 channels
+  // per block), B = the attention fragment (16 query rows per block): lane (n = lane & 15, g = lane >> 4) holds row / column
+  // n and the eight keys of group g. 8 channel blocks x 2 row blocks x 3 products = 48 MFMAs per chunk, as many matrix-pipe
+  // cycles as the 24 MFMAs of the 32x32x16 form; the V^T image has a 160-byte row pitch (conflict-free for this lane map).
+  constexpr int VROW = 160;
+  constexpr int IMG = 128 * VROW;      // V^T chunk: [128 channels][160 B]
   constexpr int BLK = AT_BLK_BYTES;
   constexpr int D = 3;                 // attention chunks resident per wave (ring of register sets; 4 measured 2 % slower)
   __shared__ __attribute__((aligned(16))) char lds[3 * IMG];
@@ -267,23 +276,25 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   const int b = id / tiles, tile = id - b * tiles;
   const int strip = tile * 8 + wave;
   const bool strip_ok = strip < g.RT;
-  const int r = lane & 31, h = lane >> 5;
-  const int m = strip * 32 + r;
+  const int n16 = lane & 15, g16 = lane >> 4;
   const int Q = g.Q;
 
   const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * BLK;
-  f16x8 ring[D][2];
+  f16x8 ring[D][2];      // [slot][row block]
   u32x2 ringb[D][2];
   auto loadP = [&](int q, int slot) __attribute__((always_inline)) {
     const char* p = pblk + (long)min(q, Q - 1) * BLK;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      ring[slot][t] = ld_frag_nt(p + t * 1024 + lane * 16);
-      ringb[slot][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
+    for (int rb = 0; rb < 2; ++rb) {
+      ring[slot][rb] = ld_frag_nt(p + rb * 1024 + lane * 16);
+      ringb[slot][rb] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 2048 + rb * 512 + lane * 8));
     }
   };
 
-  // V^T staging (set A only: tid < 256): rows lr + 32 i, 16-byte slot ls; halves go to the bit-2/3-swapped positions
+  // V^T staging (set A only: tid < 256): rows lr + 32 i, 16-byte slot ls of the row's 128-byte [32 hi | 32 lo] chunk = two
+  // 8-byte pieces p = 2 (ls & 3), 2 (ls & 3) + 1 of four consecutive keys each. The attention fragments hold, in key group
+  // g = 2 h + t, the keys 4 h + 16 t + (i & 3) + 8 (i >> 2) (accumulator order of the producer), so piece p goes to slot
+  // 2 (p & 1) + (p >> 2), half (p >> 1) & 1 of the LDS row.
   const int lr = (tid & 255) >> 3, ls = tid & 7;
   const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
   v4f breg[2][4];
@@ -291,53 +302,56 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) breg[set][i] = *reinterpret_cast<const v4f*>(vrow + (long)(32 * i) * g.ldN + min(q, Q - 1) * 32);
   };
-  const int sp = ls & 3;
-  const int boff = lr * ROWB + 64 * (ls >> 2) + 32 * (sp >> 1) + 8 * (sp & 1);
+  const int p0 = 2 * (ls & 3), p1 = p0 + 1;
+  const int boff0 = lr * VROW + 64 * (ls >> 2) + 16 * (2 * (p0 & 1) + (p0 >> 2)) + 8 * ((p0 >> 1) & 1);
+  const int boff1 = lr * VROW + 64 * (ls >> 2) + 16 * (2 * (p1 & 1) + (p1 >> 2)) + 8 * ((p1 >> 1) & 1);
   auto stashB = [&](int image, int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      char* d = lds + image * IMG + boff + 32 * i * ROWB;
-      *reinterpret_cast<float2*>(d) = make_float2(breg[set][i].x, breg[set][i].y);
-      *reinterpret_cast<float2*>(d + 16) = make_float2(breg[set][i].z, breg[set][i].w);
+      char* d = lds + image * IMG + 32 * i * VROW;
+      *reinterpret_cast<float2*>(d + boff0) = make_float2(breg[set][i].x, breg[set][i].y);
+      *reinterpret_cast<float2*>(d + boff1) = make_float2(breg[set][i].z, breg[set][i].w);
     }
   };
 
-  f32x16 acc[4];
+  f32x4v acc[8][2];      // [channel block][row block]
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[cb][rb][e] = 0.f;
 
   // operands of the chunk about to be multiplied, all in registers
-  f16x8 vh[2][4], vl[2][4], ph[2], pl[2];
-  const int foff = r * ROWB + 16 * h;
+  f16x8 vh[8], vl[8], ph[2], pl[2];
+  const int foff = n16 * VROW + 16 * g16;
   auto read_frags = [&](int image) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const char* vp = lds + image * IMG + foff + 32 * j * ROWB + 32 * t;
-        vh[t][j] = ld_frag(vp);
-        if (!FAST) vl[t][j] = ld_frag(vp + 64);
-      }
+    for (int cb = 0; cb < 8; ++cb) {
+      const char* vp = lds + image * IMG + foff + 16 * cb * VROW;
+      vh[cb] = ld_frag(vp);
+      if (!FAST) vl[cb] = ld_frag(vp + 64);
+    }
   };
   auto take_chunk = [&](int slot) __attribute__((always_inline)) {   // attention operands of a chunk out of the ring
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      ph[t] = ring[slot][t];
-      if (!FAST) pl[t] = h3_decode_lo(ph[t], ringb[slot][t]);
+    for (int rb = 0; rb < 2; ++rb) {
+      ph[rb] = ring[slot][rb];
+      if (!FAST) pl[rb] = h3_decode_lo(ph[rb], ringb[slot][rb]);
     }
   };
   auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int rb = 0; rb < 2; ++rb) {
+        f32x4v c = acc[cb][rb];
         if (!FAST) {
-          acc[j] = mfma(vl[t][j], ph[t], acc[j]);
-          acc[j] = mfma(vh[t][j], pl[t], acc[j]);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[cb], ph[rb], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[cb], pl[rb], c, 0, 0, 0);
         }
-        acc[j] = mfma(vh[t][j], ph[t], acc[j]);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[cb], ph[rb], c, 0, 0, 0);
+        acc[cb][rb] = c;
       }
   };
 
@@ -402,20 +416,24 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
     }
   }
 
-  if (strip_ok && m < g.N) {
-    const float rv = rinv[(long)b * g.Npad + m] * gamma[0];
-    const float* mfb = mf + (long)b * sb;
-    float* ob = out + (long)b * sb;
+  // lane (n, g) holds, for query rows 32 strip + 16 rb + n, channels 16 cb + 4 g + 0..3
+  const float gam = gamma[0];
+  const float* mfb = mf + (long)b * sb;
+  float* ob = out + (long)b * sb;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+  for (int rb = 0; rb < 2; ++rb) {
+    const int m = strip * 32 + 16 * rb + n16;
+    if (strip_ok && m < g.N) {
+      const float rv = rinv[(long)b * g.Npad + m] * gam;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int c = 32 * j + 8 * jj + 4 * h;
+      for (int cb = 0; cb < 8; ++cb) {
+        const int c = 16 * cb + 4 * g16;
         const float4 x = sf_load4(mfb, (long)m * ld, c);
-        const float4 o = make_float4(x.x + rv * acc[j][4 * jj], x.y + rv * acc[j][4 * jj + 1], x.z + rv * acc[j][4 * jj + 2],
-                                     x.w + rv * acc[j][4 * jj + 3]);
+        const float4 o = make_float4(x.x + rv * acc[cb][rb][0], x.y + rv * acc[cb][rb][1], x.z + rv * acc[cb][rb][2],
+                                     x.w + rv * acc[cb][rb][3]);
         sf_store4(ob, (long)m * ld, c, o);
       }
+    }
   }
 }
 
@@ -426,18 +444,19 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict
   const int q = (int)(blk % g.Q);
   const long bs = blk / g.Q;
   const int strip = (int)(bs % g.RT), b = (int)(bs / g.RT);
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-  const int m = strip * 32 + r;
-  if (m >= g.N) return;
+  const int lane = threadIdx.x, n = lane & 15, gq = lane >> 4;
   const char* p = reinterpret_cast<const char*>(P) + blk * AT_BLK_BYTES;
-  const float rv = rinv[(long)b * g.Npad + m];
-  float* row = rows + ((long)b * g.N + m) * g.ldN + q * 32;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const f16x8 hi = ld_frag(p + t * 1024 + lane * 16);
-    const f16x8 lo = h3_decode_lo(hi, *reinterpret_cast<const u32x2*>(p + 2048 + t * 512 + lane * 8));
+  for (int rb = 0; rb < 2; ++rb) {
+    const int m = strip * 32 + 16 * rb + n;
+    if (m >= g.N) continue;
+    const float rv = rinv[(long)b * g.Npad + m];
+    float* row = rows + ((long)b * g.N + m) * g.ldN + q * 32;
+    const f16x8 hi = ld_frag(p + rb * 1024 + lane * 16);
+    const f16x8 lo = h3_decode_lo(hi, *reinterpret_cast<const u32x2*>(p + 2048 + rb * 512 + lane * 8));
+    // key group g = 2 h + t of the producer: keys 4 h + 16 t + (i & 3) + 8 (i >> 2)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) row[16 * t + 8 * (i >> 2) + 4 * h + (i & 3)] = ((float)hi[i] + (float)lo[i]) * rv;
+    for (int i = 0; i < 8; ++i) row[4 * (gq >> 1) + 16 * (gq & 1) + (i & 3) + 8 * (i >> 2)] = ((float)hi[i] + (float)lo[i]) * rv;
   }
 }
 
