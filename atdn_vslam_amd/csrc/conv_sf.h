@@ -15,15 +15,23 @@
 
 namespace atdn {
 
+bool& sf_mfma16();   // MFMA shape for the calling thread's sf kernels (documented below, next to sf_fast_mode)
+
 // PF: chunks of global loads in flight ahead of the one being multiplied. The register sets form a ring whose slot is a
 // compile-time constant (the chunk loop is unrolled PF times): rotating one register set by copying makes the compiler
 // wait (vmcnt(0)) for every outstanding load at the top of each iteration, i.e. no depth at all. PF = 3 is for operands
 // streamed once from HBM (attention x V: 16 KB of the attention matrix per block and chunk; at PF = 1 a CU has ~28 KB
 // in flight, half of what hides an HBM miss at full rate).
-template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false, int PF = 1>
+// M16 (round 3): the products run on v_mfma_f32_16x16x32_f16 (K = 32 = one chunk per instruction; the chip holds a higher
+// clock under this shape): lane (n = lane & 15, g = lane >> 4) holds row / column n of a 16-wide block and
+// the 16-byte slot g of the chunk's [32 hi] / [32 lo] halves; the LDS row pitch is 160 B (conflict-free for that lane map;
+// 144 B for the 32x32x16 map); a 32 x 32 tile is 2 x 2 blocks of four accumulator registers: lane (n, g) holds column
+// 16 cb + n and rows 16 hb + 4 g + 0..3.
+template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false, int PF = 1, bool M16 = false>
 __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const float wscale, const Epi ep) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int LDS_LD = M16 ? 40 : atdn::LDS_LD;   // floats per LDS row
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
   float* As = lds;
   float* Bs = lds + BM * LDS_LD;
@@ -101,19 +109,29 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int r = lane & 31, h = lane >> 5;
-  f32x16 acc[TM][TN];
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  // accumulators: 32x32x16 -> v[16]; 16x16x32 -> b[row block][column block] x 4
+  struct Acc32 { f32x16 v; };
+  struct Acc16 { f32x4v b[2][2]; };
+  typename std::conditional<M16, Acc16, Acc32>::type acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (M16) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][j].b[e >> 3][(e >> 2) & 1][e & 3] = 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j].v[e] = 0.f;
+      }
+    }
 
-  // byte view of the LDS image: row stride 144 B; hi halves at [0,64), lo halves at [64,128)
-  const char* a_rd = reinterpret_cast<const char*>(As + (wm * TM * 32 + r) * LDS_LD) + 16 * h;
-  const char* b_rd = reinterpret_cast<const char*>(Bs + (wn * TN * 32 + r) * LDS_LD) + 16 * h;
+  // byte view of the LDS image: hi halves at [0,64), lo halves at [64,128) of a row
   constexpr int ROWB = LDS_LD * 4;
+  const int rr = M16 ? (lane & 15) : (lane & 31), hh = M16 ? (lane >> 4) : (lane >> 5);
+  const char* a_rd = reinterpret_cast<const char*>(As + (wm * TM * 32 + rr) * LDS_LD) + 16 * hh;
+  const char* b_rd = reinterpret_cast<const char*>(Bs + (wn * TN * 32 + rr) * LDS_LD) + 16 * hh;
 
   // The chunk loop is branch-free: look-ahead fetches past the end are clamped (valid, unused data) and the trip
   // count is rounded up to a multiple of PF with the surplus chunks stored to LDS as zeros, so the waits the compiler
@@ -136,6 +154,39 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
       *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = keep_if(wok[j], rb[d][j]);
     __syncthreads();
     fetch(min(q + PF, last), d);   // into the slot just drained
+    if constexpr (M16) {
+      f16x8 ah[TM][2], al[TM][2], bh[TN][2], bl[TN][2];   // [tile][16-row block]
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          ah[i][hb] = *reinterpret_cast<const f16x8*>(a_rd + (i * 32 + 16 * hb) * ROWB);
+          if constexpr (!FAST) al[i][hb] = *reinterpret_cast<const f16x8*>(a_rd + (i * 32 + 16 * hb) * ROWB + 64);
+        }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          bh[j][cb] = *reinterpret_cast<const f16x8*>(b_rd + (j * 32 + 16 * cb) * ROWB);
+          if constexpr (!FAST) bl[j][cb] = *reinterpret_cast<const f16x8*>(b_rd + (j * 32 + 16 * cb) * ROWB + 64);
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              f32x4v c = acc[i][j].b[hb][cb];
+              if constexpr (!FAST) {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i][hb], bh[j][cb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i][hb], bl[j][cb], c, 0, 0, 0);
+              }
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i][hb], bh[j][cb], c, 0, 0, 0);
+              acc[i][j].b[hb][cb] = c;
+            }
+    } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -154,86 +205,101 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if constexpr (!FAST) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j].v, 0, 0, 0);
+            acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j].v, 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j].v, 0, 0, 0);
         }
+    }
     }
    }
   }
 
+  // Epilogue: a lane owns NSET channel columns of a 32 x 32 tile with NPX rows each (32x32x16: column lane & 31, rows
+  // (e & 3) + 8 (e >> 2) + 4 (lane >> 5); 16x16x32: columns 16 cs + (lane & 15), rows 16 (e >> 2) + 4 (lane >> 4) + (e & 3)).
+  constexpr int NSET = M16 ? 2 : 1, NPX = M16 ? 8 : 16;
+  auto col_of = [&](int cs) { return M16 ? 16 * cs + (lane & 15) : (lane & 31); };
+  auto row_of = [&](int e) { return M16 ? 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); };
+  auto val_of = [&](int i, int j, int cs, int e) __attribute__((always_inline)) {
+    if constexpr (M16) return acc[i][j].b[e >> 2][cs][e & 3]; else return acc[i][j].v[e];
+  };
   // per-column constants once per wave, before any store (a load issued after a store waits for that store too)
-  typename EpiCol<Epi>::type colj[TN];
-  float biasj[TN];
+  typename EpiCol<Epi>::type colj[TN][NSET];
+  float biasj[TN][NSET];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = min(n0 + (wn * TN + j) * 32 + r, g.N - 1);
-    biasj[j] = 0.f;
-    if constexpr (Epi::kStats) biasj[j] = ep.bias[n];
-    if constexpr (epi_bias_arg<Epi>::value) colj[j] = ep.col(n);
-  }
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int cs = 0; cs < NSET; ++cs) {
+      const int n = min(n0 + (wn * TN + j) * 32 + col_of(cs), g.N - 1);
+      biasj[j][cs] = 0.f;
+      if constexpr (Epi::kStats) biasj[j][cs] = ep.bias[n];
+      if constexpr (epi_bias_arg<Epi>::value) colj[j][cs] = ep.col(n);
+    }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int mbase = pix0 + (wm * TM + i) * 32;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + r;
-      const bool nok = n < g.N;
-      if constexpr (Epi::kStats) {
-        const float bias = nok ? biasj[j] : 0.f;
-        float v[16];
-        float sum = 0.f;
-        int cnt = 0;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-          v[e] = acc[i][j][e] * wscale + bias;
-          if (m < HoWo) { sum += v[e]; ++cnt; }
-        }
-        sum += __shfl_xor(sum, 32);
-        cnt += __shfl_xor(cnt, 32);
-        const float mean = sum / (float)(cnt > 0 ? cnt : 1);
-        float m2 = 0.f;
+      for (int cs = 0; cs < NSET; ++cs) {
+        const int n = n0 + (wn * TN + j) * 32 + col_of(cs);
+        const bool nok = n < g.N;
+        if constexpr (Epi::kStats) {
+          const float bias = nok ? biasj[j][cs] : 0.f;
+          float v[NPX];
+          float sum = 0.f;
+          int cnt = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m < HoWo) { const float d = v[e] - mean; m2 += d * d; }
+          for (int e = 0; e < NPX; ++e) {
+            const int m = mbase + row_of(e);
+            v[e] = val_of(i, j, cs, e) * wscale + bias;
+            if (m < HoWo) { sum += v[e]; ++cnt; }
+          }
+          if constexpr (M16) { sum += __shfl_xor(sum, 16); cnt += __shfl_xor(cnt, 16); }
+          sum += __shfl_xor(sum, 32);
+          cnt += __shfl_xor(cnt, 32);
+          const float mean = sum / (float)(cnt > 0 ? cnt : 1);
+          float m2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < NPX; ++e) {
+            const int m = mbase + row_of(e);
+            if (m < HoWo) { const float d = v[e] - mean; m2 += d * d; }
+          }
+          if constexpr (M16) m2 += __shfl_xor(m2, 16);
+          m2 += __shfl_xor(m2, 32);
+          if ((M16 ? (lane >> 4) : (lane >> 5)) == 0 && nok) {
+            const int grp = mbase >> 5;
+            const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
+            ep.part_sum[o] = sum;
+            ep.part_m2[o] = m2;
+          }
         }
-        m2 += __shfl_xor(m2, 32);
-        if (h == 0 && nok) {
-          const int grp = mbase >> 5;
-          const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
-          ep.part_sum[o] = sum;
-          ep.part_m2[o] = m2;
+        if (nok) {
+          if constexpr (Epi::kPrefetch) {
+            // all operand loads of the column set are issued back to back (clamped rows), then applied
+            typename Epi::Aux aux[NPX];
+#pragma unroll
+            for (int e = 0; e < NPX; ++e) aux[e] = ep.load(img, min(mbase + row_of(e), HoWo - 1), n);
+#pragma unroll
+            for (int e = 0; e < NPX; ++e) {
+              const int m = mbase + row_of(e);
+              if (m < HoWo) ep.apply(img, m, n, val_of(i, j, cs, e) * wscale, aux[e]);
+            }
+          } else if constexpr (epi_bias_arg<Epi>::value) {
+#pragma unroll
+            for (int e = 0; e < NPX; ++e) {
+              const int m = mbase + row_of(e);
+              if (m < HoWo) ep.store_c(img, m, n, val_of(i, j, cs, e) * wscale, colj[j][cs]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < NPX; ++e) {
+              const int m = mbase + row_of(e);
+              if (m < HoWo) ep(img, m, n, val_of(i, j, cs, e) * wscale);
+            }
+          }
         }
       }
-      if (nok) {
-        if constexpr (Epi::kPrefetch) {
-          // all 16 operand loads of the tile are issued back to back (clamped rows), then applied
-          typename Epi::Aux aux[16];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) aux[e] = ep.load(img, min(mbase + (e & 3) + 8 * (e >> 2) + 4 * h, HoWo - 1), n);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < HoWo) ep.apply(img, m, n, acc[i][j][e] * wscale, aux[e]);
-          }
-        } else if constexpr (epi_bias_arg<Epi>::value) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < HoWo) ep.store_c(img, m, n, acc[i][j][e] * wscale, colj[j]);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < HoWo) ep(img, m, n, acc[i][j][e] * wscale);
-          }
-        }
-      }
-    }
   }
 }
 
@@ -242,7 +308,9 @@ inline void launch_conv_sf(const ConvShape& s, float wscale, const Epi& ep, hipS
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   ConvGeom g = make_geom<MODE_TAP>(s, BM, BN);
   const int nblk = g.nimg * g.tiles_per_img * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST, PF>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
+  if (sf_mfma16()) hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST, PF, true>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
+  else
+  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST, PF, false>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
   ATDN_HIP(hipGetLastError());
 }
 
