@@ -181,7 +181,7 @@ void GmaNet::finalize() {
   fnet_ = pack_encoder(arena_, sd_, "fnet.", false, sf);
   cnet_ = pack_encoder(arena_, sd_, "cnet.", true, sf);
   convc1_ = tap({u + "encoder.convc1"});
-  if (sf && !lookup_legacy_) pack_fragment_major(arena_, convc1_);   // the fused lookup kernel loads operand-order weights
+  if (sf && !lookup_legacy_) pack_fragment_major16(arena_, convc1_);   // the fused lookup kernel loads operand-order weights (16x16x32)
   convc2_ = tap({u + "encoder.convc2"});
   convf1_ = pack_conv(arena_, sd_, {u + "encoder.convf1"}, MODE_ROW, 4);
   {  // the same weights as [(ky*7 + kx)*2 + c][128] for the register-tiled VALU kernel (small_convs.hip)
@@ -568,7 +568,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   }
   if (!lookup_legacy_) {
     // cor1 = relu(convc1(lookup(coords1))) in one kernel: the 324 samples of a pixel never leave the CU
-    launch_lookup_conv(brick_pyramid(), coords1_.p, n8, coords_used_.p, convc1_.wf, convc1_.wscale, convc1_.b, cor1_.p,
+    launch_lookup_conv(brick_pyramid(), coords1_.p, n8, coords_used_.p, convc1_.wf16, convc1_.wscale, convc1_.b, cor1_.p,
                        sf_fast_mode(), st);
     mark(ST_LOOKUP, st);
   } else {

@@ -113,7 +113,7 @@ void launch_brick_rows(const float* src, long sb, int nimg, int H, int W, int C,
 // bricked level -> row-major [npix][H*W] (debug reads)
 void launch_unbrick(const float* src, long NB, int H, int W, long npix, float* dst, hipStream_t st);
 // cor1 = relu(convc1(lookup(coords1))) (corr.py:32-53 + update.py:76-78): out sf [npix][256]; wfrag = convc1 weights in
-// fragment-major order (K = 352), bias [256]; coords_used (optional) receives the coordinates that were sampled
+// fragment-major order for v_mfma_f32_16x16x32_f16 (weights.h: pack_fragment_major16; K = 352), bias [256]; coords_used (optional) receives the coordinates that were sampled
 void launch_lookup_conv(const BrickPyramid& pyr, const float* coords1, long npix, float* coords_used, const float* wfrag,
                         float wscale, const float* bias, float* out, bool fast, hipStream_t st);
 // the lookup alone: out sf [npix][352]

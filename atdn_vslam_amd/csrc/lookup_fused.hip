@@ -15,8 +15,8 @@
 //     come from 2x2-pooled features (correlation is linear in the target features) the same way.
 //   * a 12 x 12 window touches at most 3 x 4 bricks: one wave fetches them as whole lines (8 lanes x 16 B per brick, two
 //     load instructions), three (pixel, level) units ahead;
-//   * a block owns 32 source pixels: its eight waves (level = wave & 3, sixteen pixels each) sample into a 32 x 352
-//     split-f16 tile in LDS — the A operand of the 1x1 convolution — and then multiply it with the fragment-major weights (straight
+//   * a block owns 64 source pixels (round 3; 32 before): its sixteen waves (level = wave & 3, sixteen pixels each) sample into
+//     a 64 x 352 split-f16 tile in LDS — the A operand of the 1x1 convolution — and then multiply it with the fragment-major weights (straight
 //     from L2 into operand registers, as the halo kernels do) and store relu(. + bias) as sf rows. The sampled
 //     correlation features never touch HBM.
 // Sample arithmetic is that of lookup_sf_kernel (kernels.hip), step by step, so results are unchanged.
@@ -29,9 +29,11 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int TP = 32;            // source pixels per block
+constexpr int TP = 64;            // source pixels per block (round 3: 64 — the convc1 phase was bound by the L1 rate of its weight loads,
+                                  // a block multiplies twice the pixels with every weight fragment it fetches)
 constexpr int NCH = 352;          // 4 * 81 samples padded to a multiple of 32
-constexpr int APITCH = 1424;      // bytes per pixel row of the A tile: 11 x 128 + 16 (144 mod 256: conflict-free b128 reads)
+constexpr int APITCH = 1440;      // bytes per pixel row of the A tile: 11 x 128 + 32 = 90 slots of 16 B, 90 = 2 (mod 4): conflict-free
+                                  // ds_read_b128 for the operand lane map of v_mfma_f32_16x16x32_f16 (16 pixels x 4 slots per instruction)
 constexpr int GW = 24, GH = 24;   // per-wave window grid: 3 x 4 bricks (24 x 16 cells). Pitch 24 dwords = -8 (mod 32 banks): the four
                                   // rows x two 16-byte halves a brick's eight lanes write (ds_write_b128: groups of 8 lanes) are eight
                                   // distinct bank quads, and a 32-lane group of sample reads (ds_read_b32) laid out as 8 x-positions x 4
@@ -40,7 +42,7 @@ constexpr int GW = 24, GH = 24;   // per-wave window grid: 3 x 4 bricks (24 x 16
                                   // body has NO branch (a branch around an LDS store made the compiler drain every prefetched load,
                                   // vmcnt(0), per unit)
 constexpr int DEPTH = 4;          // (pixel, level) units in flight per wave
-constexpr int NWAVE = 8;          // waves per block: level = wave & 3, pixels (wave >> 2) * 16 .. + 15
+constexpr int NWAVE = 16;         // waves per block (one 1024-thread block per CU): wave w samples all four levels of pixels 4 w .. 4 w + 3
 constexpr int UPW = TP * 4 / NWAVE;   // units (pixels of its level) per wave
 
 // One (pixel, level) unit. Everything here is wave-uniform: the integers are forced into scalar registers
@@ -66,7 +68,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // FUSED: multiply the sampled tile with convc1 and store relu(. + bias) as sf rows [pixel][256];
 // !FUSED: store the sampled tile itself as sf rows [pixel][352] (debug reads, the unfused comparison path)
 template <bool FUSED, bool FAST>
-__global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickPyramid pyr, const float* __restrict__ coords1,
+__global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickPyramid pyr, const float* __restrict__ coords1,
                                                             const long npix, float* __restrict__ coords_used,
                                                             const float* __restrict__ wfrag, const float wscale,
                                                             const float* __restrict__ bias, float* __restrict__ out) {
@@ -76,7 +78,6 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
   __shared__ __attribute__((aligned(16))) float2 ctab[NWAVE][2][64];   // per wave, two units: (weight, grid index) of the 18 chains
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (tells the compiler what the hardware guarantees: wave-uniform)
-  const int lvl = wave & 3, pbase = (wave >> 2) * UPW;
   const long p0 = (long)blockIdx.x * TP;
   const int np = (int)min((long)TP, npix - p0);
 
@@ -88,16 +89,21 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
     q[32] = (_Float16)0.f;
   }
 
-  // ---- phase 1: wave lvl samples level lvl of the block's pixels
-  const int Hl = pyr.H[lvl], Wl = pyr.W[lvl], BWl = pyr.BW[lvl], BHl = pyr.BH[lvl];
-  const long NBl = pyr.NB[lvl];
-  const float inv = 1.0f / (float)(1 << lvl);
-  const float wm1 = (float)(Wl - 1), hm1 = (float)(Hl - 1);
-  const float* lvl_base = pyr.base[lvl];
+  // ---- phase 1: wave w samples ALL FOUR levels of the pixels 4 w .. 4 w + 3. (Rounds 2 and early 3 gave a wave one level of
+  // sixteen pixels: the four level-0 waves — whose bricks come from HBM, 222 MB of volume per pair, while levels 1-3 mostly
+  // hit L2 / the Infinity Cache — set the pace and the other twelve waited at the block barrier: `SQ_WAIT_ANY` 0.45.) Units run
+  // in the order (pixel, level) with the level fastest, so unit pi has level pi & 3 = its slot in the DEPTH-4 ring: every
+  // level-dependent quantity is indexed by a compile-time slot.
+  static_assert(DEPTH == 4, "unit pi has level pi & 3 = pi % DEPTH");
+  const int pbase = wave * (UPW / 4);
+  float wm1[4], hm1[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) { wm1[l] = (float)(pyr.W[l] - 1); hm1[l] = (float)(pyr.H[l] - 1); }
   // coordinates of the block's pixels: lane i holds pixel i (pixels past the end repeat the last one; never stored)
-  const long pc = p0 + min(lane & 31, np - 1);
+  static_assert(TP == 64, "one lane per pixel of the block");
+  const long pc = p0 + min(lane, np - 1);
   const float2 cmine = *reinterpret_cast<const float2*>(coords1 + pc * 2);
-  if (lvl == 0 && lane < np && coords_used) *reinterpret_cast<float2*>(coords_used + (p0 + lane) * 2) = cmine;
+  if (wave == 0 && lane < np && coords_used) *reinterpret_cast<float2*>(coords_used + (p0 + lane) * 2) = cmine;
 
   Unit un[DEPTH];
   v4f bv[DEPTH][2];
@@ -105,41 +111,43 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
   int bxi[2], byi[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) { const int bi = 8 * k + (lane >> 3); byi[k] = bi / 3; bxi[k] = bi - 3 * byi[k]; }
-  auto issue = [&](int pi, int slot) __attribute__((always_inline)) {
-    const int pp = min(pbase + pi, np - 1);
+  auto issue = [&](int pi, int l) __attribute__((always_inline)) {   // l = pi & 3: level of the unit AND its ring slot
+    const int pp = min(pbase + (pi >> 2), np - 1);
     // (pp is wave-uniform: v_readlane, not a ds_bpermute whose wait would also sit behind the sampling phase's LDS traffic)
     const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cmine.x), pp));
     const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cmine.y), pp));
-    un[slot] = unit_origin(cx, cy, inv);
-    const Unit& u = un[slot];
+    un[l] = unit_origin(cx, cy, 1.0f / (float)(1 << l));
+    const Unit& u = un[l];
+    const int BWl = pyr.BW[l], BHl = pyr.BH[l];
+    const long NBl = pyr.NB[l];
     // only the bricks the 12 x 12 window really touches: 2-3 columns, 3-4 rows of bricks (scalar arithmetic)
     const int nbx = (((u.wx0 & 7) + 11) >> 3) + 1, nby = (((u.wy0 & 3) + 11) >> 2) + 1;
     // the pixel's map of this level as a buffer: a lane whose brick is outside the window or outside the map gets an offset
     // past the end, and the load returns zeros by itself (they ARE grid_sample's zero padding): no select on the data
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lvl_base + (p0 + pp) * NBl), 0,
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pyr.base[l] + (p0 + pp) * NBl), 0,
                                                                            (int)NBl * 4, 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int bx = u.bx0 + bxi[k], by = u.by0 + byi[k];
       const bool ok = (bxi[k] < nbx) & (byi[k] < nby) & ((unsigned)bx < (unsigned)BWl) & ((unsigned)by < (unsigned)BHl);
       const int off = ok ? (by * BWl + bx) * 128 + (lane & 7) * 16 : 0x7FFFFFF0;
-      bv[slot][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+      bv[l][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
 #pragma unroll
   for (int d = 0; d < DEPTH - 1; ++d) issue(d, d);
   float* gw = grid[wave];
   bool clamped = false;   // saturation of the sf format, reported once after the loop (sf.h)
-  // Round 3: the unit body has no lane permutes (eight ds_bpermute per unit before) and never drains the LDS queue (twice per
-  // unit before): it relies on what the hardware guarantees — the LDS instructions of ONE wave execute in issue order, so a
+  // The unit body has no lane permutes (eight ds_bpermute per unit in round 2) and never drains the LDS queue (twice per unit
+  // in round 2): it relies on what the hardware guarantees — the LDS instructions of ONE wave execute in issue order, so a
   // read issued after a write of the same wave sees it, and the next unit's grid writes cannot overtake this unit's reads.
   // The 9 + 9 coordinate chains of a unit (x offsets -4..4, y offsets -4..4; the reference's arithmetic, corr.py:43-49 and
   // utils.py:63-70) are evaluated ONCE, by lanes 0-17, one unit ahead, and left in a 64-entry table of the wave; a sample
   // lane picks up the (weight, grid index) pairs of its two samples with four ds_read_b64 — LDS instructions, while the
-  // vector pipe, which bounds this phase, does the arithmetic of the current unit.
+  // vector pipe does the arithmetic of the current unit.
   // per-lane constants: grid slot of this lane's two brick parts; its two samples (i, j), their table entries and where they
   // go in a pixel's row of the A tile (the 47 lanes past the 81st sample compute sample (8, 8) again into the dump rows)
-  int gofs[2], dofs[2], ex[2], ey[2];
+  int gofs[2], dofs[4][2], ex[2], ey[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int part = lane & 7;   // bricks 12..15 do not exist: their lanes load zeros and write them to rows 16..23
@@ -149,26 +157,31 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
     const int i9 = k == 0 ? (lane & 7) : (lane < 9 ? 8 : (lane < 17 ? lane - 9 : 8));
     const int j9 = k == 0 ? (lane >> 3) : (lane < 9 ? lane : 8);
     ex[k] = i9; ey[k] = 9 + j9;
-    const int c = lvl * 81 + i9 * 9 + j9;
-    dofs[k] = (c >> 5) * 128 + (c & 31) * 2;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int c = l * 81 + i9 * 9 + j9;
+      dofs[l][k] = (c >> 5) * 128 + (c & 31) * 2;
+    }
   }
   char* const dump = reinterpret_cast<char*>(gw + 22 * GW) + (lane & 15) * 2;
   // chain constants of THIS lane's table entry: lanes 0-8 x offset lane - 4, lanes 9-17 y offset lane - 13 (the rest: unused entries)
   const bool isx = lane < 9;
   const float cfd = (float)((isx ? lane : min(lane - 9, 8)) - 4);
-  const float csz = isx ? wm1 : hm1, crs = 1.0f / csz, chs = csz / 2.f;   // (IEEE division, once per wave)
+  float csz[4], crs[4], chs[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) { csz[l] = isx ? wm1[l] : hm1[l]; crs[l] = 1.0f / csz[l]; chs[l] = csz[l] / 2.f; }   // (IEEE divisions, once per wave)
   float2* const tab = ctab[wave][0];
   // pos = c + d; g = 2 pos / (S - 1) - 1; u = (g + 1) * ((S - 1) / 2); weight = u - floor(u);
   // grid index = clamp(floor(u) - window origin, 0, 10) + origin in the grid. The division is a multiplication by the correctly
   // rounded reciprocal plus one FMA correction (Markstein): the correctly rounded quotient, the same bits as the division.
-  auto chain_to_table = [&](const Unit& u, int buf) __attribute__((always_inline)) {
+  auto chain_to_table = [&](const Unit& u, int l, int buf) __attribute__((always_inline)) {
 #pragma clang fp contract(off)   // the same roundings in every unrolled copy (results must not depend on a pixel's slot)
     const float c0 = isx ? u.xc : u.yc;
     const int org = isx ? u.wx0 : u.wy0, gorg = isx ? u.wx0 - 8 * u.bx0 : u.wy0 - 4 * u.by0;
     const float t = 2.f * (c0 + cfd);
-    float q = t * crs;
-    q = __builtin_fmaf(__builtin_fmaf(-q, csz, t), crs, q);          // = t / csz, correctly rounded
-    const float uu = ((q - 1.f) + 1.f) * chs;
+    float q = t * crs[l];
+    q = __builtin_fmaf(__builtin_fmaf(-q, csz[l], t), crs[l], q);          // = t / csz, correctly rounded
+    const float uu = ((q - 1.f) + 1.f) * chs[l];
     const float fl = floorf(uu);
     // (a unit that is not sane has its origin at -2^24: the clamp alone keeps the index inside the grid)
     const int idx = min(max((int)fl - org, 0), 10) + gorg;
@@ -183,14 +196,17 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
       tp.off[t] = __float_as_int(y.y) * GW + __float_as_int(x.y);
     }
   };
-  static_assert(UPW % DEPTH == 0 && DEPTH % 2 == 0, "units per wave: a multiple of the (even) prefetch depth");
+  auto fence = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // (compiler only: no instruction)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  static_assert(UPW % DEPTH == 0, "units per wave must be a multiple of the prefetch depth");
   Taps tcur, tnext;
-  chain_to_table(un[0], 0);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();   // (compiler only: no instruction)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  chain_to_table(un[0], 0, 0);
+  fence();
   read_table(0, tcur);
-  // the unit loop is unrolled by DEPTH so that the register slots are compile-time constants
+  // the unit loop is unrolled by DEPTH so that the register slots (= levels) are compile-time constants
   for (int pi0 = 0; pi0 < UPW; pi0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
@@ -200,9 +216,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
       // window bricks -> grid. No wait: these writes come after the previous unit's sample reads and before this unit's
 #pragma unroll
       for (int k = 0; k < 2; ++k) *reinterpret_cast<v4f*>(gw + gofs[k]) = bv[d][k];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      fence();
       float q00[2], q01[2], q10[2], q11[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -211,12 +225,10 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
       }
       // the next unit's chains -> the other half of the table, and this lane's entries of it back (its coordinates arrived
       // DEPTH - 2 units ago); both behind the sample reads in the LDS queue
-      chain_to_table(un[(d + 1) % DEPTH], (d + 1) & 1);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      chain_to_table(un[(d + 1) % DEPTH], (d + 1) % DEPTH, (d + 1) & 1);
+      fence();
       read_table((d + 1) & 1, tnext);
-      char* arow = atile + (pbase + pi) * APITCH;
+      char* arow = atile + (pbase + (pi >> 2)) * APITCH;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         // explicit FMAs: left to itself the compiler fused these products differently in different copies of the unrolled
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
         v = u.sane ? v : 0.f;
         const SfPair sp = sf_split_flag(v, clamped);
         // (no branch around the store: lanes past the 81st sample write to the dump rows)
-        _Float16* dst = reinterpret_cast<_Float16*>((t == 0 || lane < 17) ? arow + dofs[t] : dump);
+        _Float16* dst = reinterpret_cast<_Float16*>((t == 0 || lane < 17) ? arow + dofs[d][t] : dump);
         dst[0] = sp.hi;
         dst[32] = sp.lo;
       }
@@ -237,23 +249,23 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
   }
   sf_report(clamped);
 
-  // ---- phase 2: [32 pixels x 352] x convc1^T -> 256 channels. Wave w owns channel tile w (32 channels); weights come
-  // straight from L2 in operand order (one contiguous KiB per wave load) through a ring of WD chunks — six MFMAs per
-  // chunk cover far less than an L2 round trip, so the first WD chunks are requested BEFORE the barrier that ends the
-  // sampling phase; operands swapped (weights are the row operand), so a lane ends up with 4-channel runs of ONE pixel
-  // and stores 8 + 8 bytes.
+  // ---- phase 2: [64 pixels x 352] x convc1^T -> 256 channels on v_mfma_f32_16x16x32_f16. Wave w owns the 16 channels
+  // 16 w .. 16 w + 15 for ALL 64 pixels (four 16-pixel column blocks), so the block fetches the 352 x 256 weight matrix
+  // exactly once (352 KiB per 64 pixels; the 8-wave / 32-pixel block of round 2 fetched it once per 32 pixels and was
+  // bound by the L1 rate of those loads: 5,600 cycles at 64 B/clk against 4,200 cycles of MFMA per block). Weights come
+  // straight from L2 in operand order (weights.h: pack_fragment_major16, one contiguous KiB per wave load) through a ring
+  // of WD chunks, the first WD requested BEFORE the barrier that ends the sampling phase; weights are the row operand, so
+  // lane (n, g) ends up with channels 16 w + 4 g + 0..3 of pixel 16 pb + n and stores 8 + 8 bytes.
   constexpr int NQ = NCH / 32;
   constexpr int WD = 4;
-  const int r = lane & 31, h = lane >> 5;
-  const char* wbase = reinterpret_cast<const char*>(wfrag) + (long)wave * NQ * 4096 + lane * 16;
-  f16x8 wh[WD][2], wl[WD][2];   // [slot][t]
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const int n16 = lane & 15, g16 = lane >> 4;
+  const char* wbase = reinterpret_cast<const char*>(wfrag) + (long)wave * NQ * 2048 + lane * 16;
+  f16x8 wh[WD], wl[WD];
   auto load_w = [&](int slot, int q) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const char* p = wbase + (long)q * 4096 + t * 2048;
-      wh[slot][t] = *reinterpret_cast<const f16x8*>(p);
-      if (!FAST) wl[slot][t] = *reinterpret_cast<const f16x8*>(p + 1024);
-    }
+    const char* p = wbase + (long)q * 2048;
+    wh[slot] = *reinterpret_cast<const f16x8*>(p);
+    if (!FAST) wl[slot] = *reinterpret_cast<const f16x8*>(p + 1024);
   };
   if (FUSED) {
 #pragma unroll
@@ -270,33 +282,39 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_conv_kernel(const BrickP
     return;
   }
 
-  f32x16 acc;
+  f32x4v acc[4];   // [pixel block]
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const char* arow = atile + r * APITCH + 16 * h;
+  for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[pb][e] = 0.f;
+  const char* arow = atile + n16 * APITCH + 16 * g16;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + q * 128 + 32 * t);
+    for (int pb = 0; pb < 4; ++pb) {
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + 16 * pb * APITCH + q * 128);
+      f32x4v c = acc[pb];
       if (!FAST) {
-        const f16x8 al = *reinterpret_cast<const f16x8*>(arow + q * 128 + 32 * t + 64);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q % WD][t], al, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[q % WD][t], ah, acc, 0, 0, 0);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(arow + 16 * pb * APITCH + q * 128 + 64);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q % WD], al, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q % WD], ah, c, 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q % WD][t], ah, acc, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q % WD], ah, c, 0, 0, 0);
+      acc[pb] = c;
     }
     if (q + WD < NQ) load_w(q % WD, q + WD);
   }
-  if (r < np) {
-    float* orow = out + (p0 + r) * 256;
+  {
+    const int c = 16 * wave + 4 * g16;
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int c = 32 * wave + 8 * jj + 4 * h;
-      const float4 b = *reinterpret_cast<const float4*>(bias + c);
-      const float4 o = make_float4(fmaxf(acc[4 * jj] * wscale + b.x, 0.f), fmaxf(acc[4 * jj + 1] * wscale + b.y, 0.f),
-                                   fmaxf(acc[4 * jj + 2] * wscale + b.z, 0.f), fmaxf(acc[4 * jj + 3] * wscale + b.w, 0.f));
-      sf_store4(orow, 0, c, o);
+    for (int pb = 0; pb < 4; ++pb) {
+      const int px = 16 * pb + n16;
+      if (px < np) {
+        const float4 o = make_float4(fmaxf(acc[pb][0] * wscale + b.x, 0.f), fmaxf(acc[pb][1] * wscale + b.y, 0.f),
+                                     fmaxf(acc[pb][2] * wscale + b.z, 0.f), fmaxf(acc[pb][3] * wscale + b.w, 0.f));
+        sf_store4(out + (p0 + px) * 256, 0, c, o);
+      }
     }
   }
 }
