@@ -10,9 +10,9 @@ namespace atdn {
 //   strips  RT = ceil(N / 32) 32-row strips per pair, chunks Q = ldN / 32 32-column chunks per row
 //   block (pair, strip, chunk) = 32 rows x 32 columns, strip-major: ((pair*RT + strip)*Q + chunk) * blk bytes
 //   a block holds two ROW BLOCKS rb = 0, 1 of 16 rows each; lane (n = lane & 15, g = lane >> 4) owns, in row block rb, row
-//   32*strip + 16*rb + n and the eight columns 32*chunk + 4*(g >> 1) + 16*(g & 1) + (i & 3) + 8*(i >> 2), i = 0..7 — the B
-//   operand of v_mfma_f32_16x16x32_f16 (round 3; K = 32 = the whole chunk), with the columns of a key group in the
-//   accumulator order of the producing 32x32x16 MFMA, so producer stores and consumer loads need no shuffle; the V^T
+//   32*strip + 16*rb + n and the eight columns 32*chunk + 4*g + (i & 3) + 16*(i >> 2), i = 0..7 — the B operand of
+//   v_mfma_f32_16x16x32_f16 (round 3; K = 32 = the whole chunk), with the columns of a key group in the accumulator
+//   order of the producing MFMAs (two 16-key blocks), so producer stores and consumer loads need no shuffle; the V^T
 //   operand is brought into the same column order when it is written to LDS.
 // Values are e = exp(s - rowmax~) * 2^AT_SHIFT, NOT normalised: rinv[pair][row] = 1 / sum_k e is applied by the
 // consumer. rowmax~ comes from a cheap first pass (f16 x f16 logits); softmax is shift-invariant, so any shift close to

@@ -20,7 +20,6 @@
 namespace atdn {
 namespace {
 
-constexpr int ROWB = 144;   // LDS row pitch (128 B of operands + 16): 32 consecutive rows read by ds_read_b128 do not conflict
 constexpr float LOG2E = 1.4426950408889634f;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -91,9 +90,15 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
                                                            const float* __restrict__ rowmax_in,
                                                            float* __restrict__ rowmax_out, float* __restrict__ P,
                                                            float* __restrict__ rinv) {
+  // Round 3: on v_mfma_f32_16x16x32_f16 (K = 32 = one channel chunk per instruction). Keys are the row operand (four blocks
+  // of 16 keys per 64-key tile), the wave's strip of 32 queries the column operand (two blocks rb of 16): lane (n = lane & 15,
+  // g = lane >> 4) holds, for query 32 strip + 16 rb + n, the keys 16 kb + 4 g + 0..3 of key block kb. A 32-key chunk is two
+  // key blocks, so the lane's eight values of a chunk are the keys 4 g + (i & 3) + 16 (i >> 2) — exactly one entry
+  // (rb, lane) of the stored block (attention.h): the store is one contiguous KiB per wave instruction again.
+  constexpr int KROW = 160;            // LDS pitch of a key row: conflict-free ds_read_b128 for the 16x16x32 lane map
   constexpr int KT = 64;               // keys per LDS tile
-  constexpr int CH = KT * ROWB;        // one 32-channel chunk of the tile
-  constexpr int IMG = 4 * CH;          // [4 channel chunks][64 keys][144 B]
+  constexpr int CH = KT * KROW;        // one 32-channel chunk of the tile
+  constexpr int IMG = 4 * CH;          // [4 channel chunks][64 keys][160 B]
   constexpr bool FULL = !STATS && !FAST;   // all three products of the split
   constexpr int BLK = AT_BLK_BYTES;
   __shared__ __attribute__((aligned(16))) char lds[2 * IMG];
@@ -104,22 +109,23 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   const int b = id / tiles, tile = id - b * tiles;
   const int strip = tile * 4 + wave;
   const bool strip_ok = strip < g.RT;
-  const int r = lane & 31, h = lane >> 5;
-  const int m = strip * 32 + r;
-  const bool m_ok = strip_ok && m < g.N;
+  const int n16 = lane & 15, g16 = lane >> 4;
   const char* qkb = reinterpret_cast<const char*>(qk + (long)b * g.N * 256);
 
-  // query fragments (the column operand), resident for the whole sweep: row m, channel chunk c, k-step t
-  f16x8 qh[4][2], ql[4][2];
-  {
-    const char* qrow = qkb + (long)min(m, g.N - 1) * 1024 + 16 * h;
+  // query fragments (the column operand), resident for the whole sweep: [row block][channel chunk]
+  f16x8 qh[2][4], ql[2][4];
+  int mrow[2];
+  bool m_ok[2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+  for (int rb = 0; rb < 2; ++rb) {
+    mrow[rb] = strip * 32 + 16 * rb + n16;
+    m_ok[rb] = strip_ok && mrow[rb] < g.N;
+    const char* qrow = qkb + (long)min(mrow[rb], g.N - 1) * 1024 + 16 * g16;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        qh[c][t] = ld_frag(qrow + c * 128 + 32 * t);
-        if (FULL) ql[c][t] = ld_frag(qrow + c * 128 + 32 * t + 64);
-      }
+    for (int c = 0; c < 4; ++c) {
+      qh[rb][c] = ld_frag(qrow + c * 128);
+      if (FULL) ql[rb][c] = ld_frag(qrow + c * 128 + 64);
+    }
   }
 
   // key tile loader: thread -> key rows lr, lr + 32 of the tile, 16-byte slot ls of every 128-byte channel chunk
@@ -139,14 +145,18 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        *reinterpret_cast<v4f*>(lds + buf * IMG + c * CH + (lr + 32 * i) * ROWB + 16 * ls) = kreg[i][c];
+        *reinterpret_cast<v4f*>(lds + buf * IMG + c * CH + (lr + 32 * i) * KROW + 16 * ls) = kreg[i][c];
   };
 
   const int NHT = (g.Q + 1) >> 1;
-  float run = STATS ? -INFINITY : 0.f;   // running row maximum / running row sum of this lane's columns
+  float run[2];          // running row maximum / running row sum of this lane's keys, per row block
+  float c0[2] = {0.f, 0.f};
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    run[rb] = STATS ? -INFINITY : 0.f;
+    if (!STATS) c0[rb] = (float)AT_SHIFT - rowmax_in[(long)b * g.Npad + min(mrow[rb], g.Npad - 1)] * LOG2E;
+  }
   bool clamped = false;                  // saturation of the f16 store, reported once after the sweep
-  float c0 = 0.f;
-  if (!STATS) c0 = (float)AT_SHIFT - rowmax_in[(long)b * g.Npad + min(m, g.Npad - 1)] * LOG2E;
   char* pdst = reinterpret_cast<char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * g.Q) * BLK;
 
   fetch(0);
@@ -154,24 +164,24 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   __syncthreads();
   fetch(min(1, NHT - 1));
   for (int j = 0; j < NHT; ++j) {
-    const char* img = lds + (j & 1) * IMG + r * ROWB + 16 * h;
-    f32x16 acc[2];
+    const char* img = lds + (j & 1) * IMG + n16 * KROW + 16 * g16;
+    f32x4v acc[4][2];   // [key block][row block]
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[kb][rb][e] = 0.f;
     // key fragments of channel chunk c + 1 are requested before the MFMAs of chunk c are issued (two register sets);
     // left to itself the compiler reads each fragment right before its MFMA and waits out the LDS round trip
-    f16x8 kh[2][2][2], kl[2][2][2];   // [set][t][nt]
+    f16x8 kh[2][4], kl[2][4];   // [set][key block]
     auto read_keys = [&](int set, int c) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const char* kp = img + c * CH + nt * 32 * ROWB + 32 * t;
-          kh[set][t][nt] = ld_frag(kp);
-          if (FULL) kl[set][t][nt] = ld_frag(kp + 64);
-        }
+      for (int kb = 0; kb < 4; ++kb) {
+        const char* kp = img + c * CH + 16 * kb * KROW;
+        kh[set][kb] = ld_frag(kp);
+        if (FULL) kl[set][kb] = ld_frag(kp + 64);
+      }
     };
     read_keys(0, 0);
 #pragma unroll
@@ -179,14 +189,16 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
       if (c + 1 < 4) read_keys((c + 1) & 1, c + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int rb = 0; rb < 2; ++rb) {
+          f32x4v a = acc[kb][rb];
           if (FULL) {
-            acc[nt] = mfma(kl[c & 1][t][nt], qh[c][t], acc[nt]);
-            acc[nt] = mfma(kh[c & 1][t][nt], ql[c][t], acc[nt]);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[c & 1][kb], qh[rb][c], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[c & 1][kb], ql[rb][c], a, 0, 0, 0);
           }
-          acc[nt] = mfma(kh[c & 1][t][nt], qh[c][t], acc[nt]);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[c & 1][kb], qh[rb][c], a, 0, 0, 0);
+          acc[kb][rb] = a;
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -195,33 +207,31 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
     stash((j + 1) & 1);
     fetch(min(j + 2, NHT - 1));
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col0 = j * KT + nt * 32 + 4 * h;
-      if (STATS) {
+    for (int cq = 0; cq < 2; ++cq) {        // the two 32-key chunks of the tile
+      const int key0 = j * KT + 32 * cq + 4 * g16;
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (col0 + (e & 3) + 8 * (e >> 2) < g.N) run = fmaxf(run, acc[nt][e]);
-      } else {
-        float v[16];
+      for (int rb = 0; rb < 2; ++rb) {
+        if (STATS) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const bool ok = m_ok && (col0 + (e & 3) + 8 * (e >> 2) < g.N);
-          const float x = __builtin_amdgcn_exp2f(fmaf(acc[nt][e], LOG2E, c0));
-          v[e] = ok ? x : 0.f;
-          run += v[e];
-        }
-        const int q = 2 * j + nt;
-        if (strip_ok && q < g.Q) {
-          char* d = pdst + (long)q * BLK;
-          // consumer entry (attention.h): row block rb = r >> 4, lane' = (r & 15) + 16 g with key group g = 2 h + t
+          for (int i = 0; i < 8; ++i)
+            if (key0 + (i & 3) + 16 * (i >> 2) < g.N) run[rb] = fmaxf(run[rb], acc[2 * cq + (i >> 2)][rb][i & 3]);
+        } else {
+          float v[8];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
+          for (int i = 0; i < 8; ++i) {
+            const bool ok = m_ok[rb] && (key0 + (i & 3) + 16 * (i >> 2) < g.N);
+            const float x = __builtin_amdgcn_exp2f(fmaf(acc[2 * cq + (i >> 2)][rb][i & 3], LOG2E, c0[rb]));
+            v[i] = ok ? x : 0.f;
+            run[rb] += v[i];
+          }
+          const int q = 2 * j + cq;
+          if (strip_ok && q < g.Q) {
+            char* d = pdst + (long)q * BLK;
             f16x8 hi;
             u32x2 bytes;
-            h3_encode(v + 8 * t, hi, bytes, clamped);
-            const int lp = (r & 15) + 16 * (2 * h + t), rb = r >> 4;
-            st_frag_nt(d + rb * 1024 + lp * 16, hi);
-            __builtin_nontemporal_store(bytes, reinterpret_cast<u32x2*>(d + 2048 + rb * 512 + lp * 8));
+            h3_encode(v, hi, bytes, clamped);
+            st_frag_nt(d + rb * 1024 + lane * 16, hi);
+            __builtin_nontemporal_store(bytes, reinterpret_cast<u32x2*>(d + 2048 + rb * 512 + lane * 8));
           }
         }
       }
@@ -229,12 +239,18 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
     __syncthreads();
   }
   sf_report(clamped);
-  if (STATS) {
-    run = fmaxf(run, __shfl_xor(run, 32));
-    if (h == 0 && strip_ok) rowmax_out[(long)b * g.Npad + m] = run;
-  } else {
-    run += __shfl_xor(run, 32);
-    if (h == 0 && strip_ok) rinv[(long)b * g.Npad + m] = (m < g.N && run > 0.f) ? 1.0f / run : 0.f;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    float r_ = run[rb];
+    if (STATS) {
+      r_ = fmaxf(r_, __shfl_xor(r_, 16));
+      r_ = fmaxf(r_, __shfl_xor(r_, 32));
+      if (g16 == 0 && strip_ok) rowmax_out[(long)b * g.Npad + mrow[rb]] = r_;
+    } else {
+      r_ += __shfl_xor(r_, 16);
+      r_ += __shfl_xor(r_, 32);
+      if (g16 == 0 && strip_ok) rinv[(long)b * g.Npad + mrow[rb]] = (mrow[rb] < g.N && r_ > 0.f) ? 1.0f / r_ : 0.f;
+    }
   }
 }
 
@@ -293,8 +309,8 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
 
   // V^T staging (set A only: tid < 256): rows lr + 32 i, 16-byte slot ls of the row's 128-byte [32 hi | 32 lo] chunk = two
   // 8-byte pieces p = 2 (ls & 3), 2 (ls & 3) + 1 of four consecutive keys each. The attention fragments hold, in key group
-  // g = 2 h + t, the keys 4 h + 16 t + (i & 3) + 8 (i >> 2) (accumulator order of the producer), so piece p goes to slot
-  // 2 (p & 1) + (p >> 2), half (p >> 1) & 1 of the LDS row.
+  // g, the keys 4 g + (i & 3) + 16 (i >> 2) (accumulator order of the producer), so piece p (keys 4 p .. 4 p + 3) goes to
+  // slot p & 3, half p >> 2 of the LDS row.
   const int lr = (tid & 255) >> 3, ls = tid & 7;
   const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
   v4f breg[2][4];
@@ -303,8 +319,8 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
     for (int i = 0; i < 4; ++i) breg[set][i] = *reinterpret_cast<const v4f*>(vrow + (long)(32 * i) * g.ldN + min(q, Q - 1) * 32);
   };
   const int p0 = 2 * (ls & 3), p1 = p0 + 1;
-  const int boff0 = lr * VROW + 64 * (ls >> 2) + 16 * (2 * (p0 & 1) + (p0 >> 2)) + 8 * ((p0 >> 1) & 1);
-  const int boff1 = lr * VROW + 64 * (ls >> 2) + 16 * (2 * (p1 & 1) + (p1 >> 2)) + 8 * ((p1 >> 1) & 1);
+  const int boff0 = lr * VROW + 64 * (ls >> 2) + 16 * (p0 & 3) + 8 * (p0 >> 2);
+  const int boff1 = lr * VROW + 64 * (ls >> 2) + 16 * (p1 & 3) + 8 * (p1 >> 2);
   auto stashB = [&](int image, int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -454,9 +470,9 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict
     float* row = rows + ((long)b * g.N + m) * g.ldN + q * 32;
     const f16x8 hi = ld_frag(p + rb * 1024 + lane * 16);
     const f16x8 lo = h3_decode_lo(hi, *reinterpret_cast<const u32x2*>(p + 2048 + rb * 512 + lane * 8));
-    // key group g = 2 h + t of the producer: keys 4 h + 16 t + (i & 3) + 8 (i >> 2)
+    // key group g of the producer: keys 4 g + (i & 3) + 16 (i >> 2)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) row[4 * (gq >> 1) + 16 * (gq & 1) + (i & 3) + 8 * (i >> 2)] = ((float)hi[i] + (float)lo[i]) * rv;
+    for (int i = 0; i < 8; ++i) row[4 * gq + (i & 3) + 16 * (i >> 2)] = ((float)hi[i] + (float)lo[i]) * rv;
   }
 }
 
