@@ -76,7 +76,18 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
     us_out[8] = ATDN_MB_SF6M(128, 1, 4);
     us_out[9] = ATDN_MB_SF6M(64, 2, 2);
 #undef ATDN_MB_SF6M
-    for (int i = 10; i < 12; ++i) us_out[i] = 0.f;
+    us_out[10] = us_out[11] = 0.f;
+    if (KH == 1 && KW == 5 && N == 256 && C == 384) {
+      // round 3: what the ConvGRU gate epilogue costs — the 128-wide block the pipeline uses, with SfBias and with SfGruZR
+      float *hbuf, *zbuf, *rhbuf, *pre;
+      ATDN_HIP(hipMalloc(&hbuf, npix * 128 * 4)); ATDN_HIP(hipMalloc(&zbuf, npix * 128 * 4));
+      ATDN_HIP(hipMalloc(&rhbuf, npix * 128 * 4)); ATDN_HIP(hipMalloc(&pre, npix * 256 * 4));
+      ATDN_HIP(hipMemset(hbuf, 0, npix * 128 * 4)); ATDN_HIP(hipMemset(pre, 0, npix * 256 * 4));
+      SfGruZR eg{bias, hbuf, zbuf, rhbuf, (long)H * W * 128, pre, (long)H * W * 256};
+      us_out[10] = time_it([&]() { launch_conv_sf6<8, 128, 1, 4, 1, 5, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
+      us_out[11] = time_it([&]() { launch_conv_sf6<8, 128, 1, 4, 1, 5, SfGruZR, 0, true, false, 2, false, true>(s, 1.f, eg, st); });
+      (void)hipFree(hbuf); (void)hipFree(zbuf); (void)hipFree(rhbuf); (void)hipFree(pre);
+    }
     (void)hipFree(x); (void)hipFree(w); (void)hipFree(wf); (void)hipFree(y); (void)hipFree(bias);
     return 0;
   } catch (const std::exception& e) {

@@ -12,12 +12,15 @@ L = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libatdn_microbench.so")
 out = (C.c_float * 12)()
 names = ["gen6 8x16 px x 256 ch (8 waves)", "gen6 8x16 px x 128 ch (4 waves)", "gen6 8x16 px x 64 ch (2x2 waves)",
          "  x256 minus epilogue", "  ... minus weight loads", "  ... minus LDS reads", "  ... minus patch refresh (bare MFMA)",
-         "16x16x32 loop: 8x16 px x 256 ch (8 waves)", "16x16x32 loop: 8x16 px x 128 ch (4 waves)", "16x16x32 loop: 8x16 px x 64 ch (2x2 waves)"]
-for (nimg, H, W, Cc, N, KH, KW) in ((8, 47, 154, 384, 256, 1, 5), (8, 47, 154, 256, 192, 3, 3), (8, 47, 154, 128, 256, 3, 3)):
+         "16x16x32 loop: 8x16 px x 256 ch (8 waves)", "16x16x32 loop: 8x16 px x 128 ch (4 waves)", "16x16x32 loop: 8x16 px x 64 ch (2x2 waves)",
+         "16x16x32, 128-wide, SfBias epilogue (z|r shape only)", "16x16x32, 128-wide, SfGruZR gate epilogue (z|r shape only)"]
+for (nimg, H, W, Cc, N, KH, KW) in ((8, 47, 154, 384, 256, 1, 5), (16, 47, 154, 384, 256, 1, 5), (8, 47, 154, 256, 192, 3, 3), (8, 47, 154, 128, 256, 3, 3)):
     torch.cuda.synchronize()
     rc = L.atdn_microbench_conv(nimg, H, W, Cc, N, KH, KW, 50, out)
     assert rc == 0
     flop = 2.0 * nimg * H * W * N * KH * KW * Cc
     print("conv %dx%d C=%d N=%d B=%d: %.1f GFLOP algorithmic, 3x-f16 MFMA floor at 2.5 PF %.1f us" % (KH, KW, Cc, N, nimg, flop / 1e9, 3 * flop / 2.5e15 * 1e6))
     for n, v in zip(names, out):
+        if v <= 0.0:
+            continue
         print("   %-42s %8.1f us   %6.1f TF algorithmic   %6.0f TF executed" % (n, v, flop / v / 1e6, 3 * flop / v / 1e6))
