@@ -42,7 +42,8 @@ void launch_qk_rowmax(const float* qk, const AttnGeom& g, float* rowmax, hipStre
 void launch_qk_softmax(const float* qk, const AttnGeom& g, const float* rowmax, float* P, float* rinv, bool fast,
                        hipStream_t st);
 // out[b][m][c] = mf[b][m][c] + gamma * rinv[b][m] * sum_k P[b][m][k] * V[b][k][c]          (gma.py:111-115)
-//   vT sf [B][128][ldN] (V transposed, k contiguous); mf / out sf rows with pixel stride ld (floats), per-pair stride sb
+//   vT sf [B][128][ldN] (V transposed, k contiguous, the 32 keys of every chunk in the operand order above: SfVT);
+//   mf / out sf rows with pixel stride ld (floats), per-pair stride sb
 void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const float* vT, const float* gamma,
                    const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st);
 // debug / tests: normalised probabilities as fp32 rows [B][N][ldN]

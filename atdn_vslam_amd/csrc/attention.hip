@@ -307,10 +307,11 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
     }
   };
 
-  // V^T staging (set A only: tid < 256): rows lr + 32 i, 16-byte slot ls of the row's 128-byte [32 hi | 32 lo] chunk = two
-  // 8-byte pieces p = 2 (ls & 3), 2 (ls & 3) + 1 of four consecutive keys each. The attention fragments hold, in key group
-  // g, the keys 4 g + (i & 3) + 16 (i >> 2) (accumulator order of the producer), so piece p (keys 4 p .. 4 p + 3) goes to
-  // slot p & 3, half p >> 2 of the LDS row.
+  // V^T staging (set A only: tid < 256): rows lr + 32 i, 16-byte slot ls of the row's 128-byte [32 hi | 32 lo] chunk. The
+  // producer of V^T (epilogues_sf.h: SfVT) already stores the keys of a chunk in operand order — slot g = keys
+  // 4 g + (i & 3) + 16 (i >> 2), the order of the attention fragments — so a slot is copied verbatim: one ds_write_b128
+  // per row, eight lanes = one contiguous 128-byte row, no bank conflicts (the 8-byte piece moves this replaced had
+  // SQ_LDS_BANK_CONFLICT at 17 % of the kernel's LDS cycles).
   const int lr = (tid & 255) >> 3, ls = tid & 7;
   const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
   v4f breg[2][4];
@@ -318,16 +319,10 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) breg[set][i] = *reinterpret_cast<const v4f*>(vrow + (long)(32 * i) * g.ldN + min(q, Q - 1) * 32);
   };
-  const int p0 = 2 * (ls & 3), p1 = p0 + 1;
-  const int boff0 = lr * VROW + 64 * (ls >> 2) + 16 * (p0 & 3) + 8 * (p0 >> 2);
-  const int boff1 = lr * VROW + 64 * (ls >> 2) + 16 * (p1 & 3) + 8 * (p1 >> 2);
+  const int boff = lr * VROW + 16 * ls;
   auto stashB = [&](int image, int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      char* d = lds + image * IMG + 32 * i * VROW;
-      *reinterpret_cast<float2*>(d + boff0) = make_float2(breg[set][i].x, breg[set][i].y);
-      *reinterpret_cast<float2*>(d + boff1) = make_float2(breg[set][i].z, breg[set][i].w);
-    }
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<v4f*>(lds + image * IMG + 32 * i * VROW + boff) = breg[set][i];
   };
 
   f32x4v acc[8][2];      // [channel block][row block]

@@ -2,5 +2,5 @@
 namespace atdn {
 ATDN_INSTANTIATE_CONV_SF(EpiScale)
 ATDN_INSTANTIATE_CONV_SF(SfQK)
-ATDN_INSTANTIATE_CONV_SF(SfStoreT)
+ATDN_INSTANTIATE_CONV_SF(SfVT)
 }

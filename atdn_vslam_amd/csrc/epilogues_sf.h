@@ -90,13 +90,20 @@ struct SfQK {
   }
 };
 
-// transposed sf store: dst[img][n][m]  (m is the K index of attention·V)
-struct SfStoreT {
+// V^T for attention x V (attention.hip): dst[img][channel m][key n] in sf, with the 32 keys of a chunk stored in the order
+// the consumer's MFMA operand wants them — slot g (16 bytes) = keys 4 g + (i & 3) + 16 (i >> 2), i = 0..7 (attention.h) —
+// so the consumer copies 16-byte slots verbatim into its LDS image (round 3: it used to move 8-byte pieces to permuted
+// positions, ds_write_b64 with 2-way bank conflicts at the 160-byte row pitch).
+struct SfVT {
   static constexpr bool kStats = false;
   static constexpr bool kPrefetch = false;
   float* dst; long ob; int ld;
+  __device__ __forceinline__ static int perm(int n) {   // key n -> its position inside the chunk
+    const int k = n & 31;
+    return (n & ~31) | (((k >> 2) & 3) << 3) | ((k >> 4) << 2) | (k & 3);
+  }
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const {
-    sf_store(dst, (long)img * ob + (long)n * ld, m, a);
+    sf_store(dst, (long)img * ob + (long)m * ld, perm(n), a);
   }
 };
 

@@ -29,7 +29,7 @@ extern template TileChoice conv_dispatch<MODE_ROW, SfBias<ACT_RELU>>(const ConvS
 #define ATDN_EXTERN_SF(EPI) extern template TileChoice conv_sf_dispatch<EPI>(const ConvShape&, float, EPI, hipStream_t);
 ATDN_EXTERN_SF(SfBias<ACT_NONE>) ATDN_EXTERN_SF(SfBias<ACT_RELU>) ATDN_EXTERN_SF(EpiBias<ACT_NONE>)
 ATDN_EXTERN_SF(EpiBiasStats) ATDN_EXTERN_SF(SfBiasReluAddRelu) ATDN_EXTERN_SF(SfContextSplit)
-ATDN_EXTERN_SF(EpiScale) ATDN_EXTERN_SF(SfQK) ATDN_EXTERN_SF(SfStoreT)
+ATDN_EXTERN_SF(EpiScale) ATDN_EXTERN_SF(SfQK) ATDN_EXTERN_SF(SfVT)
 ATDN_EXTERN_SF(SfAggregate) ATDN_EXTERN_SF(SfGruZR) ATDN_EXTERN_SF(SfGruQ) ATDN_EXTERN_SF(SfFlowDelta)
 
 namespace {
@@ -601,7 +601,8 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   ConvShape v;
   v.src0 = to_v_.w; v.ld0 = 128; v.sb0 = 0; v.C0 = 128; v.H = 1; v.W = 128;
   v.w = mf; v.wb = (long)N * XLD; v.ldw = XLD; v.N = N; v.nimg = B;
-  conv_sf_dispatch(v, to_v_.wscale, SfBias<ACT_NONE>{nullptr, vT_.p, (long)128 * ldN, ldN}, st);
+  if (attn_legacy_) conv_sf_dispatch(v, to_v_.wscale, SfBias<ACT_NONE>{nullptr, vT_.p, (long)128 * ldN, ldN}, st);
+  else conv_sf_dispatch(v, to_v_.wscale, SfVT{vT_.p, (long)128 * ldN, ldN}, st);   // keys of a chunk in operand order
   mark(ST_AGG_VT, st);
   if (attn_legacy_) {
     ConvShape a;
