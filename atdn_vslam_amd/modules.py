@@ -117,13 +117,17 @@ class RAFTGMA(_NativeModule):
 
     PRECISIONS = {"f32": 0, "split_f16": 1, "f16": 2}
 
-    def __init__(self, args=None, max_batch=1, precision=None, saturation_check_every=512):
+    def __init__(self, args=None, max_batch=1, precision=None, saturation_check_every=512, saturation_fallback=False):
         """`saturation_check_every`: in the split-f16 modes the module reads the library's saturation counter after the
         FIRST forward of a freshly loaded checkpoint (and whenever the weights changed), then every that many forwards
         (0: never again), and `check_saturation()` can be called at any time (OdometryPipeline.run_sequence does, at the end
-        of a sequence). A non-zero count raises SplitF16RangeError."""
+        of a sequence). A non-zero count raises SplitF16RangeError — or, with `saturation_fallback=True`, switches THIS
+        module to precision="f32" (a new handle in the same process, a warning, `self.fell_back = True`) and recomputes the
+        forward that detected it, so the caller never receives a result computed with clamped activations."""
         super().__init__()
         self.args = args
+        self.saturation_fallback = bool(saturation_fallback)
+        self.fell_back = False
         self.saturation_check_every = int(saturation_check_every)
         self.saturation_checks = 0      # how many times the counter has been read (tests)
         self._sat_pending = True        # a checkpoint whose first forward has not been checked yet
@@ -175,11 +179,24 @@ class RAFTGMA(_NativeModule):
         return clamped
 
     def _after_forward(self):
+        """Returns True when the forward just issued must be recomputed (the module has switched itself to f32)."""
         if self.precision == "f32":
-            return
+            return False
         self._sat_calls += 1
         if self._sat_pending or (self.saturation_check_every > 0 and self._sat_calls >= self.saturation_check_every):
-            self.check_saturation()
+            if not self.saturation_fallback:
+                self.check_saturation()
+                return False
+            clamped = self.check_saturation(raise_on_clamp=False)
+            if clamped:
+                import warnings
+                warnings.warn("RAFTGMA: %d activation(s) left the split-f16 range; this module now runs in precision=\"f32\" "
+                              "(exact-fp32 MFMA) and the forward is recomputed" % clamped, RuntimeWarning)
+                self.precision = "f32"
+                self.fell_back = True
+                self._drop_handles()
+                return True
+        return False
 
     def _handle(self, H, W, B):
         key = self._key(H, W)
@@ -222,7 +239,9 @@ class RAFTGMA(_NativeModule):
             h = self._handle(H, W, B)
             _lib.check(_lib.lib().atdn_gma_forward(h, _ptr(im1), _ptr(im2), B, int(iters), _ptr(fi), _ptr(flow_low),
                                                    _ptr(flow_up), _stream()))
-            self._after_forward()
+            retry = self._after_forward()
+        if retry:
+            return self.forward(image1, image2, iters=iters, flow_init=flow_init, upsample=upsample, test_mode=test_mode)
         return flow_low, flow_up
 
     @torch.no_grad()
@@ -252,7 +271,9 @@ class RAFTGMA(_NativeModule):
             h = self._handle(H, W, B)
             fn = _lib.lib().atdn_gma_forward_sequence_continued if continued else _lib.lib().atdn_gma_forward_sequence
             _lib.check(fn(h, _ptr(fr), B, int(iters), _ptr(fi), _ptr(flow_low), _ptr(flow_up), _stream()))
-            self._after_forward()
+            retry = self._after_forward()
+        if retry:   # (the f32 mode has no sequence form: pair mode on the same frames)
+            return self.forward(frames[:-1], frames[1:], iters=iters, flow_init=flow_init, test_mode=True)
         return flow_low, flow_up
 
     def debug_read(self, name, shape, H, W):

@@ -86,11 +86,12 @@ class FrameIngest:
 class OdometryPipeline:
     """Holds the two networks on one device and runs batches of frame pairs."""
 
-    def __init__(self, gma_state, clvo_state, device="cuda:0", max_batch=4, iters=12, size=SLAM_SIZE, precision=None):
+    def __init__(self, gma_state, clvo_state, device="cuda:0", max_batch=4, iters=12, size=SLAM_SIZE, precision=None,
+                 saturation_fallback=False):
         self.device = torch.device(device)
         self.iters = iters
         self.size = size
-        self.flow_net = RAFTGMA(max_batch=max_batch, precision=precision)
+        self.flow_net = RAFTGMA(max_batch=max_batch, precision=precision, saturation_fallback=saturation_fallback)
         self.flow_net.load_state_dict(gma_state)
         self.flow_net = self.flow_net.to(self.device).eval()
         self.head = ATDNVO()

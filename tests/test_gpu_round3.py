@@ -85,6 +85,26 @@ def test_saturation_guard_raises_through_the_product_path():
     assert bool(torch.isfinite(up).all())
 
 
+def test_saturation_fallback_recomputes_in_f32():
+    """Opt-in self-healing: with saturation_fallback=True the module that detects clamped activations switches itself to the
+    exact-fp32 matrix core (new handle, same process), warns, and recomputes the forward — the caller gets the f32 result."""
+    bad = _scaled_state({"cnet.conv1": 3e5})
+    fr = torch.from_numpy(syn.make_frames(3, 160, 512, seed=3)).to(DEV)
+    ref = RAFTGMA(precision="f32")
+    ref.load_state_dict(bad)
+    ref = ref.to(DEV).eval()
+    want_low, want_up = ref(fr[0:2], fr[1:3], iters=2, test_mode=True)
+    net = RAFTGMA(saturation_fallback=True)
+    net.load_state_dict(bad)
+    net = net.to(DEV).eval()
+    with pytest.warns(RuntimeWarning):
+        low, up = net.forward_sequence(fr, iters=2)          # detected after the first (sequence-mode) forward
+    assert net.fell_back and net.precision == "f32"
+    assert torch.equal(up, want_up) and torch.equal(low, want_low)
+    low2, up2 = net(fr[0:2], fr[1:3], iters=2, test_mode=True)   # stays in f32, no further checks
+    assert torch.equal(up2, want_up)
+
+
 def test_saturation_guard_interval_and_explicit_check():
     good = syn.to_torch(syn.make_gma_state(seed=1))
     net = RAFTGMA(saturation_check_every=3)
