@@ -117,11 +117,6 @@ class GmaNet {
   void mark(int stage, hipStream_t st);
 
   hipStream_t cap_stream_ = nullptr;
-  // the flow branch of the motion encoder runs beside the correlation branch (a parallel branch of the graph): gma.hip,
-  // iteration_sf. ATDN_FORK_FLOW=0 keeps everything on one stream
-  bool fork_flow_branch_ = false;
-  hipStream_t aux_stream_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   std::map<std::pair<int, int>, hipGraphExec_t> graphs_;  // key: (B, iters * 2 + seq)
 };
 

@@ -110,8 +110,6 @@ void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st, int 
   ATDN_CHECK(mode == 0 || precision >= 1, "sequence modes are built for the split-f16 pipeline");
   for (int i = 0; i < ST_COUNT; ++i) ms[i] = 0.f;
   seq_ = mode;   // 0 pair, 1 sequence, 2 continued sequence (fmap_ slot 0 is read as it stands: timing only)
-  // per-stage times must be per-kernel times: the parallel flow branch of the graph stays on the one timed stream here
-  struct ForkOff { bool& f; bool prev; explicit ForkOff(bool& x) : f(x), prev(x) { f = false; } ~ForkOff() { f = prev; } } fork_off(fork_flow_branch_);
   last_frame_ = 0;   // fmap_ is overwritten: a continued sequence call must not read it
   for (int r = 0; r < reps; ++r) {
     Timer t;
@@ -146,7 +144,6 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   lookup_legacy_ = precision == 0 || (getenv("ATDN_LOOKUP_LEGACY") && getenv("ATDN_LOOKUP_LEGACY")[0] == '1');
   attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
   mfma16_ = !(getenv("ATDN_CONV_M32") && getenv("ATDN_CONV_M32")[0] == '1');
-  fork_flow_branch_ = precision >= 1 && !(getenv("ATDN_FORK_FLOW") && getenv("ATDN_FORK_FLOW")[0] == '0');
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
   (void)hipGetDevice(&dev_);   // (no throw: argument errors must be reportable without a device; finalize() needs one anyway)
@@ -158,9 +155,6 @@ GmaNet::~GmaNet() {
   (void)hipDeviceSynchronize();
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
-  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-  if (ev_join_) (void)hipEventDestroy(ev_join_);
   DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
@@ -280,9 +274,6 @@ void GmaNet::finalize() {
   (void)zero_line();  // allocate the shared zero line now: never inside a stream capture
   sf_counter_attach(); // saturation counter of the sf format (sf.h): attached before the first launch
   ATDN_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
-  ATDN_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
-  ATDN_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-  ATDN_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   ready_ = true;
 }
 
@@ -556,16 +547,6 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
 void GmaNet::iteration_sf(int B, hipStream_t st) {
   const long n8 = (long)B * N;
   ConvShape s;
-  if (fork_flow_branch_) {
-    // The flow branch of the motion encoder (convf1 7x7 on the current flow, convf2 3x3: update.py:79-80) depends on nothing
-    // the correlation branch (lookup, convc1, convc2: update.py:76-78) produces: it runs on a second stream — a parallel
-    // branch of the captured graph — beside the lookup, whose waves spend most of their time waiting, and joins before `conv`.
-    ATDN_HIP(hipEventRecord(ev_fork_, st));
-    ATDN_HIP(hipStreamWaitEvent(aux_stream_, ev_fork_, 0));
-    launch_flow_conv7(flow4_.p, B, H8, W8, arena_.dev(convf1_vw_off_), convf1_.b, flo1_.p, aux_stream_);
-    s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
-    conv_sf_dispatch(s, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, aux_stream_);
-  }
   if (!lookup_legacy_) {
     // cor1 = relu(convc1(lookup(coords1))) in one kernel: the 324 samples of a pixel never leave the CU
     launch_lookup_conv(brick_pyramid(), coords1_.p, n8, coords_used_.p, convc1_.wf16, convc1_.wscale, convc1_.b, cor1_.p,
@@ -582,15 +563,12 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   }
   s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
-  if (fork_flow_branch_) {
-    // join: the flow branch (forked before the lookup, below) wrote corflo[192:256]
-    ATDN_HIP(hipEventRecord(ev_join_, aux_stream_));
-    ATDN_HIP(hipStreamWaitEvent(st, ev_join_, 0));
-  } else {
-    launch_flow_conv7(flow4_.p, B, H8, W8, arena_.dev(convf1_vw_off_), convf1_.b, flo1_.p, st);
-    s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
-    conv_sf_dispatch(s, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
-  }
+  // (Round 3 captured the flow branch — convf1, convf2: independent of the correlation branch — as a parallel branch of the
+  // graph on a second stream: +0.3 % on bench.py's two-stream loop, but -3 % in the sequence driver, whose lane streams then
+  // share hardware queues with the branch streams of the two graphs. Removed: one stream per clip, one queue per stream.)
+  launch_flow_conv7(flow4_.p, B, H8, W8, arena_.dev(convf1_vw_off_), convf1_.b, flo1_.p, st);
+  s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  conv_sf_dispatch(s, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
   s = conv_shape(convm_, corflo_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   float* mf = x_.p + 128;
   conv_sf_dispatch(s, convm_.wscale, SfBias<ACT_RELU>{convm_.b, mf, (long)N * XLD, XLD}, st);

@@ -147,10 +147,23 @@ class OdometryPipeline:
                 raise RuntimeError("run_sequence: every lane must be an OdometryPipeline on %s with the same size / iterations"
                                    % (self.device,))
         L = len(pipes)
+        # lane streams and ingest objects live as long as the pipeline (a new stream per call would also mean a new pool of
+        # the caching allocator per call)
+        cache = self.__dict__.setdefault("_lane_cache", {})
         with torch.cuda.device(self.device):
-            streams = [torch.cuda.current_stream()] if L == 1 else [torch.cuda.Stream(device=self.device) for _ in pipes]
-        ingests = [FrameIngest(tuple(frames.shape[-2:]), batch + 1, size=self.size, antialias=antialias, device=self.device)
-                   for _ in pipes] if host else None
+            if L == 1:
+                streams = [torch.cuda.current_stream()]
+            else:
+                while len(cache.setdefault("streams", [])) < L:
+                    cache["streams"].append(torch.cuda.Stream(device=self.device))
+                streams = cache["streams"][:L]
+        ingests = None
+        if host:
+            key = (tuple(frames.shape[-2:]), batch + 1, tuple(self.size), bool(antialias))
+            pool = cache.setdefault("ingests", {}).setdefault(key, [])
+            while len(pool) < L:
+                pool.append(FrameIngest(key[0], key[1], size=self.size, antialias=antialias, device=self.device))
+            ingests = pool[:L]
         main = torch.cuda.current_stream(self.device)
 
         def encode_clip(s, e, continued, lane=0):

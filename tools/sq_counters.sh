@@ -4,7 +4,6 @@
 out=${1:-gpurun_out/sq}
 mkdir -p "$out"
 export TMPDIR=/tmp
-export ATDN_FORK_FLOW=0   # every kernel alone on the one stream
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
