@@ -22,7 +22,10 @@ def shard_range(n_pairs, rank, world):
 def gather_features(local, n_pairs, group=None):
     """local [p_r, D] (this rank's shard, in sequence order) -> [n_pairs, D] in global sequence order on every
     rank. One all_gather of equally sized (padded) blocks; ragged and empty shards are handled."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    import os
+    # (ATDN_FORCE_COLLECTIVE=1: a one-rank group still goes through the collective — a plumbing test of the backend)
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size(group) == 1 and os.environ.get("ATDN_FORCE_COLLECTIVE") != "1"):
         assert local.shape[0] == n_pairs
         return local
     world = dist.get_world_size(group)

@@ -205,7 +205,11 @@ def main():
     rehearsal = os.environ.get("ATDN_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
-    if world > 1:
+    # ATDN_BENCH_FORCE_DIST=1: a ONE-rank launch still initialises the process group and runs every collective of the N > 1
+    # path (barriers, the max all-reduce, the all-gather of features) — on a one-GPU box that is RCCL itself at world size 1
+    # (tests/test_gpu_bench_rehearsal.py); with ATDN_BENCH_REHEARSAL it is gloo
+    dist_on = world > 1 or os.environ.get("ATDN_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         if rehearsal:
@@ -276,7 +280,7 @@ def main():
         # warm the tail too, at the length the timed region scans (the recurrent scan replays as one hipGraph per length)
         pipe.scan(torch.zeros((world * K * B, 512), device=dev))
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
         t0 = time.perf_counter()
@@ -287,17 +291,17 @@ def main():
         join()
         torch.cuda.current_stream().synchronize()
         t_tail = time.perf_counter()   # sequence tail: all-gather + ordered LSTM scan over all N*K*B features + rel2abs
-        allf = gather_features(feats[:K * B], world * K * B) if world > 1 else feats[:K * B]
+        allf = gather_features(feats[:K * B], world * K * B) if dist_on else feats[:K * B]
         rot, tr = pipe.scan(allf)
         poses = transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         dt = time.perf_counter() - t0
         tail_ms = (time.perf_counter() - t_tail) * 1e3
         assert tuple(poses.shape) == (world * K * B + 1, 4, 4) and bool(torch.isfinite(poses).all())
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # completion-to-completion intervals on the launch streams (steps overlap when S > 1)
         step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(S, K)] if K > S else [dt * 1e3 / K]
@@ -324,18 +328,18 @@ def main():
                     pipes[lane].features_clip(resize_frames(seq_dev[:n + 1]), continued=cont)
         join()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         timing = {}
         t0 = time.perf_counter()
         poses3 = pipe.run_sequence(cyc, batch=B, lanes=lanes, timing=timing)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         dt3 = time.perf_counter() - t0
         assert tuple(poses3.shape) == (T3, 4, 4) and bool(torch.isfinite(poses3).all())
         t3 = torch.tensor([dt3, timing["encode_s"], timing["gather_s"], timing["scan_s"]], device=dev, dtype=torch.float64)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(t3, op=dist.ReduceOp.MAX)
         c3 = [float(x) for x in t3.tolist()] + [T3]
 
@@ -429,7 +433,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(gsd, hsd, resize_frames(seq_dev[:6]))
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -52,3 +52,21 @@ def test_bench_config3_with_a_shard_shorter_than_one_clip():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["config3"]["pairs"] == 9 and d["config3"]["value"] > 0
+
+
+def test_bench_collectives_on_real_rccl_at_world_size_one():
+    """As much of the N > 1 path as ONE GPU can run on the real backend: `bench.py` under torch.distributed.run with one
+    rank, process group = nccl (RCCL), every barrier / all-reduce / all-gather of the multi-GPU path executed
+    (ATDN_BENCH_FORCE_DIST, ATDN_FORCE_COLLECTIVE), `config3` through run_sequence's gather included. Catches device / dtype /
+    ordering mistakes in the collective plumbing that gloo forgives; two ranks on real RCCL need the driver's 8-GPU node."""
+    env = dict(os.environ, ATDN_BENCH_FORCE_DIST="1", ATDN_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29621", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--config3-frames", "40"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config3"]["pairs"] == 39 and d["config3"]["value"] > 0
+    assert "REHEARSAL" not in d["data"]
