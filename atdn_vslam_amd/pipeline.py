@@ -98,6 +98,7 @@ class OdometryPipeline:
         self.head.load_state_dict(clvo_state)
         self.head = self.head.to(self.device).eval()
         self.padder = transforms.InputPadder((3,) + tuple(size))
+        self._lane_cache = {}   # run_sequence: lane streams and FrameIngest objects, kept for the life of the pipeline
 
     @torch.no_grad()
     def features(self, im1, im2):
@@ -149,7 +150,7 @@ class OdometryPipeline:
         L = len(pipes)
         # lane streams and ingest objects live as long as the pipeline (a new stream per call would also mean a new pool of
         # the caching allocator per call)
-        cache = self.__dict__.setdefault("_lane_cache", {})
+        cache = self._lane_cache
         with torch.cuda.device(self.device):
             if L == 1:
                 streams = [torch.cuda.current_stream()]
