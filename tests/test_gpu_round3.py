@@ -232,3 +232,20 @@ def test_clip_modes_are_bit_identical_to_pair_mode():
     for b in range(3):                                                                  # single pairs
         low_1, up_1 = net(fr[b:b + 1], fr[b + 1:b + 2], iters=4, test_mode=True)
         assert torch.equal(up_1, up_p[b:b + 1]), b
+
+
+def test_two_lane_sequence_driver_is_bit_identical_to_one_lane():
+    """The config3 leg walks a shard as two independent lanes (sharding.lane_ranges) on two streams with their own handles.
+    With the clip modes bit-identical (test above) the lane cut may not change a single bit of the trajectory: lane 1 merely
+    starts with a clip that is not continued. 45 frames = 44 pairs = lanes of 24 (3 clips of 8) and 20 (8 + 8 + 4) pairs; a
+    second call reuses the cached lane streams and ingest objects."""
+    gsd = syn.to_torch(syn.make_gma_state(seed=1))
+    hsd = syn.to_torch(syn.make_clvo_state(seed=1))
+    frames = _u8_frames(45, 376, 1241, seed=91).pin_memory()
+    pipe = OdometryPipeline(gsd, hsd, device=DEV, max_batch=8)
+    pipe2 = OdometryPipeline(gsd, hsd, device=DEV, max_batch=8)
+    one = pipe.run_sequence(frames, batch=8)
+    two = pipe.run_sequence(frames, batch=8, lanes=[pipe2])
+    assert tuple(two.shape) == (45, 4, 4) and torch.equal(two, one)
+    assert torch.equal(pipe.run_sequence(frames, batch=8, lanes=[pipe2]), one)
+    assert float(one[-1][:3, 3].norm()) > 0.1
