@@ -77,6 +77,15 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
     us_out[9] = ATDN_MB_SF6M(64, 2, 2);
 #undef ATDN_MB_SF6M
     us_out[10] = us_out[11] = 0.f;
+    us_out[12] = us_out[13] = us_out[14] = us_out[15] = 0.f;
+    if (KH == 3 && KW == 3) {
+      // 3x3 only: the tall (12x16 px) 64-wide block and the 96-wide 2x3-wave blocks (N = 192 as two of them)
+      us_out[12] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
+      if (N % 96 == 0) {
+        us_out[13] = time_it([&]() { launch_conv_sf6<8, 96, 2, 3, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
+        us_out[14] = time_it([&]() { launch_conv_sf6<12, 96, 2, 3, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
+      }
+    }
     if (KH == 1 && KW == 5 && N == 256 && C == 384) {
       // round 3: what the ConvGRU gate epilogue costs — the 128-wide block the pipeline uses, with SfBias and with SfGruZR
       float *hbuf, *zbuf, *rhbuf, *pre;
