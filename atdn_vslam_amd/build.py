@@ -1,6 +1,6 @@
 """Builds libatdn_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m atdn_vslam_amd.build [--force] [--microbench]
+    python -m atdn_vslam_amd.build [--force] [--microbench] [--variant NAME -DMACRO[=V] ...]
 
 --microbench also builds the diagnostic micro-benchmark library (tools/microbench/, ablation builds of the kernels): it is
 not part of the product and a break in it must not fail the product build, so it is only built on request
@@ -39,12 +39,12 @@ def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def _compile(src, objdir=OBJ, defines=()):
+    obj = os.path.join(objdir, src[:-4] + ".o")
     newest = max([_mtime(os.path.join(CSRC, src))] + [_mtime(h) for h in _headers()])
     if _mtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stdout))
@@ -53,24 +53,32 @@ def _compile(src):
     return obj, True
 
 
-def build(force=False, jobs=None, microbench=False):
-    """Compile every HIP translation unit for gfx950 and link the shared library. Returns its path."""
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, jobs=None, microbench=False, variant=None, defines=()):
+    """Compile every HIP translation unit for gfx950 and link the shared library. Returns its path.
+    `variant` + `defines`: a second build of the same sources with extra -D macros, into libatdn_hip_<variant>.so (its own
+    object directory): A/B timing of two builds inside one GPU job via ATDN_LIB_PATH. Diagnostics only, never loaded by default."""
+    objdir = OBJ if not variant else OBJ + "_" + variant
+    lib = LIB if not variant else os.path.join(HERE, "libatdn_hip_%s.so" % variant)
+    os.makedirs(objdir, exist_ok=True)
     if force:
-        for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+        for f in os.listdir(objdir):
+            os.remove(os.path.join(objdir, f))
     jobs = jobs or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        results = list(ex.map(_compile, _sources()))
+        results = list(ex.map(lambda src: _compile(src, objdir, tuple(defines)), _sources()))
     objs = [o for o, _ in results]
-    if any(changed for _, changed in results) or not os.path.exists(LIB) or _mtime(LIB) < max(_mtime(o) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs
+    if variant:
+        LIBV = lib
+    else:
+        LIBV = LIB
+    if any(changed for _, changed in results) or not os.path.exists(LIBV) or _mtime(LIBV) < max(_mtime(o) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIBV] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stdout)
-    if microbench:
+    if microbench and not variant:
         build_microbench()
-    return LIB
+    return LIBV
 
 
 def build_microbench():
@@ -88,4 +96,6 @@ def build_microbench():
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, microbench="--microbench" in sys.argv))
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    _defs = [a[2:] for a in sys.argv if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, microbench="--microbench" in sys.argv, variant=_variant, defines=_defs))

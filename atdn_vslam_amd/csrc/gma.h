@@ -85,6 +85,7 @@ class GmaNet {
   void iteration_sf(int B, hipStream_t st);
   void capture(int B, int iters);
   void launch_body(int B, int iters, hipStream_t st);
+  int enc_sub_ = 0;    // frames per depth-first pass of the encoders (0: all frames of a launch breadth-first)
   int seq_ = 0;        // 0: pair mode; 1: sequence (B+1 frames, every frame through fnet once); 2: sequence continued
                        //    (frame 0 is the previous call's last frame: its features are reused, fnet sees B frames)
   int last_frame_ = -1;  // fmap_ slot of the last frame of the previous sequence call

@@ -144,6 +144,7 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   lookup_legacy_ = precision == 0 || (getenv("ATDN_LOOKUP_LEGACY") && getenv("ATDN_LOOKUP_LEGACY")[0] == '1');
   attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
   mfma16_ = !(getenv("ATDN_CONV_M32") && getenv("ATDN_CONV_M32")[0] == '1');
+  if (const char* es = getenv("ATDN_ENC_SUB")) enc_sub_ = atoi(es);
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
   (void)hipGetDevice(&dev_);   // (no throw: argument errors must be reportable without a device; finalize() needs one anyway)
@@ -626,10 +627,23 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   // were already moved into fmap_ slot 0 by forward_sequence and only frames 1..B are encoded (img4_ still holds all
   // B+1 frames: the context network needs frame 0)
   const int nfeat = seq_ == 0 ? 2 * B : seq_ == 1 ? B + 1 : B;
-  run_encoder_sf(fnet_, true, nfeat, st, &f, seq_ == 2 ? 1 : 0);
-  ConvShape s = conv_shape(fnet_.head, f, 128, (long)N * 128, nfeat, H8, W8, 1, 0, 0);
-  float* fdst = fmap_.p + (seq_ == 2 ? (long)N * 256 : 0);
-  conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fdst, (long)N * 256, 256}, st);
+  ConvShape s;
+  // Depth-first over sub-batches of frames (enc_sub_ frames at most, sizes balanced): at 16 frames a 64-channel half-resolution
+  // map is 474 MB, so every conv -> conv hand-off of the breadth-first order is a round trip through HBM; with <= 3-4 frames per
+  // pass the producer's output and the consumer's input fit the 256 MiB Infinity Cache together. Frames are independent
+  // (InstanceNorm statistics are per image, tile heights follow from the geometry alone), so the bits do not change.
+  {
+    const int first = seq_ == 2 ? 1 : 0;
+    const int nsb = enc_sub_ > 0 ? cdiv(nfeat, enc_sub_) : 1;
+    for (int sb = 0, i0 = 0; sb < nsb; ++sb) {
+      const int n = nfeat / nsb + (sb < nfeat % nsb ? 1 : 0);
+      run_encoder_sf(fnet_, true, n, st, &f, first + i0);
+      s = conv_shape(fnet_.head, f, 128, (long)N * 128, n, H8, W8, 1, 0, 0);
+      float* fdst = fmap_.p + (long)(first + i0) * N * 256;
+      conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fdst, (long)N * 256, 256}, st);
+      i0 += n;
+    }
+  }
   mark(ST_FNET, st);
 
   ConvShape c;
@@ -671,10 +685,17 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   mark(ST_POOL, st);
   }
 
-  run_encoder_sf(cnet_, false, B, st, &f);
-  s = conv_shape(cnet_.head, f, 128, (long)N * 128, B, H8, W8, 1, 0, 0);
-  conv_sf_dispatch(s, cnet_.head.wscale,
-                   SfContextSplit{cnet_.head.b, h_[0].p, (long)N * 128, x_.p, (long)N * XLD, XLD}, st);
+  {
+    const int nsb = enc_sub_ > 0 ? cdiv(B, enc_sub_) : 1;
+    for (int sb = 0, i0 = 0; sb < nsb; ++sb) {
+      const int n = B / nsb + (sb < B % nsb ? 1 : 0);
+      run_encoder_sf(cnet_, false, n, st, &f, i0);
+      s = conv_shape(cnet_.head, f, 128, (long)N * 128, n, H8, W8, 1, 0, 0);
+      conv_sf_dispatch(s, cnet_.head.wscale,
+                       SfContextSplit{cnet_.head.b, h_[0].p + (long)i0 * N * 128, (long)N * 128, x_.p + (long)i0 * N * XLD, (long)N * XLD, XLD}, st);
+      i0 += n;
+    }
+  }
   mark(ST_CNET, st);
 
   s = conv_shape(to_qk_, x_.p, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
