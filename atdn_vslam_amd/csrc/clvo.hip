@@ -208,7 +208,8 @@ void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, f
     // Graph policy: a (T, Bs) is graphed only when it is seen for the SECOND time and T is moderate. A one-off
     // sequence (run_sequence scans all pairs of a KITTI sequence in one call, T ~ 4500) would pay capture + instantiation
     // of a multi-thousand-node graph for a single replay; the step is bound by its dependent launches' L2 round trips
-    // either way, so eager launches lose nothing there. bench.py warms and repeats one length: it replays.
+    // either way, so eager launches lose nothing there. A caller that repeats one length (bench.py) warms it TWICE:
+    // first sight runs eagerly, second sight captures, the timed call replays.
     const auto key = std::make_pair(T, Bs);
     const bool seen = scan_seen_.count(key) != 0;
     if (!seen && scan_seen_.size() < 4096) scan_seen_.insert(key);

@@ -597,13 +597,22 @@ void sf_counter_attach() {
   std::lock_guard<std::mutex> lock(g_sf_counter_mutex);
   (void)sf_counter_for_current_device(true);
 }
+// read-and-reset is ONE atomic exchange executed on the caller's stream (behind everything the caller has launched there):
+// a clamp that another stream's kernel records at any moment lands either in this read or in the next one, never between a
+// read and a separate zeroing (the two-step form could lose it)
+__global__ void sf_counter_exchange_kernel(unsigned int* counter, unsigned int* out) { *out = atomicExch(counter, 0u); }
 unsigned int sf_counter_read_reset(hipStream_t st) {
   std::lock_guard<std::mutex> lock(g_sf_counter_mutex);
   unsigned int* p = sf_counter_for_current_device(true);
+  unsigned int* slot = nullptr;
   unsigned int v = 0;
-  ATDN_HIP(hipStreamSynchronize(st));
-  ATDN_HIP(hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost));
-  ATDN_HIP(hipMemset(p, 0, sizeof(v)));
+  ATDN_HIP(hipMalloc(&slot, sizeof(unsigned int)));
+  hipLaunchKernelGGL(sf_counter_exchange_kernel, dim3(1), dim3(1), 0, st, p, slot);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&v, slot, sizeof(v), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(slot);
+  ATDN_HIP(e);
   return v;
 }
 

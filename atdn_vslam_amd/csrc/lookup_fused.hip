@@ -173,14 +173,17 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
   float2* const tab = ctab[wave][0];
   // pos = c + d; g = 2 pos / (S - 1) - 1; u = (g + 1) * ((S - 1) / 2); weight = u - floor(u);
   // grid index = clamp(floor(u) - window origin, 0, 10) + origin in the grid. The division is a multiplication by the correctly
-  // rounded reciprocal plus one FMA correction (Markstein): the correctly rounded quotient, the same bits as the division.
+  // rounded reciprocal plus one FMA correction step. That is the correctly rounded quotient whenever the first product is
+  // within one ulp of it (Markstein) — not a theorem for every (t, b); for the divisors this network has (W_l - 1, H_l - 1 of
+  // the four levels at C1 and C2) tests/test_host_arith.py checks the chain against the IEEE division over every position on
+  // a 1/64-pixel lattice across the maps plus 16 pixels of margin, so "the same bits as the division" holds where it is used.
   auto chain_to_table = [&](const Unit& u, int l, int buf) __attribute__((always_inline)) {
 #pragma clang fp contract(off)   // the same roundings in every unrolled copy (results must not depend on a pixel's slot)
     const float c0 = isx ? u.xc : u.yc;
     const int org = isx ? u.wx0 : u.wy0, gorg = isx ? u.wx0 - 8 * u.bx0 : u.wy0 - 4 * u.by0;
     const float t = 2.f * (c0 + cfd);
     float q = t * crs[l];
-    q = __builtin_fmaf(__builtin_fmaf(-q, csz[l], t), crs[l], q);          // = t / csz, correctly rounded
+    q = __builtin_fmaf(__builtin_fmaf(-q, csz[l], t), crs[l], q);          // = t / csz (see above)
     const float uu = ((q - 1.f) + 1.f) * chs[l];
     const float fl = floorf(uu);
     // (a unit that is not sane has its origin at -2^24: the clamp alone keeps the index inside the grid)

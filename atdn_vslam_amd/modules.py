@@ -86,6 +86,16 @@ class _NativeModule(nn.Module):
             return torch.device("cuda", torch.cuda.current_device())
         return p.device
 
+    def _require_input(self, t, what):
+        """Inputs must be on a HIP device, and on the SAME device as the module's parameters once those are on a GPU: handles
+        are keyed and created on the parameters' device (with parameters on cuda:0 and an input on cuda:1 the
+        handle used to be built on device 1 and cached under device 0's key)."""
+        _require_gpu(t, what)
+        p = next(self.parameters(), None)
+        if p is not None and p.is_cuda and p.device != t.device:
+            raise RuntimeError("%s: input on %s but the module's parameters are on %s — move one of them (.to()) first"
+                               % (what, t.device, p.device))
+
     def _key(self, H, W):
         """Native handles own weights and workspace on ONE device: keyed by (device index of the module's parameters, H, W),
         so a module moved with .to(other_gpu) builds a new handle there instead of launching on the old device's memory."""
@@ -111,6 +121,10 @@ class _NativeModule(nn.Module):
             pass
 
 
+# device index -> {"events", "count", "reader"}: what the per-device saturation counter has reported so far (check_saturation)
+_SAT_LEDGER = {}
+
+
 class RAFTGMA(_NativeModule):
     """GMA optical flow; `args` is the reference's GMA_Parameters-like object (only
     `num_heads`, `position_only`, `position_and_content` are consulted)."""
@@ -123,7 +137,9 @@ class RAFTGMA(_NativeModule):
         (0: never again), and `check_saturation()` can be called at any time (OdometryPipeline.run_sequence does, at the end
         of a sequence). A non-zero count raises SplitF16RangeError — or, with `saturation_fallback=True`, switches THIS
         module to precision="f32" (a new handle in the same process, a warning, `self.fell_back = True`) and recomputes the
-        forward that detected it, so the caller never receives a result computed with clamped activations."""
+        forward that detected it. What that guarantees: the forward that DETECTED the clamp is never returned clamped; forwards
+        between two checks (up to `saturation_check_every` - 1 of them) are only covered by the next check, which raises /
+        falls back then — OdometryPipeline.run_sequence checks every lane before the all-gather of a sequence."""
         super().__init__()
         self.args = args
         self.saturation_fallback = bool(saturation_fallback)
@@ -132,6 +148,7 @@ class RAFTGMA(_NativeModule):
         self.saturation_checks = 0      # how many times the counter has been read (tests)
         self._sat_pending = True        # a checkpoint whose first forward has not been checked yet
         self._sat_calls = 0
+        self._sat_seen = 0              # ledger count (per device) this module has already answered for
         self.precision = precision or os.environ.get("ATDN_PRECISION", "split_f16")
         if self.precision not in self.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
@@ -154,28 +171,43 @@ class RAFTGMA(_NativeModule):
         self._sat_pending = True        # new weights (load_state_dict / .to()): the next forward is checked again
 
     def check_saturation(self, raise_on_clamp=True):
-        """Reads (and resets) the split-f16 saturation counter of this module's device: the number of values that had to be
-        clamped to +-65504 (or were NaN) since the last read. Synchronises the current stream. The counter is per device, so
-        it covers every split-f16 handle of the process on that device."""
-        if self.precision == "f32" or not self._handles:
+        """Reads (and atomically resets) the split-f16 saturation counter of this module's device: the number of values that
+        had to be clamped to +-65504 (or were NaN) since the last read. Synchronises the current stream.
+        The hardware counter is ONE per device, shared by every handle of the process on that device (lanes of run_sequence,
+        a f16 handle beside a split-f16 one), so whichever module reads first takes everybody's count. The count is
+        therefore published in a per-device ledger (`_SAT_LEDGER`): every split-f16 / f16 module of that device that has a
+        live handle sees an event it has not yet reacted to at ITS next check and raises (or falls back) too — a clamp
+        can be attributed too widely, never swallowed. Returns the count this module must answer for (the ledger entries it
+        had not seen); an f32 module still reads and publishes, and returns 0."""
+        if not self._handles:
             return 0
         dev = self._device()
         out = torch.empty(1, dtype=torch.float32)
         with torch.cuda.device(dev):
-            h = next(ent[0] for key, ent in self._handles.items() if key[0] == dev.index)
-            n = _lib.lib().atdn_gma_debug_read(h, b"sf_clamped", C.c_void_p(out.data_ptr()), 1, _stream())
+            key, ent = next((key, ent) for key, ent in self._handles.items() if key[0] == dev.index)
+            n = _lib.lib().atdn_gma_debug_read(ent[0], b"sf_clamped", C.c_void_p(out.data_ptr()), 1, _stream())
         if n < 0:
             _lib.check(1)
+        led = _SAT_LEDGER.setdefault(dev.index, {"events": 0, "count": 0, "reader": None})
+        fresh = int(out[0])
+        if fresh:
+            led["events"] += 1
+            led["count"] += fresh
+            led["reader"] = "RAFTGMA handle %#x (%s, %dx%d)" % (ent[0].value or 0, self.precision, key[1], key[2])
+        if self.precision == "f32":
+            self._sat_seen = led["count"]
+            return 0
         self.saturation_checks += 1
         self._sat_pending = False
         self._sat_calls = 0
-        clamped = int(out[0])
+        clamped = led["count"] - self._sat_seen
+        self._sat_seen = led["count"]
         if clamped and raise_on_clamp:
             raise SplitF16RangeError(
-                "%d activation(s) of the flow network left the range of the split-f16 format (|x| > 65504, or NaN): with this "
-                "checkpoint the default arithmetic is not fp32-grade. Construct the module with precision=\"f32\" (or set "
-                "ATDN_PRECISION=f32; the C ABI calls this mode ATDN_PRECISION_F32) to run every GEMM on the exact-fp32 matrix "
-                "core instead." % clamped)
+                "%d activation(s) of the flow network left the range of the split-f16 format (|x| > 65504, or NaN) on %s "
+                "(counter is per device; last read through %s): with this checkpoint the default arithmetic is not fp32-grade. "
+                "Construct the module with precision=\"f32\" (or set ATDN_PRECISION=f32; the C ABI calls this mode "
+                "ATDN_PRECISION_F32) to run every GEMM on the exact-fp32 matrix core instead." % (clamped, dev, led["reader"]))
         return clamped
 
     def _after_forward(self):
@@ -214,6 +246,9 @@ class RAFTGMA(_NativeModule):
             _lib.load_state(L.atdn_gma_load, h, self.state_dict())
             _lib.check(L.atdn_gma_finalize(h))
             ent = (h, fp, L.atdn_gma_destroy, mb)
+            if not any(k[0] == key[0] for k in self._handles):
+                # first handle of this module on the device: clamps recorded before it existed are not its own
+                self._sat_seen = _SAT_LEDGER.get(key[0], {"count": 0})["count"]
             self._handles[key] = ent
         return ent[0]
 
@@ -222,7 +257,7 @@ class RAFTGMA(_NativeModule):
         if not test_mode:
             raise NotImplementedError("only the inference contract (test_mode=True) is built; the per-iteration "
                                       "training outputs of network.py:129 are out of scope")
-        _require_gpu(image1, "RAFTGMA.forward")
+        self._require_input(image1, "RAFTGMA.forward")
         if image1.shape != image2.shape or image1.dim() != 4 or image1.shape[1] != 3:
             raise RuntimeError("expected two [B,3,H,W] frames, got %s and %s" % (tuple(image1.shape), tuple(image2.shape)))
         B, _, H, W = image1.shape
@@ -253,7 +288,7 @@ class RAFTGMA(_NativeModule):
         clip of the same sequence); its features are reused and only frames[1:] go through the feature network.
         Same bits as the non-continued call and as pair mode (round 3: the kernels' statistics grouping no longer depends on
         how many images share a launch; tests/test_gpu_round3.py)."""
-        _require_gpu(frames, "RAFTGMA.forward_sequence")
+        self._require_input(frames, "RAFTGMA.forward_sequence")
         if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[0] < 2:
             raise RuntimeError("expected frames [B+1,3,H,W] with B >= 1, got %s" % (tuple(frames.shape),))
         if self.precision not in ("split_f16", "f16"):
@@ -351,7 +386,7 @@ class ATDNVO(_NativeModule):
     @torch.no_grad()
     def encode(self, flows):
         """Stateless part: flows [B,2,H,W] -> 512-d features (shardable across frame pairs)."""
-        _require_gpu(flows, "ATDNVO.encode")
+        self._require_input(flows, "ATDNVO.encode")
         if flows.dim() != 4 or flows.shape[1] != 2:
             raise RuntimeError("expected flows [B,2,H,W], got %s" % (tuple(flows.shape),))
         B, _, H, W = flows.shape
@@ -364,7 +399,7 @@ class ATDNVO(_NativeModule):
     @torch.no_grad()
     def scan(self, feats, state=None, hw=(376, 1232)):
         """Ordered recurrence over feats [T,Bs,512]; returns (rot [T,Bs,3], tr [T,Bs,3], state [4,Bs,512])."""
-        _require_gpu(feats, "ATDNVO.scan")
+        self._require_input(feats, "ATDNVO.scan")
         T, Bs, _ = feats.shape
         with torch.cuda.device(feats.device):
             f = feats.float().contiguous()
@@ -423,7 +458,7 @@ class MappingVAE(_NativeModule):
 
     @torch.no_grad()
     def forward(self, image):
-        _require_gpu(image, "MappingVAE.forward")
+        self._require_input(image, "MappingVAE.forward")
         if image.dim() == 3:
             image = image.unsqueeze(0)
         if image.dim() != 4 or image.shape[1] != 3:

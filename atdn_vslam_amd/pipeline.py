@@ -180,17 +180,23 @@ class OdometryPipeline:
             for st in streams:
                 main.wait_stream(st)
 
+        def finish():
+            # split-f16 saturation guard, once per sequence and BEFORE the all-gather: EVERY lane's module is checked (the
+            # counter is per device and whoever reads first takes the count: modules.RAFTGMA.check_saturation publishes it in a
+            # per-device ledger, so no lane can swallow another lane's clamp), and a SplitF16RangeError raised here travels
+            # through the gather to every rank (sharding.gather_features) instead of leaving them blocked in it
+            join()
+            for p in pipes:
+                p.flow_net.check_saturation()
+
         encode_clip.device = self.device
         encode_clip.join = join
+        encode_clip.finish = finish
         encode_clip.sync = lambda: torch.cuda.synchronize(self.device)
         if L > 1:
             for st in streams:
                 st.wait_stream(main)
         rot, tr = sharded_sequence(T, encode_clip, self.scan, batch, group, lanes=L, timing=timing)
-        # split-f16 saturation guard: one counter read per sequence (the first forward of a fresh checkpoint was checked
-        # inside forward_sequence already); raises SplitF16RangeError if anything was clamped on this rank's shard
-        # (the counter is per device: it covers every lane)
-        self.flow_net.check_saturation()
         return transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
 
 

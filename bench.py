@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 from atdn_vslam_amd import synthetic as syn  # noqa: E402
 from atdn_vslam_amd import transforms  # noqa: E402
 from atdn_vslam_amd.pipeline import FrameIngest, OdometryPipeline, resize_frames  # noqa: E402
-from atdn_vslam_amd.sharding import gather_features  # noqa: E402
+from atdn_vslam_amd.sharding import gather_features, rendezvous  # noqa: E402
 
 H_KITTI, W_KITTI = 376, 1241
 H, W = 376, 1232
@@ -117,6 +117,9 @@ def kernel_table(stages, B):
             row["mfma_executed_frac"] = row["mfma_executed_tflops"] / PEAK_F16_MFMA_TFLOPS
             row["stored_bytes_per_launch"] = nn * 3.0 * B
             row["frac_stored_bytes"] = nn * 3.0 * B / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
+        if stage == "corr":
+            # what the level-0 correlation must move: the fp32 volume written once + the two feature maps read once
+            row["algorithmic_bytes_per_launch"] = (nn * 4.0 + 2.0 * N8 * 256 * 4.0) * B
         rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_forward"])
     return rows
@@ -151,27 +154,40 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(gsd, hsd, frames, budget_s=25.0):
-    """The CPU oracle (a port of the reference's PyTorch-CPU op sequence) on this host's cores, bounded sample."""
+def cpu_baseline(gsd, hsd, frames, budget_s=12.0, budget_1t_s=16.0):
+    """The CPU oracle (a port of the reference's PyTorch-CPU op sequence) on this host's cores, bounded sample: all usable
+    cores first (warm-up pair + up to 3 timed pairs), then ONE pair on a single thread (SURVEY 8d asks for both figures; a
+    pair takes ~15 s on one core, so that leg is one pair, warmed by the all-cores leg). Returns (all_cores, one_thread)."""
     from oracle import clvo_ref, gma_ref
     cores = usable_cores()
-    torch.set_num_threads(cores)
     fr = frames.cpu()
-    state = clvo_ref.zero_state(1)
-    times = []
-    t_all = time.time()
-    for i in range(min(4, fr.shape[0] - 1)):
-        t0 = time.time()
-        _, up = gma_ref.gma_forward(gsd, fr[i:i + 1], fr[i + 1:i + 2], iters=ITERS)
-        _, _, state = clvo_ref.clvo_forward(hsd, up, state)
-        times.append(time.time() - t0)
-        if time.time() - t_all > budget_s:
-            break
+
+    def run(threads, max_pairs, budget):
+        torch.set_num_threads(threads)
+        state = clvo_ref.zero_state(1)
+        times = []
+        t_all = time.time()
+        for i in range(min(max_pairs, fr.shape[0] - 1)):
+            t0 = time.time()
+            _, up = gma_ref.gma_forward(gsd, fr[i:i + 1], fr[i + 1:i + 2], iters=ITERS)
+            _, _, state = clvo_ref.clvo_forward(hsd, up, state)
+            times.append(time.time() - t0)
+            if time.time() - t_all > budget:
+                break
+        return times
+
+    times = run(cores, 4, budget_s)
     timed = times[1:] if len(times) > 1 else times  # first pair is warm-up
     sec = float(np.median(timed))
-    return {"value": 1.0 / sec, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+    allc = {"value": 1.0 / sec, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
             "sample": "%d pair(s) after 1 warm-up, 376x1232, %d iters, fp32, torch CPU ops, median %.3f s/pair"
                       % (len(timed), ITERS, sec)}
+    t1 = run(1, 1, budget_1t_s)
+    one = {"value": 1.0 / t1[0], "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+           "sample": "1 pair on 1 thread (no separate warm-up: the all-cores leg ran first), 376x1232, %d iters, fp32, "
+                     "torch CPU ops, %.3f s/pair" % (ITERS, t1[0])}
+    torch.set_num_threads(cores)
+    return allc, one
 
 
 MFMA_PER_PRODUCT = {"split_f16": 3, "f16": 1, "f32": 1}   # MFMAs the engine executes per algorithmic product
@@ -273,25 +289,42 @@ def main():
         nonlocal calls
         calls = [0] * S
         nw = max(Wm, 2 * S)
-        for i in range(nw):
-            step(i, feats, slot=i % nw, host=host)
-        calls = [0] * S   # the timed region starts a fresh sequence on every pipeline: nothing computed earlier is reused
-        join()
-        # warm the tail too, at the length the timed region scans (the recurrent scan replays as one hipGraph per length)
-        pipe.scan(torch.zeros((world * K * B, 512), device=dev))
-        torch.cuda.synchronize()
+        err = None
+        try:
+            for i in range(nw):
+                step(i, feats, slot=i % nw, host=host)
+            calls = [0] * S   # the timed region starts a fresh sequence on every pipeline: nothing computed earlier is reused
+            join()
+            # warm the tail too, at the length the timed region scans (the recurrent scan graphs a length on second sight:
+            # two calls, so that the timed scan REPLAYS — ADVICE r3: capture used to land inside the timed region)
+            for _ in range(2):
+                pipe.scan(torch.zeros((world * K * B, 512), device=dev))
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001 — one rank failing in warm-up must not leave the others in the barrier
+            err = e
+        # barrier that agrees on failure (sharding.rendezvous: one small all-gather of status rows; every rank raises if
+        # any rank did), then the contract's plain barrier
+        rendezvous(err, device=dev)
         if dist_on:
             dist.barrier()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
         t0 = time.perf_counter()
         ev[0].record()
-        for i in range(K):
-            step(i, feats, host=host)
-            ev[i + 1].record(streams[i % S])
-        join()
-        torch.cuda.current_stream().synchronize()
+        try:
+            for i in range(K):
+                step(i, feats, host=host)
+                ev[i + 1].record(streams[i % S])
+            join()
+            torch.cuda.current_stream().synchronize()
+        except Exception as e:   # noqa: BLE001 — carried through the all-gather below and raised on EVERY rank
+            err = e
         t_tail = time.perf_counter()   # sequence tail: all-gather + ordered LSTM scan over all N*K*B features + rel2abs
-        allf = gather_features(feats[:K * B], world * K * B) if dist_on else feats[:K * B]
+        if dist_on:
+            allf = gather_features(None if err is not None else feats[:K * B], world * K * B, error=err, device=dev)
+        elif err is not None:
+            raise err
+        else:
+            allf = feats[:K * B]
         rot, tr = pipe.scan(allf)
         poses = transforms.rel2abs(rot.cpu().numpy(), tr.cpu().numpy())
         torch.cuda.synchronize()
@@ -321,13 +354,18 @@ def main():
         # warm every (clip length, continued) graph the plan needs, on every lane, outside the timed region
         from atdn_vslam_amd.sharding import clip_plan, lane_ranges, shard_range
         lo3, hi3 = shard_range(T3 - 1, rank, world)
-        for lane, (a, b) in enumerate(lane_ranges(lo3, hi3, B, S)):
-            need = sorted({(e - s, c) for (s, e, c) in clip_plan(a, b, B)}, key=lambda t: (t[1], -t[0]))
-            with torch.cuda.stream(streams[lane]):
-                for (n, cont) in need:
-                    pipes[lane].features_clip(resize_frames(seq_dev[:n + 1]), continued=cont)
-        join()
-        torch.cuda.synchronize()
+        err3 = None
+        try:
+            for lane, (a, b) in enumerate(lane_ranges(lo3, hi3, B, S)):
+                need = sorted({(e - s, c) for (s, e, c) in clip_plan(a, b, B)}, key=lambda t: (t[1], -t[0]))
+                with torch.cuda.stream(streams[lane]):
+                    for (n, cont) in need:
+                        pipes[lane].features_clip(resize_frames(seq_dev[:n + 1]), continued=cont)
+            join()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            err3 = e
+        rendezvous(err3, device=dev)
         if dist_on:
             dist.barrier()
         timing = {}
@@ -364,6 +402,16 @@ def main():
         # in the call form the timed loop uses: a CONTINUED clip (B feature-network passes, not the 2B of pair mode)
         st = pipe.flow_net.profile(H, W, B, iters=ITERS, reps=reps, mode="continued")
         rows = kernel_table(st, B)
+        # HBM-side bytes per launch from the committed PMC passes (NOT this run: `traffic_source` names the file) on every row
+        # whose kernel the profile holds, and their ratio to the row's algorithmic bytes — the lookup and the level-0
+        # correlation are the two kernels that move more than they must
+        for r in rows:
+            tb, src = pmc_traffic(r["rocprof_name_contains"], B)
+            if tb is not None:
+                r["traffic"], r["traffic_source"] = tb, src
+                ab = r.get("algorithmic_bytes_per_launch", r["algorithmic_per_launch"] if r["bound"] == "hbm" else None)
+                if ab:
+                    r["traffic_ratio"] = tb / ab
         top = rows[0]
         traffic, traffic_src = pmc_traffic(top["rocprof_name_contains"], B)
         fwd_ms = float(np.median(step_ms))
@@ -390,7 +438,7 @@ def main():
                          # and of the timed step (two streams overlapping: completion-to-completion interval)
                          "share_of_forward": top["ms_per_forward"] / sum(st.values()),
                          "share_of_timed_step": top["ms_per_forward"] / fwd_ms},
-            "kernels": rows[:5],
+            "kernels": rows[:5] + [r for r in rows[5:] if r["stage"] in ("lookup", "corr")],
             "stages_mode": "continued clip (B feature-network passes per B pairs): the call form the timed loop uses",
             "forward": {"ms_per_batch_median": fwd_ms,
                         "tflops_algorithmic_0.951_per_pair": FLOP_PER_PAIR * B / (fwd_ms * 1e-3) / 1e12,
@@ -431,7 +479,7 @@ def main():
                                     "ratio_to_value": (total_pairs / h2d[0]) / (total_pairs / dt),
                                     "host_bytes_per_step": (B + 1) * 3 * H_KITTI * W_KITTI}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only (rank 0)
-            out["cpu_baseline"] = cpu_baseline(gsd, hsd, resize_frames(seq_dev[:6]))
+            out["cpu_baseline"], out["cpu_baseline_1thread"] = cpu_baseline(gsd, hsd, resize_frames(seq_dev[:6]))
         print(json.dumps(out))
     if dist_on:
         dist.barrier()

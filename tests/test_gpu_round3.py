@@ -157,7 +157,9 @@ def test_split_f16_validity_sweep_c1(label, scales):
     assert clamped == 0, label
     # fp32-grade: inside the stated tolerances, or — where the rescaled network itself amplifies rounding beyond them, which
     # the exact-fp32 MFMA mode then shows too — no worse than 3x that mode's own distance from the CPU path
-    assert e1l <= max(2e-4 * scale, 3 * e0l) and e1u <= max(1e-3 * scale, 3 * e0u), (label, e1l, e0l, e1u, e0u, scale)
+    # (that second clause is capped at 10x the stated tolerance — "as good as f32" is no licence for any distance)
+    assert e1l <= max(2e-4 * scale, min(3 * e0l, 10 * 2e-4 * scale)), (label, e1l, e0l, scale)
+    assert e1u <= max(1e-3 * scale, min(3 * e0u, 10 * 1e-3 * scale)), (label, e1u, e0u, scale)
 
 
 def test_split_f16_validity_c2_sharp_attention_and_large_correlation():
@@ -173,18 +175,103 @@ def test_split_f16_validity_c2_sharp_attention_and_large_correlation():
 
 
 def test_h3_encode_saturation_is_counted():
-    """the H3 attention store converts exp(s - rowmax~) * 2^10 to f16. With logits that exceed the first-pass
-    (f16 x f16) row maximum by more than ~4.16 the value passes 65504: it is now clamped and counted instead of becoming inf.
-    Weights that make the f16 first pass inaccurate: a to_qk scaled by 64 (logits of the order of 10^3-10^4)."""
-    sd = _scaled_state({"att.to_qk": 64.0})
+    """ADVICE r2 / VERDICT r3: the H3 attention store converts exp(s - rowmax~) * 2^10 to f16, where rowmax~ comes from the
+    cheap first sweep (f16 x f16 logits: the hi halves of q and k only). A full-precision logit more than ~4.16 above that
+    maximum passes 65504: the store clamps AND counts. Built to overflow: to_qk x512 makes the logits ~2.6e5 times the
+    checkpoint's, so the hi-only sweep is off by tens of units on every row while q and k themselves stay far inside the f16
+    range — the count must be NON-ZERO (it asserted `>= 0` before), nothing may become inf / NaN, and the guard must raise."""
+    sd = _scaled_state({"att.to_qk": 512.0})
     fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=3))
     net = RAFTGMA(saturation_check_every=0)
     net.load_state_dict(sd)
     net = net.to(DEV).eval()
     net._sat_pending = False                                # look at the counter by hand
     low, up = net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=2, test_mode=True)
+    qk = net.debug_read("qk", (1, 20 * 64, 256), 160, 512)
+    assert float(qk.abs().max()) < 6e4                      # q, k are representable: what clamps is the H3 store
     assert bool(torch.isfinite(up).all())                   # no inf / NaN reaches the output whichever way the rows fall
-    assert net.check_saturation(raise_on_clamp=False) >= 0
+    attn = net.debug_read("attn", (1, 20 * 64, 20 * 64), 160, 512)
+    assert bool(torch.isfinite(attn).all())
+    n = net.check_saturation(raise_on_clamp=False)
+    print("H3 clamps counted:", n)
+    assert n > 0
+    net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=2, test_mode=True)
+    with pytest.raises(SplitF16RangeError):
+        net.check_saturation()
+
+
+def test_split_f16_validity_c2_one_hot_attention_rows():
+    """the synthetic checkpoint's attention rows are nearly uniform; trained GMA attention is peaked. to_qk x16
+    (logits x256) makes every row one-hot at the headline size — the regime where H3's one residual byte and the first-pass
+    f16 row maximum matter — and the whole flow is compared with the CPU oracle on the same checkpoint, 12 iterations."""
+    for f in (8.0, 16.0):
+        sd = _scaled_state({"att.to_qk": f})
+        fr = torch.from_numpy(syn.make_frames(2, 376, 1232, seed=11))
+        ref_low, ref_up = gma_ref.gma_forward(sd, fr[0:1], fr[1:2], iters=12)
+        net = RAFTGMA(precision="split_f16")
+        net.load_state_dict(sd)
+        net = net.to(DEV).eval()
+        low1, up1 = net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=12, test_mode=True)
+        clamped = net.check_saturation(raise_on_clamp=False)
+        N = 47 * 154
+        attn = net.debug_read("attn", (1, N, 7264), 376, 1232)[0, :, :N]
+        peak = attn.max(dim=1).values
+        scale = max(1.0, float(ref_low.abs().max()) / 16.0)
+        el, eu = float((low1.cpu() - ref_low).abs().max()), float((up1.cpu() - ref_up).abs().max())
+        print("to_qk x%g: median row peak %.3f, rows with peak > 0.9: %.1f %%, flow_low err %.2e, flow_up err %.2e, clamped %d"
+              % (f, float(peak.median()), 100.0 * float((peak > 0.9).float().mean()), el, eu, clamped))
+        assert clamped == 0
+        assert float((attn.sum(dim=1) - 1.0).abs().max()) < 1e-4
+        assert el <= 2e-4 * scale and eu <= 1e-3 * scale, (f, el, eu, scale)
+    assert float(peak.median()) > 0.5     # x16: the rows really are peaked
+
+
+def test_a_clamp_cannot_be_swallowed_by_another_module_of_the_device():
+    """VERDICT r3 / ADVICE r3 (medium): the saturation counter is one per device, read-and-reset (now one atomic exchange) by
+    whichever module checks first. Module A runs a saturating checkpoint unchecked; module B (healthy checkpoint, same device)
+    checks first and takes A's count. The count is published per device, so B raises (too wide, never too narrow) AND A still
+    raises at its own next check; a module created afterwards does not inherit the old event."""
+    bad = _scaled_state({"cnet.conv1": 3e5})
+    good = syn.to_torch(syn.make_gma_state(seed=1))
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=3)).to(DEV)
+
+    def module(sd):
+        m = RAFTGMA(saturation_check_every=0)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        m._sat_pending = False
+        return m
+
+    A, Bm = module(bad), module(good)
+    Bm(fr[0:1], fr[1:2], iters=1, test_mode=True)
+    assert Bm.check_saturation() == 0
+    A(fr[0:1], fr[1:2], iters=1, test_mode=True)           # clamps, unchecked
+    with pytest.raises(SplitF16RangeError):
+        Bm.check_saturation()                                # B reads the device counter first ...
+    with pytest.raises(SplitF16RangeError):
+        A.check_saturation()                                 # ... and A still answers for it
+    assert A.check_saturation() == 0 and Bm.check_saturation() == 0   # one event, reported once per module
+    Cm = module(good)
+    Cm(fr[0:1], fr[1:2], iters=1, test_mode=True)
+    assert Cm.check_saturation() == 0                        # created after the event: not its own
+
+
+def test_run_sequence_checks_every_lane_before_the_gather():
+    """A lane whose checkpoint saturates: run_sequence's end-of-shard check covers every lane module (not only lane 0) and
+    raises BEFORE the all-gather (sharding.sharded_sequence carries it to every rank; tests/test_sharding.py)."""
+    gsd = syn.to_torch(syn.make_gma_state(seed=1))
+    hsd = syn.to_torch(syn.make_clvo_state(seed=1))
+    bad = _scaled_state({"cnet.conv1": 3e5})
+    main = OdometryPipeline(gsd, hsd, device=DEV, max_batch=2, iters=2)
+    lane = OdometryPipeline(bad, hsd, device=DEV, max_batch=2, iters=2)
+    for p in (main, lane):
+        p.flow_net.saturation_check_every = 0
+        p.flow_net._sat_pending = False                      # only the end-of-sequence check is left
+    frames = _u8_frames(9, 376, 1241, seed=77).pin_memory()
+    with pytest.raises(SplitF16RangeError):
+        main.run_sequence(frames, batch=2, lanes=[lane])
+    poses = main.run_sequence(frames, batch=2)               # the healthy pipeline alone still runs
+    assert tuple(poses.shape) == (9, 4, 4)
 
 
 # ------------------------------------------------------------------------------------------- MFMA shape of the halo convolutions

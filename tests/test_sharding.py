@@ -89,3 +89,56 @@ def test_sharded_odometry_matches_single_process(tmp_path, world, n_pairs):
     a = np.load(os.path.join(str(tmp_path), "rank0.npz"))
     b = np.load(os.path.join(str(tmp_path), "rank%d.npz" % (world - 1)))
     assert np.array_equal(a["rot"], b["rot"]) and np.array_equal(a["tr"], b["tr"])  # rank-identical
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,bad_rank,kind", [(2, 1, "SplitF16RangeError"), (2, 0, "RuntimeError"), (3, 1, "RuntimeError"),
+                                                 (3, 2, "SplitF16RangeError")])
+def test_a_failing_rank_raises_on_every_rank(tmp_path, world, bad_rank, kind):
+    """an exception in one rank's shard (the saturation guard's SplitF16RangeError, or any RuntimeError) used
+    to leave the other ranks blocked in all_gather_into_tensor until the RCCL watchdog fired. Now the failing rank still joins
+    the ONE all-gather with a status row inside its padded block and EVERY rank raises ShardError naming the first failing
+    rank — within seconds — through the sequence driver (one and two lanes), sharded_odometry, a bare gather_features
+    (bench.py's timed loop) and the rendezvous barrier; afterwards the group is still in step."""
+    import json
+    port = 29700 + world * 11 + bad_rank * 3 + len(kind)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_dist_fail_worker.py"), str(tmp_path), str(bad_rank), kind]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    for rank in range(world):
+        rep = json.load(open(os.path.join(str(tmp_path), "fail_rank%d.json" % rank)))
+        for key in ("seq1", "seq2"):
+            got = rep[key]
+            assert isinstance(got, dict), (rank, key, got)          # every rank raised
+            assert got["rank"] == bad_rank and got["type"] == kind and "synthetic failure of rank %d" % bad_rank in got["msg"]
+            assert got["s"] < 20.0, got                              # and did not wait for a watchdog
+            assert got["cause"] == (kind if rank == bad_rank else None)   # the failing rank keeps its own traceback
+        for key in ("odo", "gather", "rendezvous"):
+            assert isinstance(rep[key], dict) and rep[key]["rank"] == bad_rank and rep[key]["type"] == kind, (rank, key, rep[key])
+        assert rep["clean_ok"] is True
+
+
+def test_failure_status_row_roundtrip():
+    """The status row inside the gathered block: flag, length, message bytes — also when the row is narrower than the text."""
+    from atdn_vslam_amd.sharding import ShardError, _first_failure, _status_row
+    ok = _status_row(None, 512, torch.float32, "cpu")
+    assert float(ok.abs().sum()) == 0.0
+    bad = _status_row(ValueError("bad frame 17 é"), 512, torch.float32, "cpu")
+    rows = torch.cat([ok, bad, _status_row(RuntimeError("later"), 512, torch.float32, "cpu")])
+    assert _first_failure(rows) == (1, "ValueError", "bad frame 17 é")
+    assert _first_failure(torch.cat([ok, ok])) is None
+    narrow = _status_row(RuntimeError("x" * 100), 8, torch.float32, "cpu")
+    r, typ, msg = _first_failure(narrow)
+    assert r == 0 and (typ + ": " + msg).startswith("Runtim") and narrow.shape == (1, 8)
+    e = ShardError(3, "SplitF16RangeError", "clamped")
+    assert e.rank == 3 and "rank 3" in str(e) and isinstance(e, RuntimeError)
+    # without a process group the error is simply re-raised / passed through
+    from atdn_vslam_amd.sharding import gather_features, rendezvous
+    with pytest.raises(KeyError):
+        gather_features(None, 4, error=KeyError("k"))
+    with pytest.raises(KeyError):
+        rendezvous(KeyError("k"))
+    rendezvous(None)
