@@ -62,6 +62,8 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "atdn_conv2d_nhwc_sf": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "atdn_conv2d_nhwc_sf_epi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
 }
 
 GMA_STAGES = ("fnet", "corr", "pool", "cnet", "attention", "lookup", "motion_encoder", "aggregate", "gru_zr", "gru_q",

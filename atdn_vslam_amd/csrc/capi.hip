@@ -394,17 +394,12 @@ int atdn_ingest_frames_u8(atdn_ingest* h, const uint8_t* host_frames, int n_fram
 }
 void atdn_ingest_destroy(atdn_ingest* h) { delete h; }
 
-int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
-                        const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, float* dst,
-                        void* stream) {
+int atdn_conv2d_nhwc_sf_epi(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
+                            const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, int sf_store,
+                            float* dst, void* stream) {
   ATDN_API_BEGIN
   ATDN_CHECK(src && weight_host && dst && nimg >= 1 && Cin % 32 == 0, "bad argument (Cin must be a multiple of 32)");
-  // MFMA shape of the halo kernels for this call (tests compare both): ATDN_CONV_M32=1 selects the 32x32x16 loop
-  struct ShapeGuard {
-    bool prev = sf_mfma16();
-    ShapeGuard() { const char* e = getenv("ATDN_CONV_M32"); sf_mfma16() = !(e && e[0] == '1'); }
-    ~ShapeGuard() { sf_mfma16() = prev; }
-  } shape_guard;
+  ATDN_CHECK(!sf_store || Cout % 32 == 0, "the split-f16 store needs Cout % 32 == 0");
   StateDict sd;
   const int64_t ws[4] = {Cout, Cin, KH, KW};
   sd.put("c.weight", weight_host, ws, 4);
@@ -426,11 +421,10 @@ int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const
     s.KH = KH; s.KW = KW; s.stride = stride; s.padH = padH; s.padW = padW;
     s.w = L.w; s.ldw = L.ldw; s.N = Cout; s.nimg = nimg;
     const int Ho = conv_out(H, KH, stride, padH), Wo = conv_out(W, KW, stride, padW);
-    s.wfrag = L.wf; s.wfrag16 = L.wf16;
-    // ATDN_SF_CONV_EPILOGUE=sf (tests): write split-f16 through the SfBias epilogue, then unpack — exercises the
-    // channel-vector sf store; needs Cout % 32 == 0. Default: fp32 output through EpiBias.
-    const char* mode = getenv("ATDN_SF_CONV_EPILOGUE");
-    if (mode && mode[0] == 's' && Cout % 32 == 0) {
+    s.wfrag16 = L.wf16;
+    // sf_store: write split-f16 through the SfBias epilogue (the channel-vector sf store of the product's layers), then
+    // unpack to fp32; otherwise fp32 output through EpiBias
+    if (sf_store) {
       float* osf = nullptr;
       const long orows = (long)nimg * Ho * Wo;
       ATDN_HIP(hipMalloc(&osf, (size_t)orows * Cout * sizeof(float)));
@@ -455,6 +449,12 @@ int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const
   (void)hipFree(tmp);
   A.release();
   ATDN_API_END
+}
+
+int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
+                        const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, float* dst,
+                        void* stream) {
+  return atdn_conv2d_nhwc_sf_epi(src, nimg, H, W, Cin, weight_host, bias_host, Cout, KH, KW, stride, padH, padW, 0, dst, stream);
 }
 
 }  // extern "C"

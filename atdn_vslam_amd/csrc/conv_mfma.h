@@ -271,7 +271,6 @@ struct ConvShape {  // what the caller describes; ConvGeom is derived from it
   int H = 1, W = 1;
   int KH = 1, KW = 1, stride = 1, padH = 0, padW = 0;
   const float* w = nullptr; long wb = 0; int ldw = 0;
-  const float* wfrag = nullptr;  // fragment-major sf copy of w (weights.h pack_fragment_major), optional
   const float* wfrag16 = nullptr;   // ... in the operand order of the 16x16x32 MFMA (pack_fragment_major16), optional
   int N = 0;
   int nimg = 1;

@@ -1,12 +1,12 @@
 // Implicit-GEMM convolution / batched NT-GEMM on the f16 matrix core with split-f16 ("sf", sf.h) operands:
-//   A·B ≈ A_hi·B_hi + A_hi·B_lo + A_lo·B_hi        (three v_mfma_f32_32x32x16_f16, fp32 accumulate)
+//   A·B ≈ A_hi·B_hi + A_hi·B_lo + A_lo·B_hi        (three v_mfma_f32_16x16x32_f16, fp32 accumulate)
 // f16 x f16 products are exact in fp32 and the dropped lo·lo term is 2^-22 relative, so the result is fp32-grade
 // while the matrix pipe runs at 16/3 = 5.3x the rate of v_mfma_f32_32x32x2_f32.
 //
 // Same tiling, gather (TAP mode only: channel counts are multiples of 32), virtual concat, per-image M tiling,
 // XCD remap and epilogue interface as conv_mfma.h. Differences:
 // * operands are sf tensors: a 128-byte K-chunk of a pixel is [32 hi | 32 lo] halves, copied verbatim to LDS
-//   ([row][144 B]); lane (r, h) reads its 8 hi and 8 lo halves of a 16-deep k-step with two ds_read_b128;
+//   ([row][160 B]); lane (n, g) reads the 16-byte slot g of row n's hi and lo halves with two ds_read_b128;
 // * packed weights carry a per-layer power-of-two scale (max|w'| in [1,2)) so that the lo halves of small
 //   weights stay normal f16 numbers; the accumulator is multiplied by `wscale` = 2^-p before the epilogue.
 #pragma once
@@ -15,23 +15,15 @@
 
 namespace atdn {
 
-bool& sf_mfma16();   // MFMA shape for the calling thread's sf kernels (documented below, next to sf_fast_mode)
-
-// PF: chunks of global loads in flight ahead of the one being multiplied. The register sets form a ring whose slot is a
-// compile-time constant (the chunk loop is unrolled PF times): rotating one register set by copying makes the compiler
-// wait (vmcnt(0)) for every outstanding load at the top of each iteration, i.e. no depth at all. PF = 3 is for operands
-// streamed once from HBM (attention x V: 16 KB of the attention matrix per block and chunk; at PF = 1 a CU has ~28 KB
-// in flight, half of what hides an HBM miss at full rate).
-// M16 (round 3): the products run on v_mfma_f32_16x16x32_f16 (K = 32 = one chunk per instruction; the chip holds a higher
-// clock under this shape): lane (n = lane & 15, g = lane >> 4) holds row / column n of a 16-wide block and
-// the 16-byte slot g of the chunk's [32 hi] / [32 lo] halves; the LDS row pitch is 160 B (conflict-free for that lane map;
-// 144 B for the 32x32x16 map); a 32 x 32 tile is 2 x 2 blocks of four accumulator registers: lane (n, g) holds column
-// 16 cb + n and rows 16 hb + 4 g + 0..3.
-template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false, int PF = 1, bool M16 = false>
+// The products run on v_mfma_f32_16x16x32_f16 (K = 32 = one chunk per instruction; the chip holds a higher clock under this
+// shape than under 32x32x16): lane (n = lane & 15, g = lane >> 4) holds row / column n of a 16-wide block and
+// the 16-byte slot g of the chunk's [32 hi] / [32 lo] halves; the LDS row pitch is 160 B (conflict-free for that lane map);
+// a 32 x 32 tile is 2 x 2 blocks of four accumulator registers: lane (n, g) holds column 16 cb + n and rows 16 hb + 4 g + 0..3.
+template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false>
 __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const float wscale, const Epi ep) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int RA = BM / 32, RB = BN / 32;
-  constexpr int LDS_LD = M16 ? 40 : atdn::LDS_LD;   // floats per LDS row
+  constexpr int LDS_LD = 40;   // floats per LDS row (160 B)
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
   float* As = lds;
   float* Bs = lds + BM * LDS_LD;
@@ -73,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
   const float* s0 = g.src0 + (long)img * g.sb0;
   const float* s1 = g.src1 ? g.src1 + (long)img * g.sb1 : nullptr;
 
+  constexpr int PF = 1;   // one chunk of global loads in flight ahead of the one being multiplied
   float4 ra[PF][RA], rb[PF][RB];
   bool aok[PF][RA];  // applied at LDS-store time (see conv_mfma.h)
   int ky = 0, kx = 0, cc = 0;
@@ -87,15 +80,7 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
       const int iy = iy0[i] + ky, ix = ix0[i] + kx;
       const bool ok = ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
       const float* ap = sp + (long)(ok ? iy * g.W + ix : 0) * ld + co + 4 * s;
-      float4 v;
-      if constexpr (PF > 1) {   // streamed-once operand: non-temporal, so the stream does not evict the shared operand from L2
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(ap));
-        v = make_float4(t.x, t.y, t.z, t.w);
-      } else {
-        v = *reinterpret_cast<const float4*>(ap);
-      }
-      ra[slot][i] = v;
+      ra[slot][i] = *reinterpret_cast<const float4*>(ap);
       aok[slot][i] = ok;
     }
     cc += 32;
@@ -110,26 +95,20 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   typedef float f32x4v __attribute__((ext_vector_type(4)));
-  // accumulators: 32x32x16 -> v[16]; 16x16x32 -> b[row block][column block] x 4
-  struct Acc32 { f32x16 v; };
+  // accumulators: b[row block][column block] x 4
   struct Acc16 { f32x4v b[2][2]; };
-  typename std::conditional<M16, Acc16, Acc32>::type acc[TM][TN];
+  Acc16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if constexpr (M16) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j].b[e >> 3][(e >> 2) & 1][e & 3] = 0.f;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j].v[e] = 0.f;
-      }
+      for (int e = 0; e < 16; ++e) acc[i][j].b[e >> 3][(e >> 2) & 1][e & 3] = 0.f;
     }
 
   // byte view of the LDS image: hi halves at [0,64), lo halves at [64,128) of a row
   constexpr int ROWB = LDS_LD * 4;
-  const int rr = M16 ? (lane & 15) : (lane & 31), hh = M16 ? (lane >> 4) : (lane >> 5);
+  const int rr = lane & 15, hh = lane >> 4;
   const char* a_rd = reinterpret_cast<const char*>(As + (wm * TM * 32 + rr) * LDS_LD) + 16 * hh;
   const char* b_rd = reinterpret_cast<const char*>(Bs + (wn * TN * 32 + rr) * LDS_LD) + 16 * hh;
 
@@ -154,75 +133,46 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
       *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDS_LD + 4 * s) = keep_if(wok[j], rb[d][j]);
     __syncthreads();
     fetch(min(q + PF, last), d);   // into the slot just drained
-    if constexpr (M16) {
-      f16x8 ah[TM][2], al[TM][2], bh[TN][2], bl[TN][2];   // [tile][16-row block]
+    f16x8 ah[TM][2], al[TM][2], bh[TN][2], bl[TN][2];   // [tile][16-row block]
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-          ah[i][hb] = *reinterpret_cast<const f16x8*>(a_rd + (i * 32 + 16 * hb) * ROWB);
-          if constexpr (!FAST) al[i][hb] = *reinterpret_cast<const f16x8*>(a_rd + (i * 32 + 16 * hb) * ROWB + 64);
-        }
+      for (int hb = 0; hb < 2; ++hb) {
+        ah[i][hb] = *reinterpret_cast<const f16x8*>(a_rd + (i * 32 + 16 * hb) * ROWB);
+        if constexpr (!FAST) al[i][hb] = *reinterpret_cast<const f16x8*>(a_rd + (i * 32 + 16 * hb) * ROWB + 64);
+      }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        bh[j][cb] = *reinterpret_cast<const f16x8*>(b_rd + (j * 32 + 16 * cb) * ROWB);
+        if constexpr (!FAST) bl[j][cb] = *reinterpret_cast<const f16x8*>(b_rd + (j * 32 + 16 * cb) * ROWB + 64);
+      }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          bh[j][cb] = *reinterpret_cast<const f16x8*>(b_rd + (j * 32 + 16 * cb) * ROWB);
-          if constexpr (!FAST) bl[j][cb] = *reinterpret_cast<const f16x8*>(b_rd + (j * 32 + 16 * cb) * ROWB + 64);
-        }
+        for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-              f32x4v c = acc[i][j].b[hb][cb];
-              if constexpr (!FAST) {
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i][hb], bh[j][cb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i][hb], bl[j][cb], c, 0, 0, 0);
-              }
-              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i][hb], bh[j][cb], c, 0, 0, 0);
-              acc[i][j].b[hb][cb] = c;
+          for (int cb = 0; cb < 2; ++cb) {
+            f32x4v c = acc[i][j].b[hb][cb];
+            if constexpr (!FAST) {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i][hb], bh[j][cb], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i][hb], bl[j][cb], c, 0, 0, 0);
             }
-    } else {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(a_rd + i * 32 * ROWB + 32 * t);
-        al[i] = *reinterpret_cast<const f16x8*>(a_rd + i * 32 * ROWB + 32 * t + 64);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(b_rd + j * 32 * ROWB + 32 * t);
-        bl[j] = *reinterpret_cast<const f16x8*>(b_rd + j * 32 * ROWB + 32 * t + 64);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (!FAST) {
-            acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j].v, 0, 0, 0);
-            acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j].v, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i][hb], bh[j][cb], c, 0, 0, 0);
+            acc[i][j].b[hb][cb] = c;
           }
-          acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j].v, 0, 0, 0);
-        }
-    }
-    }
    }
   }
 
-  // Epilogue: a lane owns NSET channel columns of a 32 x 32 tile with NPX rows each (32x32x16: column lane & 31, rows
-  // (e & 3) + 8 (e >> 2) + 4 (lane >> 5); 16x16x32: columns 16 cs + (lane & 15), rows 16 (e >> 2) + 4 (lane >> 4) + (e & 3)).
-  constexpr int NSET = M16 ? 2 : 1, NPX = M16 ? 8 : 16;
-  auto col_of = [&](int cs) { return M16 ? 16 * cs + (lane & 15) : (lane & 31); };
-  auto row_of = [&](int e) { return M16 ? 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); };
-  auto val_of = [&](int i, int j, int cs, int e) __attribute__((always_inline)) {
-    if constexpr (M16) return acc[i][j].b[e >> 2][cs][e & 3]; else return acc[i][j].v[e];
-  };
+  // Epilogue: a lane owns NSET = 2 channel columns of a 32 x 32 tile with NPX = 8 rows each: columns 16 cs + (lane & 15), rows
+  // 16 (e >> 2) + 4 (lane >> 4) + (e & 3).
+  constexpr int NSET = 2, NPX = 8;
+  auto col_of = [&](int cs) { return 16 * cs + (lane & 15); };
+  auto row_of = [&](int e) { return 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3); };
+  auto val_of = [&](int i, int j, int cs, int e) __attribute__((always_inline)) { return acc[i][j].b[e >> 2][cs][e & 3]; };
   // per-column constants once per wave, before any store (a load issued after a store waits for that store too)
   typename EpiCol<Epi>::type colj[TN][NSET];
   float biasj[TN][NSET];
@@ -255,7 +205,8 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
             v[e] = val_of(i, j, cs, e) * wscale + bias;
             if (m < HoWo) { sum += v[e]; ++cnt; }
           }
-          if constexpr (M16) { sum += __shfl_xor(sum, 16); cnt += __shfl_xor(cnt, 16); }
+          sum += __shfl_xor(sum, 16);
+          cnt += __shfl_xor(cnt, 16);
           sum += __shfl_xor(sum, 32);
           cnt += __shfl_xor(cnt, 32);
           const float mean = sum / (float)(cnt > 0 ? cnt : 1);
@@ -265,9 +216,9 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
             const int m = mbase + row_of(e);
             if (m < HoWo) { const float d = v[e] - mean; m2 += d * d; }
           }
-          if constexpr (M16) m2 += __shfl_xor(m2, 16);
+          m2 += __shfl_xor(m2, 16);
           m2 += __shfl_xor(m2, 32);
-          if ((M16 ? (lane >> 4) : (lane >> 5)) == 0 && nok) {
+          if ((lane >> 4) == 0 && nok) {
             const int grp = mbase >> 5;
             const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
             ep.part_sum[o] = sum;
@@ -303,24 +254,18 @@ __global__ __launch_bounds__(256) void conv_sf_kernel(const ConvGeom g, const fl
   }
 }
 
-template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false, int PF = 1>
+template <int TM, int TN, int WGM, int WGN, class Epi, bool FAST = false>
 inline void launch_conv_sf(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   ConvGeom g = make_geom<MODE_TAP>(s, BM, BN);
   const int nblk = g.nimg * g.tiles_per_img * g.ntile_n;
-  if (sf_mfma16()) hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST, PF, true>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
-  else
-  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST, PF, false>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
+  hipLaunchKernelGGL((conv_sf_kernel<TM, TN, WGM, WGN, Epi, FAST>), dim3(nblk), dim3(256), 0, st, g, wscale, ep);
   ATDN_HIP(hipGetLastError());
 }
 
 // Plain-f16 arithmetic (precision mode 2) for the calling thread's sf convolutions: conv_sf_dispatch issues only the
 // hi x hi MFMA of every product while this is set (GmaNet sets it around its forward).
 bool& sf_fast_mode();
-// MFMA shape of the halo kernels (conv_sf6.h) for the calling thread: true = v_mfma_f32_16x16x32_f16 (default), false =
-// v_mfma_f32_32x32x16_f16, the loop round 3 replaced (a GmaNet built under ATDN_CONV_M32=1 sets it around its forward; kept
-// while tests/test_gpu_round3.py compares the two).
-bool& sf_mfma16();
 
 // Definitions are explicitly instantiated in conv_sf_inst_*.hip
 template <class Epi>

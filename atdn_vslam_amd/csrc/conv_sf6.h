@@ -55,41 +55,39 @@ template <class E> struct epi_flowhead<E, std::void_t<decltype(E::kFlowHead)>> :
 template <class E, class = void> struct epi_vec4 : std::false_type {};
 template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bool_constant<E::kVec4> {};
 
-// ABL (diagnostic builds only, wrong results): bit0 no weight loads in the loop, bit1 no patch refresh, bit2 no LDS reads in the loop
 // FAST: plain-f16 arithmetic (precision mode 2): only the hi x hi MFMA of every product is issued
-// NIMG: patch images in LDS. 2 = a chunk boundary costs one barrier (deep pipeline, one or two blocks per CU); 1 = half the
-// LDS and two barriers per boundary, for thin layers (few chunks per tile): four blocks per CU overlap each other's
-// prologue, epilogue and barriers instead
 // NORM: normalise-on-load. src0 holds the RAW fp32 output of an InstanceNorm'ed conv (same addressing: 128 bytes per
 // pixel and 32-channel chunk); the patch loader applies relu((x - mean) * rstd) per (image, channel), splits to hi | lo and
 // writes the sf chunk image itself, one patch row per half-step over the last NP half-steps of a chunk — the separate
 // normalisation pass between the two convs of a residual block (read 4 B + write 4 B per element) disappears.
-// M16: the loop runs on v_mfma_f32_16x16x32_f16 (K = 32 per instruction: a whole 32-channel chunk of one tap) instead of
-// v_mfma_f32_32x32x16_f16. Same FLOP per cycle, same operand bytes per FLOP, but on random data the chip holds a higher
-// clock under this shape: the conv-like loop of tools/microbench (pixel operands from LDS, weights in registers, two
-// waves per SIMD) runs at 1914 instead of 1575 TF/s executed (profiles/r03_microbench_mfma.txt; equal on all-zero
-// operands: it is the clock, MI355X_MICROARCH.md "DVFS give-back" item 7). What changes:
+// The loop runs on v_mfma_f32_16x16x32_f16 (K = 32 per instruction: a whole 32-channel chunk of one tap). Same FLOP per cycle
+// and operand bytes per FLOP as v_mfma_f32_32x32x16_f16 (the loop rounds 1-2 ran, removed in round 4 after a round of A/B
+// tests), but on random data the chip holds a higher clock under this shape: the conv-like loop of tools/microbench (pixel
+// operands from LDS, weights in registers, two waves per SIMD) runs at 1914 instead of 1575 TF/s executed
+// (profiles/r03_microbench_mfma.txt; equal on all-zero operands: it is the clock, MI355X_MICROARCH.md "DVFS give-back" 7):
 //   * operand lane map: lane (n = lane & 15, g = lane >> 4) holds, for row / column n of a 16-wide block, the 16-byte slot
 //     g of the chunk's [32 hi] (or [32 lo]) halves; a wave's 32-pixel row tile is two 16-pixel blocks = the two patch rows
 //     it covers (TW = 16), its 32-channel tile two 16-channel blocks;
 //   * the pixel pitch of the patch image is 160 B (144 B puts slot g + 1 of pixels 4-11 on the banks of slot g of pixels
 //     12-15 and 0-3 in the lane groups of ds_read_b128; 160 B = 10 slots is conflict-free for this lane map);
-//   * weights come from the fragment-major copy for this shape (weights.h: pack_fragment_major16): [N/16][K/32][hi | lo]
-//     [lane] x 16 B, one contiguous KiB per wave load as before;
-//   * a K step (tap, chunk) is still two half-steps — pixel half 0 (first patch row of every row tile) and half 1 — with the
+//   * weights come from the fragment-major copy (weights.h: pack_fragment_major16): [N/16][K/32][hi | lo][lane] x 16 B, one
+//     contiguous KiB per wave load;
+//   * a K step (tap, chunk) is two half-steps — pixel half 0 (first patch row of every row tile) and half 1 — with the
 //     pixel fragments of the next half-step read during the current one; the weights of a K step (channel block 0 loaded in
 //     half-step 0, block 1 in half-step 1) stay in a ring of RT K-step slots, RT - 1 steps ahead;
 //   * accumulator: b[pixel half][channel block] of 4 registers: in SWAP mode (weights = row operand) lane (n, g) holds
 //     channels 16 cb + 4 g + 0..3 of pixel 16 half + n.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <bool M16> struct SfAcc;
-template <> struct SfAcc<false> { f32x16 v; };
-template <> struct SfAcc<true> { f32x4v b[2][2]; };
+struct SfAcc { f32x4v b[2][2]; };
 
-template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2,
-          bool NORM = false, bool M16 = false>
-__global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2) ? 4 : 1)) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
-  static_assert(!M16 || (TW == 16 && FRAGW && ABL == 0), "the 16x16x32 loop is built for 16-pixel tile rows and fragment-major weights");
+// ABL (tools/microbench only — diagnostic builds with WRONG results, timing only; the product instantiates ABL = 0): bit 0 no
+// weight loads in the loop, bit 1 no patch refresh (and no chunk-boundary barrier), bit 2 no LDS fragment reads in the loop,
+// bit 3 no epilogue
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST = false, bool NORM = false, int ABL = 0>
+__global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
+  static_assert(ABL == 0 || !NORM, "ablation builds exist for the plain patch loader");
+  static_assert(TW == 16, "the 16x16x32 loop is built for 16-pixel tile rows");
+  constexpr int NIMG = 2;   // two patch images: a chunk boundary costs one barrier
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = TH * TW / 32 / WM, TN = BN / 32 / WN;
   static_assert(TM * WM * 32 == TH * TW && TN * WN * 32 == BN, "wave grid must tile the block");
@@ -99,17 +97,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
   constexpr int PROWS = (TH + KH - 1) * (TW + KW - 1);
   constexpr int PW = TW + KW - 1;
   constexpr int NP = (PROWS + RSTEP - 1) / RSTEP;
-  constexpr int ROWB = M16 ? 160 : LDS_LD * 4;   // pixel pitch of the patch image
-  // LDS pitch between patch rows. 32x32x16: a multiple of 256 B, so the two tile rows that one ds_read_b128 lane group
-  // ({0-3,12-15,20-27}, ... : pixels x..x+3, x+12..x+15 of one row and x+4..x+11 of the next) touches land on
-  // 16 distinct 16-byte bank slots (pixel pitch 144 B = 9 slots, 9 odd); PW*144 alone gives 2-way conflicts.
-  // 16x16x32: a fragment read stays inside one patch row, any pitch works
-  constexpr int RS = M16 ? PW * ROWB : (PW * ROWB + 255) / 256 * 256;
+  constexpr int ROWB = 160;   // pixel pitch of the patch image
+  // LDS pitch between patch rows: a fragment read stays inside one patch row, any pitch works
+  constexpr int RS = PW * ROWB;
   constexpr bool SWAP = epi_vec4<Epi>::value;
   // two patch images: chunk c+1 is written (from the registers its loads landed in) during the last tap of chunk c,
   // so a chunk boundary costs one barrier, not two
   constexpr int PSZ = (TH + KH - 1) * RS;
-  static_assert(NIMG == 1 || NIMG == 2, "one or two patch images");
   __shared__ __attribute__((aligned(256))) char Pbytes[NIMG * PSZ];
 
   const int tid = threadIdx.x;
@@ -130,9 +124,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
   // the normalise-on-load kernels was 11-15 % of their LDS cycles.)
   // (pixel pitch 160 B = 40 dwords: rows TWO apart are 16 banks apart)
   const int jrow = (tid >> 3) & 7;
-  const int s = tid & 7, r0 = !NORM ? tid >> 3
-                            : M16 ? ((tid >> 6) << 3) + 2 * (jrow & 1) + ((jrow >> 1) & 1) + 4 * (jrow >> 2)
-                                  : ((tid >> 6) << 3) + (jrow >> 1) + 4 * (jrow & 1);
+  const int s = tid & 7, r0 = !NORM ? tid >> 3 : ((tid >> 6) << 3) + 2 * (jrow & 1) + ((jrow >> 1) & 1) + 4 * (jrow >> 2);
   // per patch row of this thread: (pixel offset in the image + 1, 0 = zero padding) << 12 | LDS offset / 16
   static_assert((TH + KH - 1) * RS / 16 <= 4096, "LDS offset field");
   unsigned pmeta[NP];
@@ -189,158 +181,15 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
 
   // ---- MFMA roles
   const int wm = wave / WN, wn = wave % WN;
-  SfAcc<M16> acc[TM][TN];
+  SfAcc acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if constexpr (M16) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j].b[e >> 3][(e >> 2) & 1][e & 3] = 0.f;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j].v[e] = 0.f;
-      }
+      for (int e = 0; e < 16; ++e) acc[i][j].b[e >> 3][(e >> 2) & 1][e & 3] = 0.f;
     }
-  if constexpr (!M16) {
-    const int r = lane & 31, h = lane >> 5;
-    int a_off[TM];
-  #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int p = (wm * TM + i) * 32 + r;
-      a_off[i] = (p / TW) * RS + (p % TW) * ROWB + 16 * h;
-    }
-    const char* Pb = Pbytes;   // image of the current chunk
-    // weight fragment rows (clamped: accumulators of rows >= N are never stored)
-    const float* wrow[TN];
-  #pragma unroll
-    for (int j = 0; j < TN; ++j)
-      if constexpr (FRAGW)  // fragment-major weights: [n/32][q][t][hi|lo][lane] x 16 B, one contiguous KiB per wave load
-        wrow[j] = g.w + (long)min((n0 >> 5) + wn * TN + j, ((g.N + 31) >> 5) - 1) * (NTAP * nck) * 1024 + lane * 4;
-      else
-        wrow[j] = g.w + (long)min(n0 + (wn * TN + j) * 32 + r, g.N - 1) * g.ldw + 4 * h;
-
-    // Weight fragments live in a ring of R half-step slots (half-step = one 16-wide K sub-step of one tap). R divides
-    // the 2*NTAP half-steps of a chunk, so every slot index is a compile-time constant: no register rotation (copying
-    // w1 = w2 made the compiler wait for a load right after issuing it) and the load for half-step hs + R - 1 goes
-    // into the slot half-step hs - 1 just released. The chunk body is branch-free (the prefetches of the last chunk
-    // are clamped to valid, unused data), i.e. one scheduling region, and sched_group_barrier pins the interleave:
-    // one LDS read or global load behind every MFMA, reads for the NEXT half-step first.
-    constexpr int NH = 2 * NTAP;
-    // (the high-occupancy single-image variant keeps the ring short: its budget is 128 registers per lane)
-    constexpr int R = (NIMG == 1 && NH % 3 == 0) ? 3 : (NH % 5 == 0) ? 5 : (NH % 6 == 0) ? 6 : 4;
-    static_assert(NH % R == 0 && NH >= R, "ring size must divide the half-steps of a chunk");
-    struct HFrag { f16x8 hi[TN], lo[TN]; };
-    HFrag wr[R];
-    auto load_wh = [&](HFrag& f, int c, int hs) {
-      const int q = (hs >> 1) * nck + c;  // packed K order is [tap][channel chunk]
-      const int t = hs & 1;
-  #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (FRAGW) {
-          f.hi[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512);
-          f.lo[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 1024 + t * 512 + 256);
-        } else {
-          f.hi[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t);
-          f.lo[j] = *reinterpret_cast<const f16x8*>(wrow[j] + q * 32 + 8 * t + 16);
-        }
-      }
-    };
-
-    fetch_patch(0);
-    if constexpr (NORM) fetch_norm(0);
-  #pragma unroll
-    for (int hs = 0; hs < R - 1; ++hs) load_wh(wr[hs], 0, hs);
-    if (ABL & 1) load_wh(wr[R - 1], 0, R - 1);
-    if constexpr (NORM) {
-  #pragma unroll
-      for (int k = 0; k < NP; ++k) store_row_norm(0, k, nmu, nrs);
-    } else {
-      store_patch(0);
-    }
-    __syncthreads();
-    // activation fragments: two register sets, the ds_reads of half-step hs + 1 are issued among the MFMAs of hs
-    f16x8 ah[2][TM], al[2][TM];
-    auto read_a = [&](int set, int tap, int t) {
-      const char* arow = Pb + (tap / KW) * RS + (tap % KW) * ROWB;
-  #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t);
-        al[set][i] = *reinterpret_cast<const f16x8*>(arow + a_off[i] + 32 * t + 64);
-      }
-    };
-    auto mfma_half = [&](int set, const HFrag& w) {
-  #pragma unroll
-      for (int i = 0; i < TM; ++i)
-  #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (SWAP) {
-            if constexpr (!FAST) {
-              acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[j], al[set][i], acc[i][j].v, 0, 0, 0);
-              acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo[j], ah[set][i], acc[i][j].v, 0, 0, 0);
-            }
-            acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[j], ah[set][i], acc[i][j].v, 0, 0, 0);
-          } else {
-            if constexpr (!FAST) {
-              acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][i], w.hi[j], acc[i][j].v, 0, 0, 0);
-              acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][i], w.lo[j], acc[i][j].v, 0, 0, 0);
-            }
-            acc[i][j].v = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][i], w.hi[j], acc[i][j].v, 0, 0, 0);
-          }
-        }
-    };
-    constexpr int NMF = (FAST ? 1 : 3) * TM * TN;   // MFMAs per half-step
-    read_a(0, 0, 0);
-    for (int c = 0; c < nck; ++c) {
-      const int cn = min(c + 1, nck - 1);   // clamped: the prefetches of the last chunk fetch valid, unused data
-  #pragma unroll
-      for (int hs = 0; hs < NH; ++hs) {
-        // every half-step is its own scheduling region: without this fence the interleave solver moves the LDS reads
-        // of half-step hs + 1 to just before their consumers
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 2) && hs == 0) { fetch_patch(cn); if constexpr (NORM) fetch_norm(cn); }  // lands during this chunk's taps
-        if (!(ABL & 1)) {
-          const int nhs = hs + R - 1;
-          if (nhs < NH) load_wh(wr[nhs % R], c, nhs); else load_wh(wr[nhs % R], cn, nhs - NH);
-        }
-        if (!(ABL & 4) && hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1, (hs + 1) & 1);
-        if constexpr (NORM) {   // one patch row per half-step: the conversion arithmetic spreads over NP half-steps
-          static_assert(!NORM || (NIMG == 2 && NH - 1 - NP >= 1), "normalise-on-load needs two patch images and NP < NH - 1");
-          if (hs >= NH - 1 - NP && hs <= NH - 2) store_row_norm((c + 1) & 1, hs - (NH - 1 - NP), nmu, nrs);
-        } else {
-          if (NIMG == 2 && !(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c-1
-        }
-        mfma_half(hs & 1, wr[hs % R]);
-        // interleave: one memory instruction behind each MFMA — LDS reads first (they feed the next half-step), then
-        // the global loads, then the patch image writes
-        {
-          constexpr int nds = 2 * TM;
-          const int nvm = 2 * TN + (hs == 0 ? NP : 0);
-          const int ndw = NORM ? ((hs >= NH - 1 - NP && hs <= NH - 2) ? 2 : 0) : ((NIMG == 2 && hs == NH - 2) ? NP : 0);
-  #pragma unroll
-          for (int k = 0; k < NMF; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (hs + 1 < NH && k < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else if (k - ((hs + 1 < NH) ? nds : 0) < nvm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            else if (k - ((hs + 1 < NH) ? nds : 0) - nvm < ndw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          }
-        }
-      }
-      // chunk boundary: publish the next patch image (one barrier)
-      if (!(ABL & 2)) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if constexpr (NIMG == 2) {
-          Pb = Pbytes + ((c + 1) & 1) * PSZ;
-        } else if (c + 1 < nck) {   // single image: every wave is done reading it; rewrite in place and publish
-          store_patch(0);
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-      }
-      if (!(ABL & 4)) read_a(0, 0, 0);
-    }
-
-  } else {
-    // ================================================================== 16x16x32 loop (see the note above the kernel)
+  {
     const int n16 = lane & 15, g16 = lane >> 4;
     int a_off[TM];   // first patch row (pixel half 0) of row tile i: pixel n16, slot g16; half 1 is the next patch row
 #pragma unroll
@@ -375,6 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
     if constexpr (NORM) fetch_norm(0);
 #pragma unroll
     for (int st = 0; st < RT - 1; ++st) { load_w(wr[st], 0, st, 0); load_w(wr[st], 0, st, 1); }
+    if constexpr ((ABL & 1) != 0) { load_w(wr[RT - 1], 0, RT - 1, 0); load_w(wr[RT - 1], 0, RT - 1, 1); }
     if constexpr (NORM) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) store_row_norm(0, k, nmu, nrs);
@@ -417,28 +267,29 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
     };
     constexpr int NMF = (FAST ? 1 : 3) * TM * TN * 2;   // MFMAs per half-step
     constexpr int NH = 2 * NTAP;                        // half-steps per chunk
-    static_assert(!NORM || (NIMG == 2 && NH - 1 - NP >= 1), "normalise-on-load needs two patch images and NP < NH - 1");
-    static_assert(NIMG == 2, "the 16x16x32 loop keeps two patch images");
+    static_assert(!NORM || NH - 1 - NP >= 1, "normalise-on-load spreads its NP patch rows over the half-steps of a chunk");
     read_a(0, 0);
     for (int c0 = 0; c0 < nck; c0 += CU) {
 #pragma unroll
       for (int cu = 0; cu < CU; ++cu) {
         const int c = c0 + cu;
-        const bool live = CU == 1 || c < nck;   // (CU > 1 and an odd chunk count: the surplus chunk multiplies nothing)
+        // (CU > 1 and an odd chunk count: the surplus chunk multiplies nothing but still fetches, stores and joins the
+        // barrier — up to 1 / nck of the kernel; the ConvGRU shapes have nck = 12 or 16. ADVICE r3)
+        const bool live = CU == 1 || c < nck;
         const int cn = min(c + 1, nck - 1);
 #pragma unroll
         for (int hs = 0; hs < NH; ++hs) {
           const int tap = hs >> 1, half = hs & 1;
           const int st = cu * NTAP + tap;     // compile-time K step index inside the unrolled iteration
           __builtin_amdgcn_sched_barrier(0);
-          if (hs == 0) { fetch_patch(cn); if constexpr (NORM) fetch_norm(cn); }   // lands during this chunk's taps
+          if (!(ABL & 2) && hs == 0) { fetch_patch(cn); if constexpr (NORM) fetch_norm(cn); }   // lands during this chunk's taps
           // weights of K step st + RT - 1: channel block `half` in this half-step, into the slot K step st - 1 released
-          load_w(wr[(st + RT - 1) % RT], c0, st + RT - 1, half);
-          if (hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1);
+          if (!(ABL & 1)) load_w(wr[(st + RT - 1) % RT], c0, st + RT - 1, half);
+          if (!(ABL & 4) && hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1);
           if constexpr (NORM) {
             if (hs >= NH - 1 - NP && hs <= NH - 2) store_row_norm((c + 1) & 1, hs - (NH - 1 - NP), nmu, nrs);
           } else {
-            if (hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c - 1
+            if (!(ABL & 2) && hs == NH - 2) store_patch((c + 1) & 1);   // that image was last read in chunk c - 1
           }
           if (live) mfma_half(half, wr[st % RT]);
           {
@@ -455,30 +306,33 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
           }
         }
         // chunk boundary: publish the next patch image (one barrier)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        Pb = Pbytes + ((c + 1) & 1) * PSZ;
-        read_a(0, 0);
+        if (!(ABL & 2)) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          Pb = Pbytes + ((c + 1) & 1) * PSZ;
+        }
+        if (!(ABL & 4)) read_a(0, 0);
       }
     }
   }
 
-  if constexpr ((ABL & 8) != 0 && !M16) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
+  if constexpr ((ABL & 8) != 0) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
     float tot = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) tot += acc[i][j].v[e];
+        for (int e = 0; e < 16; ++e) tot += acc[i][j].b[e >> 3][(e >> 2) & 1][e & 3];
     if (tot == 1.2345e-30f) ep(img, 0, 0, tot);
     return;
   }
   if constexpr (SWAP) {
-    // ---- channel-vector epilogue. After the MFMAs lane (r, h) holds, for pixel r of a 32-pixel tile, channels
-    // 8k + 4h + (0..3) in registers 4k..4k+3. Storing from there gives every 128-byte output line 8 separate partial
-    // writes (measured: 20 us of a 170 us kernel; the same bytes as whole-line stores cost 7 us). So each tile is
-    // transposed through a wave-private LDS slab first: 4 ds_write_b128 in, 4 ds_read_b128 out, after which lane l
-    // owns pixel 8q + l/8, channels 4*(l%8)..+3 — 8 consecutive lanes cover one pixel's 32-channel group, and every
+    // ---- channel-vector epilogue. After the MFMAs lane (n, g) holds, for pixel 16 half + n of a 32-pixel tile, channels
+    // 16 cb + 4 g + (0..3). Storing from there gives every 128-byte output line 4 separate 32-byte partial writes (and the
+    // operand loads of the gate / residual epilogues the same shape): measured in round 4 against the form below, plain-store
+    // epilogues do not care but the ConvGRU gates and the residual add run 8-9 % slower (profiles/r04_ab_direct_epilogue.txt).
+    // So each tile is transposed through a wave-private LDS slab first: 4 ds_write_b128 in, 4 ds_read_b128 out, after which
+    // lane l owns pixel 8q + l/8, channels 4*(l%8)..+3 — 8 consecutive lanes cover one pixel's 32-channel group, and every
     // load and store of the epilogue (operands of the GRU gates included) is a whole line per pixel.
     // The slabs reuse the patch images (dead after the main loop; one barrier before the first write), so a block's
     // LDS footprint is the two patch images only and narrower blocks fit several to a CU: one block's epilogue then
@@ -494,20 +348,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
       return (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
     };
     // one 32-pixel x 32-channel accumulator tile -> the wave's slab [pixel][LDS_LD floats], scaled
-    auto slab_write = [&](const SfAcc<M16>& a) __attribute__((always_inline)) {
-      if constexpr (M16) {
+    auto slab_write = [&](const SfAcc& a) __attribute__((always_inline)) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-            *reinterpret_cast<float4*>(tb + (16 * hh + (lane & 15)) * LDS_LD + 16 * cb + 4 * (lane >> 4)) =
-                make_float4(a.b[hh][cb][0] * g.wscale, a.b[hh][cb][1] * g.wscale, a.b[hh][cb][2] * g.wscale, a.b[hh][cb][3] * g.wscale);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          *reinterpret_cast<float4*>(tb + (lane & 31) * LDS_LD + 8 * k + 4 * (lane >> 5)) =
-              make_float4(a.v[4 * k] * g.wscale, a.v[4 * k + 1] * g.wscale, a.v[4 * k + 2] * g.wscale, a.v[4 * k + 3] * g.wscale);
-      }
+        for (int cb = 0; cb < 2; ++cb)
+          *reinterpret_cast<float4*>(tb + (16 * hh + (lane & 15)) * LDS_LD + 16 * cb + 4 * (lane >> 4)) =
+              make_float4(a.b[hh][cb][0] * g.wscale, a.b[hh][cb][1] * g.wscale, a.b[hh][cb][2] * g.wscale, a.b[hh][cb][3] * g.wscale);
     };
     if constexpr (epi_flowhead<Epi>::value) {
       // ---- flow head: relu(conv1) x conv2's weights, reduced to 18 partial sums per pixel (epilogues_sf.h).
@@ -647,15 +494,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
     }
     return;
   }
-  // ---- pixel-major epilogue (TM x TN tiles per wave). A lane owns NSET channel columns of a 32 x 32 tile with NPX pixels
-  // each: 32x32x16 -> one column (channel lane & 31), 16 pixels (e & 3) + 8 (e >> 2) + 4 (lane >> 5); 16x16x32 -> two columns
-  // (channel 16 cb + (lane & 15)), 8 pixels 16 half + 4 (lane >> 4) + k each.
-  constexpr int NSET = M16 ? 2 : 1, NPX = M16 ? 8 : 16;
-  auto col_of = [&](int cs) { return M16 ? 16 * cs + (lane & 15) : (lane & 31); };
-  auto pix_of = [&](int e) { return M16 ? 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); };
-  auto val_of = [&](const SfAcc<M16>& a, int cs, int e) __attribute__((always_inline)) {
-    if constexpr (M16) return a.b[e >> 2][cs][e & 3]; else return a.v[e];
-  };
+  // ---- pixel-major epilogue (TM x TN tiles per wave). A lane owns NSET = 2 channel columns of a 32 x 32 tile (channel
+  // 16 cb + (lane & 15)) with NPX = 8 pixels each: 16 half + 4 (lane >> 4) + k.
+  constexpr int NSET = 2, NPX = 8;
+  auto col_of = [&](int cs) { return 16 * cs + (lane & 15); };
+  auto pix_of = [&](int e) { return 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3); };
+  auto val_of = [&](const SfAcc& a, int cs, int e) __attribute__((always_inline)) { return a.b[e >> 2][cs][e & 3]; };
   // per-column constants once per wave, before any store (a load issued after a store waits for that store too)
   typename EpiCol<Epi>::type colj[TN][NSET];
   float biasj[TN][NSET];
@@ -686,7 +530,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
         const bool nok = n < g.N;
         if constexpr (Epi::kStats) {
           // partial statistics of the tile's 32 pixels for this channel: lane-local over its NPX pixels, then across the
-          // lanes that hold the same channel (32x32x16: lane ^ 32; 16x16x32: lane ^ 16, lane ^ 32)
+          // lanes that hold the same channel (lane ^ 16, lane ^ 32)
           const float bias = nok ? biasj[j][cs] : 0.f;
           float v[NPX];
           float sum = 0.f;
@@ -696,7 +540,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
             v[e] = val_of(acc[i][j], cs, e) * g.wscale + bias;
             if (mm[e] >= 0) { sum += v[e]; ++cnt; }
           }
-          if constexpr (M16) { sum += __shfl_xor(sum, 16); cnt += __shfl_xor(cnt, 16); }
+          sum += __shfl_xor(sum, 16);
+          cnt += __shfl_xor(cnt, 16);
           sum += __shfl_xor(sum, 32);
           cnt += __shfl_xor(cnt, 32);
           const float mean = sum / (float)(cnt > 0 ? cnt : 1);
@@ -704,10 +549,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
 #pragma unroll
           for (int e = 0; e < NPX; ++e)
             if (mm[e] >= 0) { const float d = v[e] - mean; m2 += d * d; }
-          if constexpr (M16) m2 += __shfl_xor(m2, 16);
+          m2 += __shfl_xor(m2, 16);
           m2 += __shfl_xor(m2, 32);
           const int grp = tloc * (TH * TW / 32) + wm * TM + i;
-          if ((M16 ? (lane >> 4) : (lane >> 5)) == 0 && nok) {
+          if ((lane >> 4) == 0 && nok) {
             const long o = ((long)img * ep.groups_per_img + grp) * g.N + n;
             ep.part_sum[o] = sum;
             ep.part_m2[o] = m2;
@@ -736,8 +581,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((NIMG == 1 && TH * TW / 32 / WM <= 2
   }
 }
 
-template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, int ABL = 0, bool FRAGW = false, bool FAST = false, int NIMG = 2,
-          bool NORM = false, bool M16 = false>
+template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST = false, bool NORM = false, int ABL = 0>
 inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
   constexpr int TW = 16;
   ATDN_CHECK(s.KH == KH && s.KW == KW && s.stride == 1, "kernel shape does not match the instantiation");
@@ -753,14 +597,14 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
   ATDN_CHECK((long)s.H * s.W < (1L << 20) - 1, "image too large for the packed patch descriptor");
   g.tiles_x = cdiv(g.Wo, TW); g.tiles_y = cdiv(g.Ho, TH);
   g.nimg = s.nimg; g.ntile_n = cdiv(s.N, BN);
-  g.w = M16 ? s.wfrag16 : FRAGW ? s.wfrag : s.w; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;
+  g.w = s.wfrag16; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;
   g.in_mean = s.in_mean; g.in_rstd = s.in_rstd;
   ATDN_CHECK(NORM == (s.in_mean != nullptr) && (!NORM || (s.in_rstd && s.C1 == 0 && s.ld0 == s.C0)),
              "normalise-on-load: one dense fp32 source with its mean / rstd");
   ATDN_CHECK(g.w != nullptr, "missing weight copy for this kernel");
   set_groups(ep, g.tiles_x * g.tiles_y * (TH * TW / 32));
   const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
-  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, ABL, FRAGW, FAST, NIMG, NORM, M16>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
+  hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, FAST, NORM, ABL>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
   ATDN_HIP(hipGetLastError());
 }
 
@@ -781,11 +625,9 @@ inline int conv_sf6_block_width_3x3(const ConvShape& s) {
   return bn;
 }
 
-// MFMA shape of the halo kernels: sf_mfma16() (conv_sf.h) picks the 16x16x32 loop (default) or the 32x32x16 one.
 template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST, bool NORM>
-inline void launch_conv_sf6_m(bool m16, const ConvShape& s, float wscale, const Epi& ep, hipStream_t st) {
-  if (m16) launch_conv_sf6<TH, BN, WM, WN, KH, KW, Epi, 0, true, FAST, 2, NORM, true>(s, wscale, ep, st);
-  else launch_conv_sf6<TH, BN, WM, WN, KH, KW, Epi, 0, true, FAST, 2, NORM, false>(s, wscale, ep, st);
+inline void launch_conv_sf6_m(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st) {
+  launch_conv_sf6<TH, BN, WM, WN, KH, KW, Epi, FAST, NORM>(s, wscale, ep, st);
 }
 
 // Picks the block shape for N output channels and launches the fragment-major-weight kernel: 8x16-pixel tiles, or
@@ -794,7 +636,6 @@ inline void launch_conv_sf6_m(bool m16, const ConvShape& s, float wscale, const 
 // cover the chip. Returns false when this path does not serve the shape (the caller falls back to the plain implicit GEMM).
 template <int KH, int KW, class Epi, bool FAST>
 inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out, int* th_out) {
-  const bool m16 = sf_mfma16() && s.wfrag16 != nullptr;
   const int Ho = conv_out(s.H, s.KH, 1, s.padH), Wo = conv_out(s.W, s.KW, 1, s.padW);
   const long tiles = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 8);
   // block width: the one of {256, 128, 64} that pads N least (ties: the widest, it shares the patch among more
@@ -822,11 +663,11 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
       // pairs then produce bit-identical InstanceNorm statistics)
       const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103;
       *bn_out = bn; *th_out = tall ? 12 : 8;
-      if (bn == 64 && tall) launch_conv_sf6_m<12, 64, 2, 2, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
-      else if (bn == 64) launch_conv_sf6_m<8, 64, 2, 2, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
-      else if (bn == 96 && tall) launch_conv_sf6_m<12, 96, 2, 3, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
-      else if (bn == 96) launch_conv_sf6_m<8, 96, 2, 3, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
-      else if (bn == 128) launch_conv_sf6_m<8, 128, 1, 4, KH, KW, Epi, false, true>(m16, s, wscale, ep, st);
+      if (bn == 64 && tall) launch_conv_sf6_m<12, 64, 2, 2, KH, KW, Epi, false, true>(s, wscale, ep, st);
+      else if (bn == 64) launch_conv_sf6_m<8, 64, 2, 2, KH, KW, Epi, false, true>(s, wscale, ep, st);
+      else if (bn == 96 && tall) launch_conv_sf6_m<12, 96, 2, 3, KH, KW, Epi, false, true>(s, wscale, ep, st);
+      else if (bn == 96) launch_conv_sf6_m<8, 96, 2, 3, KH, KW, Epi, false, true>(s, wscale, ep, st);
+      else if (bn == 128) launch_conv_sf6_m<8, 128, 1, 4, KH, KW, Epi, false, true>(s, wscale, ep, st);
       else return false;
       return true;
     } else {
@@ -834,26 +675,26 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
     }
   }
   if constexpr (KH == 3) {
-    if (bn == 32) { *bn_out = 32; launch_conv_sf6_m<8, 32, 4, 1, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true; }
+    if (bn == 32) { *bn_out = 32; launch_conv_sf6_m<8, 32, 4, 1, KH, KW, Epi, FAST, false>(s, wscale, ep, st); return true; }
     const long tiles12 = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
     const bool tall = (bn == 64 || bn == 96) && cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 &&
                       (Epi::kStats || tiles12 * cdiv(s.N, bn) >= 512);   // (statistics: geometry only, see above)
     if (tall) {
       *bn_out = bn; *th_out = 12;
-      if (bn == 64) launch_conv_sf6_m<12, 64, 2, 2, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st);
-      else launch_conv_sf6_m<12, 96, 2, 3, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st);
+      if (bn == 64) launch_conv_sf6_m<12, 64, 2, 2, KH, KW, Epi, FAST, false>(s, wscale, ep, st);
+      else launch_conv_sf6_m<12, 96, 2, 3, KH, KW, Epi, FAST, false>(s, wscale, ep, st);
       return true;
     }
   }
   *bn_out = bn;
   switch (bn) {
-    case 64:  launch_conv_sf6_m<8, 64, 2, 2, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true;  // 4 waves of 64 px x 32 ch
-    case 128: launch_conv_sf6_m<8, 128, 1, 4, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true;
-    case 256: launch_conv_sf6_m<8, 256, 1, 8, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true;
+    case 64:  launch_conv_sf6_m<8, 64, 2, 2, KH, KW, Epi, FAST, false>(s, wscale, ep, st); return true;  // 4 waves of 64 px x 32 ch
+    case 128: launch_conv_sf6_m<8, 128, 1, 4, KH, KW, Epi, FAST, false>(s, wscale, ep, st); return true;
+    case 256: launch_conv_sf6_m<8, 256, 1, 8, KH, KW, Epi, FAST, false>(s, wscale, ep, st); return true;
     default: break;
   }
   if constexpr (KH == 3) {
-    if (bn == 96) { launch_conv_sf6_m<8, 96, 2, 3, KH, KW, Epi, FAST, false>(m16, s, wscale, ep, st); return true; }
+    if (bn == 96) { launch_conv_sf6_m<8, 96, 2, 3, KH, KW, Epi, FAST, false>(s, wscale, ep, st); return true; }
   }
   return false;
 }
@@ -861,7 +702,7 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
 template <class Epi>
 inline bool conv_sf6_try(const ConvShape& s, float wscale, const Epi& ep, hipStream_t st, int* bn_out, int* th_out, bool fast) {
   constexpr int kinds = epi_gen6<Epi>::value;
-  if (kinds == 0 || !s.wfrag || s.stride != 1) return false;
+  if (kinds == 0 || !s.wfrag16 || s.stride != 1) return false;
   if (epi_vec4<Epi>::value && Epi::kPrefetch && (s.N % 4) != 0) return false;
   if (epi_vec4<Epi>::value && s.N < 4) return false;
   if (s.C0 % 32 != 0 || s.C1 % 32 != 0 || s.C0 <= 0 || s.ld0 % 4 != 0) return false;

@@ -11,10 +11,9 @@ template <class Epi>
 TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
   const int Ho = conv_out(s.H, s.KH, s.stride, s.padH), Wo = conv_out(s.W, s.KW, s.stride, s.padW);
   // Stride-1 3x3 / 1x5 / 5x1 convolutions run on the halo-patch kernel (conv_sf6.h) for every epilogue that opts in
-  // (kGen6). ATDN_NO_HALO=1 sends them to the plain implicit GEMM below instead — the one documented fallback, which
-  // also serves 1x1 / strided convolutions and the batched GEMMs (correlation, QK^T, attention x V).
-  static const bool halo = !(getenv("ATDN_NO_HALO") && getenv("ATDN_NO_HALO")[0] == '1');
-  if (halo && conv_halo_eligible(s)) {
+  // (kGen6); shapes it does not serve (and 1x1 / strided convolutions, the batched GEMMs of the correlation levels and the
+  // projections) go to the plain implicit GEMM below.
+  if (conv_halo_eligible(s)) {
     int bn = 0, th = 8;
     if (conv_sf6_try(s, wscale, ep, st, &bn, &th, sf_fast_mode())) return TileChoice{th * 16, bn, cdiv(Wo, 16) * cdiv(Ho, th) * (th / 2), true};
   }
@@ -22,15 +21,6 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
   TileChoice t = choose_tile(s.nimg, Ho * Wo, s.N);
   t.groups_per_img = cdiv(Ho * Wo, t.BM) * (t.BM / 32);
   set_groups(ep, t.groups_per_img);
-  // attention x V: the A operand (the attention matrix) is streamed once from HBM: three chunks of loads in flight
-  // (measured per forward of 8 pairs: depth 1 5.16 ms, 2 5.03, 3 5.01, 4 5.55 — the fourth register set costs occupancy)
-  if constexpr (std::is_same_v<Epi, SfAggregate>) {
-    if (t.BM == 128 && t.BN == 128 && s.KH == 1 && s.KW == 1 && (s.C0 + s.C1) >= 2048) {
-      if (sf_fast_mode()) launch_conv_sf<2, 2, 2, 2, Epi, true, 3>(s, wscale, ep, st);
-      else launch_conv_sf<2, 2, 2, 2, Epi, false, 3>(s, wscale, ep, st);
-      return t;
-    }
-  }
   if (sf_fast_mode()) {
     if (t.BM == 128 && t.BN == 128) launch_conv_sf<2, 2, 2, 2, Epi, true>(s, wscale, ep, st);
     else if (t.BM == 128 && t.BN == 64) launch_conv_sf<2, 1, 2, 2, Epi, true>(s, wscale, ep, st);

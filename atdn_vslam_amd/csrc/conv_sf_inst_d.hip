@@ -1,7 +1,5 @@
 #include "conv_sf_dispatch_impl.h"
 namespace atdn {
-ATDN_INSTANTIATE_CONV_SF(SfAggregate)
 ATDN_INSTANTIATE_CONV_SF(SfGruZR)
 ATDN_INSTANTIATE_CONV_SF(SfGruQ)
-ATDN_INSTANTIATE_CONV_SF(SfFlowDelta)
 }

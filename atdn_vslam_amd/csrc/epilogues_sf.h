@@ -107,19 +107,6 @@ struct SfVT {
   }
 };
 
-struct SfAggregate {
-  static constexpr bool kStats = false;
-  static constexpr bool kPrefetch = true;
-  const float* gamma;
-  const float* mf; long mb; int ldm;   // sf
-  float* dst; long ob; int ld;          // sf
-  struct Aux { float x; };
-  __device__ __forceinline__ Aux load(int img, int m, int n) const { return {sf_load(mf, (long)img * mb + (long)m * ldm, n)}; }
-  __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
-    sf_store(dst, (long)img * ob + (long)m * ld, n, x.x + gamma[0] * a);
-  }
-};
-
 struct SfGruZR {
   static constexpr bool kStats = false;
   static constexpr bool kPrefetch = true;
@@ -196,9 +183,6 @@ struct SfGruQ {
 };
 
 struct SfFlowDelta {
-  static constexpr bool kStats = false;
-  static constexpr bool kPrefetch = true;
-  static constexpr int kGen6 = 1;  // conv_sf6.h (3x3), classic orientation: N = 2
   const float* bias;
   float* coords1;   // fp32 [img][pix][2]
   float* flow4;     // fp32 [img][pix][4]

@@ -52,26 +52,17 @@ class GmaNet {
 
   int H, W, H8, W8, N, ldN, maxB, precision;
   int dev_ = 0;   // device the handle lives on
-  // feature network, split-f16 pipeline: conv2 of every residual block normalises conv1's raw output in its own
-  // patch loader (conv_sf6.h NORM); ATDN_NORM_ON_LOAD=0 keeps the separate normalisation pass
+  // feature network, split-f16 pipeline (precision 1): conv2 of every residual block normalises conv1's raw output in its own
+  // patch loader (conv_sf6.h NORM); the f16 fast mode keeps the separate normalisation pass
   bool norm_on_load_ = false;
-  // halo-patch convolutions on v_mfma_f32_16x16x32_f16 (conv_sf6.h, M16); ATDN_CONV_M32=1 keeps the 32x32x16 loop
-  bool mfma16_ = true;
-  // ATDN_STEM_LEGACY=1: the 7x7 stems on the exact-fp32 ROW-mode engine (conv_mfma.h) instead of stem_sf.hip
-  bool stem_legacy_ = false;
-  // split-f16 pipeline, row-major pyramid (ATDN_LOOKUP_LEGACY=1): level 1 = fmap1 x (2x2-pooled fmap2)^T, a quarter-size
-  // GEMM, instead of pooling the 210 MB level-0 volume (correlation is linear in the target features)
-  DeviceBuf fpool_;
-  // split-f16 pipeline: attention as QK^T with the softmax fused in + the streaming attention x V kernel (attention.hip);
-  // ATDN_ATTN_LEGACY=1 keeps the round-1 path (logits GEMM, softmax pass, attention x V on the generic GEMM kernel)
-  // split-f16 pipeline: correlation pyramid in bricks (4 x 8 cells = one 128-byte line), every level a GEMM against
-  // pooled features in brick order, lookup fused with convc1 (lookup_fused.hip); ATDN_LOOKUP_LEGACY=1 keeps the
-  // row-major pyramid, the separate lookup kernel and the convc1 GEMM of round 1
-  bool lookup_legacy_ = false;
+  // precision 0 (exact-fp32 MFMA everywhere) keeps the classical data flow: row-major correlation pyramid pooled from the
+  // level-0 volume, separate lookup and convc1, fp32 logits + softmax pass + attention x V on the GEMM engine. The split-f16
+  // modes use the bricked pyramid (every level a GEMM against pooled features in brick order, 4 x 8 cells = one 128-byte
+  // line), the lookup fused with convc1 (lookup_fused.hip) and the fused attention kernels (attention.hip).
+  bool classic_ = false;
   DeviceBuf fbrick_[4], fplain_[3], coords_used_;   // features in brick order (levels 0-3), plain pooled features (1-3)
   int brickBW_[4], brickBH_[4], brickNB_[4];
   BrickPyramid brick_pyramid() const;
-  bool attn_legacy_ = false;
   DeviceBuf rowmax_, rinv_;
 
  private:
@@ -85,7 +76,6 @@ class GmaNet {
   void iteration_sf(int B, hipStream_t st);
   void capture(int B, int iters);
   void launch_body(int B, int iters, hipStream_t st);
-  int enc_sub_ = 0;    // frames per depth-first pass of the encoders (0: all frames of a launch breadth-first)
   int seq_ = 0;        // 0: pair mode; 1: sequence (B+1 frames, every frame through fnet once); 2: sequence continued
                        //    (frame 0 is the previous call's last frame: its features are reused, fnet sees B frames)
   int last_frame_ = -1;  // fmap_ slot of the last frame of the previous sequence call
@@ -99,15 +89,13 @@ class GmaNet {
   long convf1_vw_off_ = -1;  // convf1 weights as [tap*2 + c][128] for small_convs.hip
   long fh2_w32_off_ = -1;    // flow head conv2 weights as fp32 [tap*2 + output][256] for the fused flow head
   DeviceBuf fhG_;            // conv2 partial sums [maxB * N][18]
-  // ATDN_FLOWHEAD_FUSED=0: conv1 -> sf tensor -> separate conv2 kernel (the path the fusion replaced)
-  bool flowhead_fused_ = true;
   PackedConv gru_zr_[2], gru_q_[2], fh1_, fh2_, mask0_, mask2_;
   PackedConv gru_zr_ctx_[2], gru_q_ctx_[2];  // sf mode: context-channel (inp) slices, applied once per pair
   const float* gamma_ = nullptr;
   long gamma_off_ = -1;
 
   // workspace
-  DeviceBuf img4_, enc_[4], sim_, scratch_, pcnt_, fin_, fmap_, psum_, pm2_, mean_[2], rstd_[2];
+  DeviceBuf img4_, enc_[4], scratch_, pcnt_, fin_, fmap_, psum_, pm2_, mean_[2], rstd_[2];
   DeviceBuf pyr_[4], h_[2], x_, qk_, attn_, vT_, corrfeat_, cor1_, corflo_, flo1_, z_, rh_, fh_, mask_;
   DeviceBuf coords1_, flow4_, pre_zr_[2], pre_q_[2];
   int pyrH_[4], pyrW_[4];

@@ -30,15 +30,15 @@ extern template TileChoice conv_dispatch<MODE_ROW, SfBias<ACT_RELU>>(const ConvS
 ATDN_EXTERN_SF(SfBias<ACT_NONE>) ATDN_EXTERN_SF(SfBias<ACT_RELU>) ATDN_EXTERN_SF(EpiBias<ACT_NONE>)
 ATDN_EXTERN_SF(EpiBiasStats) ATDN_EXTERN_SF(SfBiasReluAddRelu) ATDN_EXTERN_SF(SfContextSplit)
 ATDN_EXTERN_SF(EpiScale) ATDN_EXTERN_SF(SfQK) ATDN_EXTERN_SF(SfVT)
-ATDN_EXTERN_SF(SfAggregate) ATDN_EXTERN_SF(SfGruZR) ATDN_EXTERN_SF(SfGruQ) ATDN_EXTERN_SF(SfFlowDelta)
+ATDN_EXTERN_SF(SfGruZR) ATDN_EXTERN_SF(SfGruQ)
 
 namespace {
 
 // precision mode 2: the sf convolutions of this thread issue only the hi x hi MFMA while the guard lives (conv_sf.h)
 struct FastGuard {
-  bool prev, prev16;
-  explicit FastGuard(bool on, bool m16 = true) : prev(sf_fast_mode()), prev16(sf_mfma16()) { sf_fast_mode() = on; sf_mfma16() = m16; }
-  ~FastGuard() { sf_fast_mode() = prev; sf_mfma16() = prev16; }
+  bool prev;
+  explicit FastGuard(bool on) : prev(sf_fast_mode()) { sf_fast_mode() = on; }
+  ~FastGuard() { sf_fast_mode() = prev; }
 };
 
 constexpr int XLD = 384;       // GRU input x = [inp | motion(126) flow(2) | motion_global]  (update.py:130)
@@ -49,7 +49,7 @@ ConvShape conv_shape(const PackedConv& L, const float* src, int ld, long sb, int
   ConvShape s;
   s.src0 = src; s.ld0 = ld; s.sb0 = sb; s.C0 = L.C;
   s.H = H; s.W = W; s.KH = L.KH; s.KW = L.KW; s.stride = stride; s.padH = padH; s.padW = padW;
-  s.w = L.w; s.wfrag = L.wf; s.wfrag16 = L.wf16; s.ldw = L.ldw; s.N = L.N; s.nimg = nimg;
+  s.w = L.w; s.wfrag16 = L.wf16; s.ldw = L.ldw; s.N = L.N; s.nimg = nimg;
   return s;
 }
 
@@ -118,7 +118,7 @@ void GmaNet::profile(int B, int iters, int reps, float* ms, hipStream_t st, int 
     else launch_init_coords(nullptr, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
     ATDN_HIP(hipEventCreate(&t.start));
     ATDN_HIP(hipEventRecord(t.start, st));
-    try { if (precision >= 1) { FastGuard fg(precision == 2, mfma16_); run_body_sf(B, iters, st); } else run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
+    try { if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, st); } else run_body(B, iters, st); } catch (...) { timer_ = nullptr; throw; }
     timer_ = nullptr;
     ATDN_HIP(hipStreamSynchronize(st));
     hipEvent_t prev = t.start;
@@ -138,13 +138,8 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   ATDN_CHECK(H % 8 == 0 && W % 8 == 0 && H >= 64 && W >= 64, "frame size must be a multiple of 8 (use the padder)");
   ATDN_CHECK(max_batch >= 1 && max_batch <= 64, "max_batch out of range");
   H8 = H / 8; W8 = W / 8; N = H8 * W8; ldN = round_up(N, 32);
-  flowhead_fused_ = !(getenv("ATDN_FLOWHEAD_FUSED") && getenv("ATDN_FLOWHEAD_FUSED")[0] == '0');
-  stem_legacy_ = getenv("ATDN_STEM_LEGACY") && getenv("ATDN_STEM_LEGACY")[0] == '1';
-  norm_on_load_ = precision == 1 && !(getenv("ATDN_NORM_ON_LOAD") && getenv("ATDN_NORM_ON_LOAD")[0] == '0');
-  lookup_legacy_ = precision == 0 || (getenv("ATDN_LOOKUP_LEGACY") && getenv("ATDN_LOOKUP_LEGACY")[0] == '1');
-  attn_legacy_ = precision == 0 || (getenv("ATDN_ATTN_LEGACY") && getenv("ATDN_ATTN_LEGACY")[0] == '1');
-  mfma16_ = !(getenv("ATDN_CONV_M32") && getenv("ATDN_CONV_M32")[0] == '1');
-  if (const char* es = getenv("ATDN_ENC_SUB")) enc_sub_ = atoi(es);
+  norm_on_load_ = precision == 1;   // (the f16 fast mode keeps the separate normalisation pass: its conv kernels are FAST builds)
+  classic_ = precision == 0;        // exact-fp32 mode: row-major pyramid + separate lookup, logits + softmax pass + GEMM
   const char* ng = getenv("ATDN_NO_GRAPH");
   use_graph_ = !(ng && ng[0] == '1');
   (void)hipGetDevice(&dev_);   // (no throw: argument errors must be reportable without a device; finalize() needs one anyway)
@@ -156,10 +151,10 @@ GmaNet::~GmaNet() {
   (void)hipDeviceSynchronize();
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
                       &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
-                      &pre_zr_[1], &pre_q_[0], &pre_q_[1], &fpool_, &rowmax_, &rinv_,
+                      &pre_zr_[1], &pre_q_[0], &pre_q_[1], &rowmax_, &rinv_,
                       &fbrick_[0], &fbrick_[1], &fbrick_[2], &fbrick_[3], &fplain_[0], &fplain_[1], &fplain_[2], &coords_used_, &fhG_};
   for (auto* b : all) b->release();
   arena_.release();
@@ -176,7 +171,7 @@ void GmaNet::finalize() {
   fnet_ = pack_encoder(arena_, sd_, "fnet.", false, sf);
   cnet_ = pack_encoder(arena_, sd_, "cnet.", true, sf);
   convc1_ = tap({u + "encoder.convc1"});
-  if (sf && !lookup_legacy_) pack_fragment_major16(arena_, convc1_);   // the fused lookup kernel loads operand-order weights (16x16x32)
+  if (sf) pack_fragment_major16(arena_, convc1_);   // the fused lookup kernel loads operand-order weights (16x16x32)
   convc2_ = tap({u + "encoder.convc2"});
   convf1_ = pack_conv(arena_, sd_, {u + "encoder.convf1"}, MODE_ROW, 4);
   {  // the same weights as [(ky*7 + kx)*2 + c][128] for the register-tiled VALU kernel (small_convs.hip)
@@ -234,7 +229,6 @@ void GmaNet::finalize() {
   const long n8 = (long)B * N;
   img4_.alloc(2L * B * H * W * 4);
   for (int i = 0; i < (sf ? 4 : 3); ++i) enc_[i].alloc(2L * B * H2 * W2 * 64);
-  if (sf && attn_legacy_) sim_.alloc((long)B * N * ldN);
   fmap_.alloc(2L * B * N * 256);
   const long groups = (long)cdiv(H2 * W2, 64) * 4 + 8;
   psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128); pcnt_.alloc(2L * B * groups); fin_.alloc(2L * B * 32 * 128 * 4 * 2);
@@ -244,10 +238,9 @@ void GmaNet::finalize() {
   ATDN_CHECK(pyrH_[3] >= 2 && pyrW_[3] >= 2, "frame too small for a 4-level pyramid");
   for (int l = 0; l < 4; ++l) {
     brickBW_[l] = cdiv(pyrW_[l], 8); brickBH_[l] = cdiv(pyrH_[l], 4); brickNB_[l] = brickBW_[l] * brickBH_[l] * 32;
-    pyr_[l].alloc(n8 * (lookup_legacy_ ? pyrH_[l] * pyrW_[l] : brickNB_[l]));
+    pyr_[l].alloc(n8 * (classic_ ? pyrH_[l] * pyrW_[l] : brickNB_[l]));
   }
-  if (sf && lookup_legacy_) fpool_.alloc((long)B * pyrH_[1] * pyrW_[1] * 256);
-  if (sf && !lookup_legacy_) {
+  if (sf) {
     for (int l = 0; l < 4; ++l) fbrick_[l].alloc((long)B * brickNB_[l] * 256);
     for (int l = 1; l < 4; ++l) fplain_[l - 1].alloc((long)B * pyrH_[l] * pyrW_[l] * 256);
     coords_used_.alloc(n8 * 2);
@@ -255,7 +248,7 @@ void GmaNet::finalize() {
   h_[0].alloc(n8 * 128); h_[1].alloc(n8 * 128); x_.alloc(n8 * XLD);
   const AttnGeom ag = attn_geom(B, N, ldN);
   qk_.alloc(n8 * 256); attn_.alloc(std::max(n8 * ldN, attn_floats(ag))); vT_.alloc((long)B * 128 * ldN);
-  if (!attn_legacy_) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
+  if (sf) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
   z_.alloc(n8 * 128); rh_.alloc(n8 * 128); fh_.alloc(n8 * 256); mask_.alloc(n8 * 576);
   if (sf) fhG_.alloc(n8 * 18);
@@ -268,7 +261,7 @@ void GmaNet::finalize() {
   ATDN_HIP(hipMemset(flow4_.p, 0, flow4_.n * sizeof(float)));
   ATDN_HIP(hipDeviceSynchronize());
   ws_bytes_ = 0;
-  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &sim_, &fmap_, &psum_, &pm2_, &pyr_[0], &pyr_[1], &pyr_[2],
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &fmap_, &psum_, &pm2_, &pyr_[0], &pyr_[1], &pyr_[2],
                       &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_, &corrfeat_, &cor1_, &corflo_, &flo1_, &z_,
                       &rh_, &fh_, &mask_, &coords1_, &flow4_};
   for (auto* b : all) ws_bytes_ += (size_t)b->n * sizeof(float);
@@ -385,7 +378,7 @@ void GmaNet::iteration(int B, hipStream_t st) {
     g.C0 = 128; g.src1 = x_.p; g.ld1 = XLD; g.sb1 = (long)N * XLD; g.C1 = XLD;
     conv_dispatch<MODE_TAP>(g, EpiGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128}, st);
     mark(p ? ST_GRU_ZR_V : ST_GRU_ZR, st);
-    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.wfrag16 = gru_q_[p].wf16; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
+    g.src0 = rh_.p; g.w = gru_q_[p].w; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_dispatch<MODE_TAP>(g, EpiGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128}, st);
     mark(p ? ST_GRU_Q_V : ST_GRU_Q, st);
   }
@@ -469,33 +462,20 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
       launch_in_finalize_cnt(psum_.p, pm2_.p, nullptr, nimg, groups, oh * ow, L.N, 1e-5f, mean_[slot].p, rstd_[slot].p,
                              reinterpret_cast<double*>(fin_.p), st);
   };
-  if (!stem_legacy_) {
-    // 7x7 stem on the split-f16 engine (stem_sf.hip); with InstanceNorm the conv runs twice (statistics, then
-    // normalise + ReLU -> sf) instead of materialising the raw tensor
-    if (instance) {
-      const int groups = stem_sf_groups(h, w);
-      ATDN_CHECK((long)nimg * groups * 64 <= psum_.n && (long)nimg * groups <= pcnt_.n, "statistics scratch too small");
-      launch_stem_sf(1, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, nullptr, psum_.p, pm2_.p, pcnt_.p, nullptr,
-                     nullptr, st);
-      launch_in_finalize_cnt(psum_.p, pm2_.p, pcnt_.p, nimg, groups, h * w, 64, 1e-5f, mean_[0].p, rstd_[0].p,
-                             reinterpret_cast<double*>(fin_.p), st);
-      launch_stem_sf(2, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, X, nullptr, nullptr, nullptr, mean_[0].p,
-                     rstd_[0].p, st);
-    } else {
-      launch_stem_sf(0, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, X, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, st);
-    }
-  } else if (instance) {
-    ConvShape s = conv_shape(E.stem, images, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
-    EpiBiasStats ep{E.stem.b, R, (long)h * w * 64, 64, psum_.p, pm2_.p, 0};
-    TileChoice t = conv_dispatch<MODE_ROW>(s, ep, st);
-    const int groups = cdiv(h * w, t.BM) * (t.BM / 32);
-    launch_in_finalize_cnt(psum_.p, pm2_.p, nullptr, nimg, groups, h * w, 64, 1e-5f, mean_[0].p, rstd_[0].p,
+  // 7x7 stem on the split-f16 engine (stem_sf.hip); with InstanceNorm the conv runs twice (statistics, then
+  // normalise + ReLU -> sf) instead of materialising the raw tensor
+  if (instance) {
+    const int groups = stem_sf_groups(h, w);
+    ATDN_CHECK((long)nimg * groups * 64 <= psum_.n && (long)nimg * groups <= pcnt_.n, "statistics scratch too small");
+    launch_stem_sf(1, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, nullptr, psum_.p, pm2_.p, pcnt_.p, nullptr,
+                   nullptr, st);
+    launch_in_finalize_cnt(psum_.p, pm2_.p, pcnt_.p, nimg, groups, h * w, 64, 1e-5f, mean_[0].p, rstd_[0].p,
                            reinterpret_cast<double*>(fin_.p), st);
-    launch_in_apply_sf(R, X, mean_[0].p, rstd_[0].p, nullptr, nullptr, nullptr, nullptr, nimg, (long)h * w, 64, st);
+    launch_stem_sf(2, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, X, nullptr, nullptr, nullptr, mean_[0].p,
+                   rstd_[0].p, st);
   } else {
-    ConvShape s = conv_shape(E.stem, images, 4, (long)H * W * 4, nimg, H, W, 2, 3, 3);
-    conv_dispatch<MODE_ROW>(s, SfBias<ACT_RELU>{E.stem.b, X, (long)h * w * 64, 64}, st);
+    launch_stem_sf(0, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, X, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, st);
   }
   int c = 64;
   for (int bi = 0; bi < 6; ++bi) {
@@ -548,20 +528,10 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
 void GmaNet::iteration_sf(int B, hipStream_t st) {
   const long n8 = (long)B * N;
   ConvShape s;
-  if (!lookup_legacy_) {
-    // cor1 = relu(convc1(lookup(coords1))) in one kernel: the 324 samples of a pixel never leave the CU
-    launch_lookup_conv(brick_pyramid(), coords1_.p, n8, coords_used_.p, convc1_.wf16, convc1_.wscale, convc1_.b, cor1_.p,
-                       sf_fast_mode(), st);
-    mark(ST_LOOKUP, st);
-  } else {
-    PyramidLevels pl;
-    for (int l = 0; l < 4; ++l) { pl.base[l] = pyr_[l].p; pl.H[l] = pyrH_[l]; pl.W[l] = pyrW_[l]; }
-    launch_lookup_sf(pl, coords1_.p, n8, corrfeat_.p, CORR_LD, st);
-    mark(ST_LOOKUP, st);
-    s = conv_shape(convc1_, corrfeat_.p, CORR_LD, (long)N * CORR_LD, B, H8, W8, 1, 0, 0);
-    conv_sf_dispatch(s, convc1_.wscale, SfBias<ACT_RELU>{convc1_.b, cor1_.p, (long)N * 256, 256}, st);
-    mark(ST_CONVC1, st);
-  }
+  // cor1 = relu(convc1(lookup(coords1))) in one kernel: the 324 samples of a pixel never leave the CU
+  launch_lookup_conv(brick_pyramid(), coords1_.p, n8, coords_used_.p, convc1_.wf16, convc1_.wscale, convc1_.b, cor1_.p,
+                     sf_fast_mode(), st);
+  mark(ST_LOOKUP, st);
   s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
   // (Round 3 captured the flow branch — convf1, convf2: independent of the correlation branch — as a parallel branch of the
@@ -580,18 +550,10 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   ConvShape v;
   v.src0 = to_v_.w; v.ld0 = 128; v.sb0 = 0; v.C0 = 128; v.H = 1; v.W = 128;
   v.w = mf; v.wb = (long)N * XLD; v.ldw = XLD; v.N = N; v.nimg = B;
-  if (attn_legacy_) conv_sf_dispatch(v, to_v_.wscale, SfBias<ACT_NONE>{nullptr, vT_.p, (long)128 * ldN, ldN}, st);
-  else conv_sf_dispatch(v, to_v_.wscale, SfVT{vT_.p, (long)128 * ldN, ldN}, st);   // keys of a chunk in operand order
+  conv_sf_dispatch(v, to_v_.wscale, SfVT{vT_.p, (long)128 * ldN, ldN}, st);   // keys of a chunk in operand order
   mark(ST_AGG_VT, st);
-  if (attn_legacy_) {
-    ConvShape a;
-    a.src0 = attn_.p; a.ld0 = ldN; a.sb0 = (long)N * ldN; a.C0 = ldN; a.H = 1; a.W = N;
-    a.w = vT_.p; a.wb = (long)128 * ldN; a.ldw = ldN; a.N = 128; a.nimg = B;
-    conv_sf_dispatch(a, 1.f, SfAggregate{gamma_, mf, (long)N * XLD, XLD, x_.p + 256, (long)N * XLD, XLD}, st);
-  } else {
-    launch_attn_v(attn_.p, rinv_.p, attn_geom(B, N, ldN), vT_.p, gamma_, mf, x_.p + 256, (long)N * XLD, XLD,
-                  sf_fast_mode(), st);
-  }
+  launch_attn_v(attn_.p, rinv_.p, attn_geom(B, N, ldN), vT_.p, gamma_, mf, x_.p + 256, (long)N * XLD, XLD,
+                sf_fast_mode(), st);
   mark(ST_AGG, st);
 
   for (int p = 0; p < 2; ++p) {
@@ -603,21 +565,16 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
     conv_sf_dispatch(g, gru_zr_[p].wscale,
                      SfGruZR{gru_zr_[p].b, hin, z_.p, rh_.p, (long)N * 128, pre_zr_[p].p, (long)N * 256}, st);
     mark(p ? ST_GRU_ZR_V : ST_GRU_ZR, st);
-    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag = gru_q_[p].wf; g.wfrag16 = gru_q_[p].wf16; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
+    g.src0 = rh_.p; g.w = gru_q_[p].w; g.wfrag16 = gru_q_[p].wf16; g.ldw = gru_q_[p].ldw; g.N = gru_q_[p].N;
     conv_sf_dispatch(g, gru_q_[p].wscale, SfGruQ{gru_q_[p].b, hin, z_.p, hout, (long)N * 128, pre_q_[p].p}, st);
     mark(p ? ST_GRU_Q_V : ST_GRU_Q, st);
   }
 
   s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   const SfFlowDelta fd{fh2_.b, coords1_.p, flow4_.p, x_.p, XLD, (long)N * XLD, 254, W8, (long)N};
-  if (flowhead_fused_ && flow_head_fusable(s)) {
-    // conv1 with conv2's partial sums in its epilogue, then the 3 x 3 gather (small_convs.h)
-    launch_flow_head_fused(s, fh1_.wscale, SfFlowHeadPartial{fh1_.b, arena_.dev(fh2_w32_off_), fhG_.p, (long)N}, st);
-    launch_flow_gather(fhG_.p, B, H8, W8, fd, st);
-  } else {
-    conv_sf_dispatch(s, fh1_.wscale, SfBias<ACT_RELU>{fh1_.b, fh_.p, (long)N * 256, 256}, st);
-    launch_flow_head2(fh_.p, B, H8, W8, fh2_.w, fh2_.ldw, fh2_.wscale, fd, st);
-  }
+  // conv1 with conv2's partial sums in its epilogue, then the 3 x 3 gather (small_convs.h)
+  launch_flow_head_fused(s, fh1_.wscale, SfFlowHeadPartial{fh1_.b, arena_.dev(fh2_w32_off_), fhG_.p, (long)N}, st);
+  launch_flow_gather(fhG_.p, B, H8, W8, fd, st);
   mark(ST_FLOWHEAD, st);
 }
 
@@ -627,87 +584,49 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   // were already moved into fmap_ slot 0 by forward_sequence and only frames 1..B are encoded (img4_ still holds all
   // B+1 frames: the context network needs frame 0)
   const int nfeat = seq_ == 0 ? 2 * B : seq_ == 1 ? B + 1 : B;
-  ConvShape s;
-  // Depth-first over sub-batches of frames (enc_sub_ frames at most, sizes balanced): at 16 frames a 64-channel half-resolution
-  // map is 474 MB, so every conv -> conv hand-off of the breadth-first order is a round trip through HBM; with <= 3-4 frames per
-  // pass the producer's output and the consumer's input fit the 256 MiB Infinity Cache together. Frames are independent
-  // (InstanceNorm statistics are per image, tile heights follow from the geometry alone), so the bits do not change.
-  {
-    const int first = seq_ == 2 ? 1 : 0;
-    const int nsb = enc_sub_ > 0 ? cdiv(nfeat, enc_sub_) : 1;
-    for (int sb = 0, i0 = 0; sb < nsb; ++sb) {
-      const int n = nfeat / nsb + (sb < nfeat % nsb ? 1 : 0);
-      run_encoder_sf(fnet_, true, n, st, &f, first + i0);
-      s = conv_shape(fnet_.head, f, 128, (long)N * 128, n, H8, W8, 1, 0, 0);
-      float* fdst = fmap_.p + (long)(first + i0) * N * 256;
-      conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fdst, (long)N * 256, 256}, st);
-      i0 += n;
-    }
-  }
+  // (Round 4 measured the encoders depth-first in sub-batches of <= 2-8 frames, so that a conv's output and its consumer's
+  // input fit the 256 MiB Infinity Cache together: every extra launch cost 10-12 us and nothing came back from the cache,
+  // profiles/r04_ab_encoder_subbatch.txt. All frames of a launch go through a layer together.)
+  run_encoder_sf(fnet_, true, nfeat, st, &f, seq_ == 2 ? 1 : 0);
+  ConvShape s = conv_shape(fnet_.head, f, 128, (long)N * 128, nfeat, H8, W8, 1, 0, 0);
+  float* fdst = fmap_.p + (seq_ == 2 ? (long)N * 256 : 0);
+  conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fdst, (long)N * 256, 256}, st);
   mark(ST_FNET, st);
 
   ConvShape c;
   c.src0 = fmap_.p; c.ld0 = 256; c.sb0 = (long)N * 256; c.C0 = 256; c.H = 1; c.W = N;
   c.w = fmap_.p + (long)(seq_ ? 1 : B) * N * 256; c.wb = (long)N * 256; c.ldw = 256; c.N = N; c.nimg = B;
-  if (!lookup_legacy_) {
-    // every level = fmap1 x (target features of that level in BRICK order)^T: output column n' is the brick address of
-    // the target cell, padding cells are zero feature rows (lookup_fused.hip). Levels 1-3: 2x2-pooled features —
-    // correlation is linear in the target features, so avg_pool2d of corr.py:28-30 commutes with the dot product.
-    const float* target = c.w;
-    for (int l = 0; l < 4; ++l) {
-      const float* plain = target;
-      long plain_sb = (long)N * 256;
-      if (l > 0) {
-        const float* prev = l == 1 ? target : fplain_[l - 2].p;
-        const long prev_sb = l == 1 ? (long)N * 256 : (long)pyrH_[l - 1] * pyrW_[l - 1] * 256;
-        plain_sb = (long)pyrH_[l] * pyrW_[l] * 256;
-        launch_pool_features_sf(prev, B, pyrH_[l - 1], pyrW_[l - 1], 256, prev_sb, fplain_[l - 1].p, plain_sb, st);
-        plain = fplain_[l - 1].p;
-      }
-      launch_brick_rows(plain, plain_sb, B, pyrH_[l], pyrW_[l], 256, fbrick_[l].p, (long)brickNB_[l] * 256, st);
-      ConvShape cl = c;
-      cl.w = fbrick_[l].p; cl.wb = (long)brickNB_[l] * 256; cl.N = brickNB_[l];
-      conv_sf_dispatch(cl, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[l].p, (long)N * brickNB_[l], brickNB_[l]}, st);
-      if (l == 0) mark(ST_CORR, st);
+  // every level = fmap1 x (target features of that level in BRICK order)^T: output column n' is the brick address of
+  // the target cell, padding cells are zero feature rows (lookup_fused.hip). Levels 1-3: 2x2-pooled features —
+  // correlation is linear in the target features, so avg_pool2d of corr.py:28-30 commutes with the dot product.
+  const float* target = c.w;
+  for (int l = 0; l < 4; ++l) {
+    const float* plain = target;
+    long plain_sb = (long)N * 256;
+    if (l > 0) {
+      const float* prev = l == 1 ? target : fplain_[l - 2].p;
+      const long prev_sb = l == 1 ? (long)N * 256 : (long)pyrH_[l - 1] * pyrW_[l - 1] * 256;
+      plain_sb = (long)pyrH_[l] * pyrW_[l] * 256;
+      launch_pool_features_sf(prev, B, pyrH_[l - 1], pyrW_[l - 1], 256, prev_sb, fplain_[l - 1].p, plain_sb, st);
+      plain = fplain_[l - 1].p;
     }
-    mark(ST_POOL, st);
-  } else {
-  conv_sf_dispatch(c, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[0].p, (long)N * N, N}, st);
-  mark(ST_CORR, st);
-  {
-    const int N1 = pyrH_[1] * pyrW_[1];
-    launch_pool_features_sf(c.w, B, H8, W8, 256, (long)N * 256, fpool_.p, (long)N1 * 256, st);
-    ConvShape c1 = c;
-    c1.w = fpool_.p; c1.wb = (long)N1 * 256; c1.N = N1;
-    conv_sf_dispatch(c1, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[1].p, (long)N * N1, N1}, st);
-    for (int l = 2; l < 4; ++l) launch_avgpool(pyr_[l - 1].p, pyrH_[l - 1], pyrW_[l - 1], pyr_[l].p, (long)B * N, st);
+    launch_brick_rows(plain, plain_sb, B, pyrH_[l], pyrW_[l], 256, fbrick_[l].p, (long)brickNB_[l] * 256, st);
+    ConvShape cl = c;
+    cl.w = fbrick_[l].p; cl.wb = (long)brickNB_[l] * 256; cl.N = brickNB_[l];
+    conv_sf_dispatch(cl, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[l].p, (long)N * brickNB_[l], brickNB_[l]}, st);
+    if (l == 0) mark(ST_CORR, st);
   }
   mark(ST_POOL, st);
-  }
 
-  {
-    const int nsb = enc_sub_ > 0 ? cdiv(B, enc_sub_) : 1;
-    for (int sb = 0, i0 = 0; sb < nsb; ++sb) {
-      const int n = B / nsb + (sb < B % nsb ? 1 : 0);
-      run_encoder_sf(cnet_, false, n, st, &f, i0);
-      s = conv_shape(cnet_.head, f, 128, (long)N * 128, n, H8, W8, 1, 0, 0);
-      conv_sf_dispatch(s, cnet_.head.wscale,
-                       SfContextSplit{cnet_.head.b, h_[0].p + (long)i0 * N * 128, (long)N * 128, x_.p + (long)i0 * N * XLD, (long)N * XLD, XLD}, st);
-      i0 += n;
-    }
-  }
+  run_encoder_sf(cnet_, false, B, st, &f);
+  s = conv_shape(cnet_.head, f, 128, (long)N * 128, B, H8, W8, 1, 0, 0);
+  conv_sf_dispatch(s, cnet_.head.wscale,
+                   SfContextSplit{cnet_.head.b, h_[0].p, (long)N * 128, x_.p, (long)N * XLD, XLD}, st);
   mark(ST_CNET, st);
 
   s = conv_shape(to_qk_, x_.p, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
   conv_sf_dispatch(s, to_qk_.wscale, SfQK{1.0f / sqrtf(128.0f), 128, qk_.p, (long)N * 256, 256}, st);
-  if (attn_legacy_) {
-    ConvShape q;
-    q.src0 = qk_.p; q.ld0 = 256; q.sb0 = (long)N * 256; q.C0 = 128; q.H = 1; q.W = N;
-    q.w = qk_.p + 128; q.wb = (long)N * 256; q.ldw = 256; q.N = N; q.nimg = B;
-    conv_sf_dispatch(q, 1.f, EpiScale{1.0f, sim_.p, (long)N * ldN, ldN}, st);
-    mark(ST_ATTN_LOGITS, st);
-    launch_softmax_rows_sf(sim_.p, attn_.p, (long)B * N, N, ldN, st);
-  } else {
+  {
     // Q K^T with the row softmax fused in (attention.hip): a cheap first sweep (f16 x f16 logits) for the row maxima,
     // then the full-precision sweep that writes exp(s - max) in MFMA-operand order and the row sums
     const AttnGeom ag = attn_geom(B, N, ldN);
@@ -740,7 +659,7 @@ void GmaNet::capture(int B, int iters) {
   hipGraph_t graph = nullptr;
   ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
   try {
-    if (precision >= 1) { FastGuard fg(precision == 2, mfma16_); run_body_sf(B, iters, cap_stream_); } else run_body(B, iters, cap_stream_);
+    if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, cap_stream_); } else run_body(B, iters, cap_stream_);
   } catch (...) {
     (void)hipStreamEndCapture(cap_stream_, &graph);
     if (graph) (void)hipGraphDestroy(graph);
@@ -786,7 +705,7 @@ void GmaNet::launch_body(int B, int iters, hipStream_t st) {
     if (!graphs_.count(key)) capture(B, iters);
     ATDN_HIP(hipGraphLaunch(graphs_[key], st));
   } else {
-    if (precision >= 1) { FastGuard fg(precision == 2, mfma16_); run_body_sf(B, iters, st); } else run_body(B, iters, st);
+    if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, st); } else run_body(B, iters, st);
   }
 }
 
@@ -816,7 +735,7 @@ BrickPyramid GmaNet::brick_pyramid() const {
 
 long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_t st) {
   const std::string k(name);
-  if (!lookup_legacy_ && k.size() == 4 && k.compare(0, 3, "pyr") == 0 && k[3] >= '0' && k[3] <= '3') {
+  if (!classic_ && k.size() == 4 && k.compare(0, 3, "pyr") == 0 && k[3] >= '0' && k[3] <= '3') {
     // bricked level -> the reference's row-major [pixel][H_l * W_l]
     const int l = k[3] - '0';
     const long rows = (long)maxB * N, total = rows * pyrH_[l] * pyrW_[l];
@@ -827,7 +746,7 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
     ATDN_HIP(hipMemcpy(host, scratch_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return n;
   }
-  if (!lookup_legacy_ && k == "corrfeat") {
+  if (!classic_ && k == "corrfeat") {
     // the fused kernel keeps the samples on chip: recompute them at the coordinates the last lookup used
     launch_lookup_bricks(brick_pyramid(), coords_used_.p, (long)maxB * N, corrfeat_.p, st);
   }
@@ -844,7 +763,7 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
   else if (k == "qk") b = &qk_; else if (k == "img4") b = &img4_;
   if (!b) return -1;
   long n = std::min(capacity, b->n);
-  if (k == "attn" && !attn_legacy_) {   // fragment-major exp(s - max) + row sums -> normalised fp32 rows [maxB][N][ldN]
+  if (k == "attn" && !classic_) {   // fragment-major exp(s - max) + row sums -> normalised fp32 rows [maxB][N][ldN]
     const long rows = (long)maxB * N * ldN;
     if (scratch_.n < rows) { scratch_.release(); scratch_.alloc(rows); }
     ATDN_HIP(hipMemsetAsync(scratch_.p, 0, (size_t)rows * sizeof(float), st));

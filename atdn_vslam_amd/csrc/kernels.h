@@ -5,7 +5,6 @@
 namespace atdn {
 
 bool& sf_fast_mode();  // see conv_sf.h
-bool& sf_mfma16();     // see conv_sf.h
 
 struct PyramidLevels {  // correlation pyramid of ONE batch: level l is [B*N][H_l*W_l] fp32
   const float* base[4];
@@ -88,13 +87,8 @@ void launch_from_sf(const float* src, float* dst, long rows, int C, hipStream_t 
 void launch_in_apply_sf(const float* x, float* y, const float* mean, const float* rstd, const float* res,
                         const float* res_raw, const float* rmean, const float* rrstd, int nimg, long HW, int C,
                         hipStream_t st);
-// lookup with sf output rows (ldo = 352: 324 samples + zero pad, 11 channel groups)
-void launch_lookup_sf(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
-                      hipStream_t st);
-// row softmax, fp32 logits [rows][ld] -> sf probabilities [rows][ld] (pad columns zero); ld % 32 == 0
 // 2x2 average (floor sizes) of an sf feature map [img][H*W][C] (per-image strides sb / db in floats)
 void launch_pool_features_sf(const float* src, int nimg, int H, int W, int C, long sb, float* dst, long db, hipStream_t st);
-void launch_softmax_rows_sf(const float* x, float* y, long rows, int n, int ld, hipStream_t st);
 // as launch_init_coords, x flow channels written in sf at channels cflow, cflow+1 of the sf GRU input
 void launch_init_coords_sf(const float* flow_init, int B, int H8, int W8, float* coords1, float* flow4, float* x,
                            int ldx, int cflow, hipStream_t st);

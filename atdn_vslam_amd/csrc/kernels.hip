@@ -7,10 +7,6 @@ bool& sf_fast_mode() {
   static thread_local bool fast = false;
   return fast;
 }
-bool& sf_mfma16() {
-  static thread_local bool m16 = true;
-  return m16;
-}
 
 // ------------------------------------------------------------------ block reductions (deterministic)
 __device__ __forceinline__ float wave_sum(float v) {
@@ -702,189 +698,6 @@ void launch_in_apply_sf(const float* x, float* y, const float* mean, const float
   const int grid = (int)std::min<long>(cdivl(total4, 256), 256 * 16);
   hipLaunchKernelGGL(in_apply_sf_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(x), y, mean,
                      rstd, res, reinterpret_cast<const float4*>(res_raw), rmean, rrstd, per_img4, C, total4);
-  ATDN_HIP(hipGetLastError());
-}
-
-// Lookup with the sample arithmetic of lookup_kernel. The 4 waves (levels) of a block stage the pixel's windows and
-// its 324 samples in LDS and the block stores the 352-channel sf row (11 groups of [32 hi | 32 lo]) as dwords.
-// The un-normalised coordinate of sample (i, j) separates into an x part that depends on i only and a y part that
-// depends on j only, so lanes 0-17 evaluate the 9 + 9 coordinate chains (with the reference's divisions) once per
-// level instead of 81 times. (One-wave-per-pixel forms, with all four levels in one wave, measured 13-25 % slower:
-// the kernel is bound by the scattered 48-byte window segments, not by pixels in flight.)
-__global__ __launch_bounds__(256) void lookup_sf_kernel(const PyramidLevels pyr, const float* __restrict__ coords1,
-                                                        long npix, float* __restrict__ out, int ldo) {
-  __shared__ float win[4][LK_WIN * LK_WIN + 16];
-  __shared__ float vals[352];
-  __shared__ float wgt[4][18];   // fractional weight of the 9 x positions then the 9 y positions
-  __shared__ int idx[4][18];     // window column / row of their floor()
-  const int lvl = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int Hl = pyr.H[lvl], Wl = pyr.W[lvl];
-  const float inv = 1.0f / (float)(1 << lvl);
-  const float wm1 = (float)(Wl - 1), hm1 = (float)(Hl - 1);
-  float* w = win[lvl];
-  if (threadIdx.x >= 324 - 256 && threadIdx.x < 352 - 256) vals[256 + threadIdx.x] = 0.f;  // pad channels 324..351
-  // Software pipeline over the block's pixels: the window of pixel p + grid is requested (into registers) before
-  // pixel p is processed, and the coordinates of p + 2*grid before that — two dependent HBM round trips per pixel
-  // (coordinates -> window) otherwise sit fully exposed with one pixel in flight per block.
-  const long G = gridDim.x;
-  auto window_origin = [&](float cx, float cy, float& xc, float& yc, bool& sane, int& wx0, int& wy0) {
-    xc = cx * inv; yc = cy * inv;
-    sane = (fabsf(xc) < 1.0e6f) && (fabsf(yc) < 1.0e6f);
-    wx0 = sane ? (int)floorf(xc) - 5 : -(1 << 24);
-    wy0 = sane ? (int)floorf(yc) - 5 : -(1 << 24);
-  };
-  auto fetch_window = [&](long p, int wx0, int wy0, float* v, bool* ok) {
-    const float* src = pyr.base[lvl] + p * ((long)Hl * Wl);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int c = lane + 64 * t;
-      const int wy = c / LK_WIN, wx = c - wy * LK_WIN;
-      const int y = wy0 + wy, x = wx0 + wx;
-      ok[t] = (c < LK_WIN * LK_WIN) & ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
-      v[t] = src[ok[t] ? (long)y * Wl + x : 0];
-    }
-  };
-  long p = blockIdx.x;
-  float xc = 0.f, yc = 0.f, nxc = 0.f, nyc = 0.f;
-  bool sane = false, nsane = false;
-  int wx0 = 0, wy0 = 0, nwx0 = 0, nwy0 = 0;
-  float cur[3], nxt[3];
-  bool okc[3], okn[3];
-  float2 cnext = make_float2(0.f, 0.f);
-  if (p < npix) {
-    window_origin(coords1[p * 2 + 0], coords1[p * 2 + 1], xc, yc, sane, wx0, wy0);
-    fetch_window(p, wx0, wy0, cur, okc);
-    if (p + G < npix) cnext = *reinterpret_cast<const float2*>(coords1 + (p + G) * 2);
-  }
-  for (; p < npix; p += G) {
-    const float2 cn = cnext;
-    if (p + 2 * G < npix) cnext = *reinterpret_cast<const float2*>(coords1 + (p + 2 * G) * 2);
-    if (p + G < npix) {
-      window_origin(cn.x, cn.y, nxc, nyc, nsane, nwx0, nwy0);
-      fetch_window(p + G, nwx0, nwy0, nxt, okn);
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int c = lane + 64 * t;
-      if (c < LK_WIN * LK_WIN) w[c] = okc[t] ? cur[t] : 0.f;
-    }
-    if (lane < 18) {
-      const bool isx = lane < 9;
-      const int d = isx ? lane : lane - 9;
-      const float c0 = isx ? xc : yc, sz1 = isx ? wm1 : hm1;
-      const float pos = c0 + (float)(d - 4);
-      const float g = 2.f * pos / sz1 - 1.f;
-      const float u = (g + 1.f) * (sz1 / 2.f);
-      const float fl = floorf(u);
-      wgt[lvl][lane] = u - fl;
-      idx[lvl][lane] = sane ? min(max((int)fl - (isx ? wx0 : wy0), 0), LK_WIN - 2) : 0;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes; the prefetched window stays in flight
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int k = lane + 64 * t;
-      if (k < 81) {
-        const int i = k / 9, j = k - i * 9;
-        const float ww = wgt[lvl][i], nn = wgt[lvl][9 + j];
-        const float ee = 1.f - ww, ss = 1.f - nn;
-        const float* q = w + idx[lvl][9 + j] * LK_WIN + idx[lvl][i];
-        const float v = ((q[0] * (ee * ss) + q[1] * (ww * ss)) + q[LK_WIN] * (ee * nn)) + q[LK_WIN + 1] * (ww * nn);
-        vals[lvl * 81 + k] = sane ? v : 0.f;
-      }
-    }
-    __syncthreads();
-    unsigned* orow = reinterpret_cast<unsigned*>(out + p * ldo);
-    for (int d = threadIdx.x; d < 352; d += 256) {
-      const int g = d >> 5, ww = d & 31;
-      const int c = g * 32 + 2 * (ww & 15);
-      const SfPair a = sf_split(vals[c]), b = sf_split(vals[c + 1]);
-      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-      h2 o;
-      if (ww < 16) { o[0] = a.hi; o[1] = b.hi; } else { o[0] = a.lo; o[1] = b.lo; }
-      orow[d] = *reinterpret_cast<unsigned*>(&o);
-    }
-    __syncthreads();
-    xc = nxc; yc = nyc; sane = nsane; wx0 = nwx0; wy0 = nwy0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) { cur[t] = nxt[t]; okc[t] = okn[t]; }
-  }
-}
-void launch_lookup_sf(const PyramidLevels& pyr, const float* coords1, long npix_total, float* out, int ldo,
-                      hipStream_t st) {
-  ATDN_CHECK(ldo == 352, "sf lookup rows are 352 channels (11 groups)");
-  const int grid = (int)std::min<long>(npix_total, 256 * 32);
-  hipLaunchKernelGGL(lookup_sf_kernel, dim3(grid), dim3(256), 0, st, pyr, coords1, npix_total, out, ldo);
-  ATDN_HIP(hipGetLastError());
-}
-
-// Row staged once in LDS (the fp32 logits are read from HBM a single time), then max / sum / normalise from LDS.
-constexpr int SOFTMAX_LDS_MAX = 12288;  // floats (48 KB): rows up to 12288 columns take the single-read path
-__global__ __launch_bounds__(256) void softmax_rows_sf_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
-                                                              int ld, int staged) {
-  __shared__ float sm[4];
-  extern __shared__ float rowbuf[];
-  const float* row = x + (long)blockIdx.x * ld;
-  float* orow = y + (long)blockIdx.x * ld;
-  float mx = -INFINITY;
-  if (staged) {
-    for (int i = threadIdx.x * 4; i < n; i += 1024) {  // ld % 32 == 0: float4 reads stay inside the padded row
-      const float4 v = *reinterpret_cast<const float4*>(row + i);
-      *reinterpret_cast<float4*>(rowbuf + i) = v;
-      mx = fmaxf(mx, v.x);
-      if (i + 1 < n) mx = fmaxf(mx, v.y);
-      if (i + 2 < n) mx = fmaxf(mx, v.z);
-      if (i + 3 < n) mx = fmaxf(mx, v.w);
-    }
-  } else {
-    for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, row[i]);
-  }
-  mx = block_reduce<true>(mx, sm);  // (contains the barrier that publishes rowbuf)
-  if (staged) {
-    // e = exp(v - max) is computed once, kept in LDS, and every pass walks the row in float4 (conflict-free b128
-    // LDS accesses; the 2-float stride of the old normalise loop was a 2-way bank conflict on half of all LDS cycles)
-    float s = 0.f;
-    for (int i = threadIdx.x * 4; i < n; i += 1024) {
-      float4 v = *reinterpret_cast<const float4*>(rowbuf + i);
-      v.x = expf(v.x - mx);
-      v.y = (i + 1 < n) ? expf(v.y - mx) : 0.f;
-      v.z = (i + 2 < n) ? expf(v.z - mx) : 0.f;
-      v.w = (i + 3 < n) ? expf(v.w - mx) : 0.f;
-      *reinterpret_cast<float4*>(rowbuf + i) = v;
-      s += (v.x + v.y) + (v.z + v.w);
-    }
-    s = block_reduce<false>(s, sm);
-    for (int i = threadIdx.x * 4; i < ld; i += 1024) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < n) {
-        const float4 e = *reinterpret_cast<const float4*>(rowbuf + i);   // entries >= n were written as 0 above
-        a = make_float4(e.x / s, e.y / s, e.z / s, e.w / s);
-      }
-      sf_store4(orow, 0, i, a);
-    }
-    return;
-  }
-  const float* src = row;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += expf(src[i] - mx);
-  s = block_reduce<false>(s, sm);
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  for (int i2 = threadIdx.x; i2 < ld / 2; i2 += 256) {
-    const int c = 2 * i2;
-    const float a = (c < n) ? expf(src[c] - mx) / s : 0.f;
-    const float b = (c + 1 < n) ? expf(src[c + 1] - mx) / s : 0.f;
-    const SfPair pa = sf_split(a), pb = sf_split(b);
-    _Float16* q = sf_ptr(orow, 0, c);
-    h2 hi = {pa.hi, pb.hi}, lo = {pa.lo, pb.lo};
-    *reinterpret_cast<h2*>(q) = hi;
-    *reinterpret_cast<h2*>(q + 32) = lo;
-  }
-}
-void launch_softmax_rows_sf(const float* x, float* y, long rows, int n, int ld, hipStream_t st) {
-  ATDN_CHECK(ld % 32 == 0, "sf rows need ld % 32 == 0");
-  const int staged = (ld <= SOFTMAX_LDS_MAX) ? 1 : 0;
-  hipLaunchKernelGGL(softmax_rows_sf_kernel, dim3((unsigned)rows), dim3(256), staged ? (size_t)ld * sizeof(float) : 0, st,
-                     x, y, n, ld, staged);
   ATDN_HIP(hipGetLastError());
 }
 

@@ -9,16 +9,10 @@ namespace atdn {
 // wl: weights re-ordered to [(ky*7 + kx)*2 + c][128] fp32.
 void launch_flow_conv7(const float* flow4, int nimg, int H, int W, const float* wl, const float* bias, float* out_sf,
                        hipStream_t st);
-// flow head conv2: sf [nimg][H*W][256] -> 2 channels through the SfFlowDelta epilogue. wsf: the layer's sf-packed
-// weights ([2][9*256] floats = [n][tap][chunk][32 hi | 32 lo]), wscale its accumulator scale.
-void launch_flow_head2(const float* fh_sf, int nimg, int H, int W, const float* wsf, int ldw, float wscale,
-                       const SfFlowDelta& ep, hipStream_t st);
-
 // Flow head with conv2 folded into conv1's epilogue (epilogues_sf.h: SfFlowHeadPartial; conv_sf_inst_e.hip):
 // conv1 writes G[img][pix][tap * 2 + output] = conv2's weights x relu(conv1) of THAT pixel; the gather sums each
 // pixel's 3 x 3 neighbourhood (zero padding outside the map) and applies SfFlowDelta (conv2's bias, coordinate update).
 struct ConvShape;
-bool flow_head_fusable(const ConvShape& s);   // the 256-wide block is what the dispatch would pick (one block = all channels)
 void launch_flow_head_fused(const ConvShape& s, float wscale, const SfFlowHeadPartial& ep, hipStream_t st);
 void launch_flow_gather(const float* G, int nimg, int H, int W, const SfFlowDelta& ep, hipStream_t st);
 

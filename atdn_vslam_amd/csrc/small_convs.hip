@@ -83,108 +83,6 @@ void launch_flow_conv7(const float* flow4, int nimg, int H, int W, const float* 
   ATDN_HIP(hipGetLastError());
 }
 
-// ---------------------------------------------------------------------------------------------- 3x3, 256 -> 2
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-namespace {
-constexpr int FH_RS = 2816;   // LDS bytes between patch rows: 18 pixels x 144 B rounded up to a multiple of 256 B
-__device__ __forceinline__ float dot8(const f16x8 a, const f16x8 b, float acc) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_fdot2(h2v{a[2 * k], a[2 * k + 1]}, h2v{b[2 * k], b[2 * k + 1]}, acc, false);
-  return acc;
-}
-}  // namespace
-
-// block: 8x16 pixels; thread (pixel = tid & 127, half = tid >> 7) covers 16 of the 32 channels of every chunk
-__global__ __launch_bounds__(256) void flow_head2_kernel(const float* __restrict__ src, int H, int W,
-                                                         const float* __restrict__ wsf, int ldw, float wscale,
-                                                         const SfFlowDelta ep, int tiles_x, int tiles_img) {
-  __shared__ __attribute__((aligned(256))) char patch[10 * FH_RS];
-  __shared__ __attribute__((aligned(16))) float wl[2 * 72 * 32];
-  __shared__ float red[128][2];
-  const int tid = threadIdx.x;
-  const int img = blockIdx.x / tiles_img, tloc = blockIdx.x - img * tiles_img;
-  const int ty0 = (tloc / tiles_x) * 8, tx0 = (tloc % tiles_x) * 16;
-  for (int i = tid; i < 2 * 72 * 8; i += 256) {   // float4 index: [n][q][8 slots]
-    const int n = i / (72 * 8), rem = i - n * 72 * 8;
-    reinterpret_cast<float4*>(wl)[i] = *reinterpret_cast<const float4*>(wsf + (long)n * ldw + rem * 4);
-  }
-  const int pix = tid & 127, half = tid >> 7;
-  const int py = pix >> 4, px = pix & 15;
-  const float* simg = src + (long)img * H * W * 256;
-  float acc0 = 0.f, acc1 = 0.f;
-  // the patch of chunk c + 1 is fetched into registers while chunk c is multiplied (180 pixels x 8 slots = 1440
-  // 16-byte pieces, 6 per thread)
-  // (TWO chunks ahead, in two register sets: with one, every chunk waited out most of an HBM round trip — SQ_WAIT_ANY 0.55)
-  constexpr int NPF = (180 * 8 + 255) / 256;
-  float4 pre[2][NPF];
-  auto fetch = [&](int chunk, int set) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int i = tid + 256 * k;
-      const int slot = i & 7, prow = min(i >> 3, 179);
-      const int ry = prow / 18, rx = prow - ry * 18;
-      const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
-      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const float4 v = *reinterpret_cast<const float4*>(simg + ((long)(ok ? iy : 0) * W + (ok ? ix : 0)) * 256 + chunk * 32 + slot * 4);
-      pre[set][k] = keep_if(ok, v);
-    }
-  };
-  fetch(0, 0);
-  fetch(1, 1);
-#pragma unroll
-  for (int chunk = 0; chunk < 8; ++chunk) {
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int i = tid + 256 * k;
-      if (i < 180 * 8) {
-        const int slot = i & 7, prow = i >> 3;
-        const int ry = prow / 18, rx = prow - ry * 18;
-        *reinterpret_cast<float4*>(patch + ry * FH_RS + rx * 144 + slot * 16) = pre[chunk & 1][k];
-      }
-    }
-    __syncthreads();
-    if (chunk + 2 < 8) fetch(chunk + 2, chunk & 1);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const char* p = patch + (py + tap / 3) * FH_RS + (px + tap % 3) * 144 + half * 32;
-      const f16x8 h0 = *reinterpret_cast<const f16x8*>(p), h1 = *reinterpret_cast<const f16x8*>(p + 16);
-      const f16x8 l0 = *reinterpret_cast<const f16x8*>(p + 64), l1 = *reinterpret_cast<const f16x8*>(p + 80);
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const char* w = reinterpret_cast<const char*>(wl) + ((n * 72 + tap * 8 + chunk) * 128) + half * 32;
-        const f16x8 wh0 = *reinterpret_cast<const f16x8*>(w), wh1 = *reinterpret_cast<const f16x8*>(w + 16);
-        const f16x8 wo0 = *reinterpret_cast<const f16x8*>(w + 64), wo1 = *reinterpret_cast<const f16x8*>(w + 80);
-        float a = n ? acc1 : acc0;
-        a = dot8(l0, wh0, a); a = dot8(l1, wh1, a);     // lo x hi
-        a = dot8(h0, wo0, a); a = dot8(h1, wo1, a);     // hi x lo
-        a = dot8(h0, wh0, a); a = dot8(h1, wh1, a);     // hi x hi
-        if (n) acc1 = a; else acc0 = a;
-      }
-    }
-  }
-  if (half == 1) { red[pix][0] = acc0; red[pix][1] = acc1; }
-  __syncthreads();
-  if (half == 0) {
-    const int oy = ty0 + py, ox = tx0 + px;
-    if (oy < H && ox < W) {
-      const int m = oy * W + ox;
-      const float v0 = (acc0 + red[pix][0]) * wscale, v1 = (acc1 + red[pix][1]) * wscale;
-      const SfFlowDelta::Aux a0 = ep.load(img, m, 0), a1 = ep.load(img, m, 1);
-      ep.apply(img, m, 0, v0, a0);
-      ep.apply(img, m, 1, v1, a1);
-    }
-  }
-}
-
-void launch_flow_head2(const float* fh_sf, int nimg, int H, int W, const float* wsf, int ldw, float wscale,
-                       const SfFlowDelta& ep, hipStream_t st) {
-  ATDN_CHECK(ldw == 9 * 256, "flow head conv2 expects 3x3 x 256 packed weights");
-  const int tx = cdiv(W, 16), ty = cdiv(H, 8);
-  hipLaunchKernelGGL(flow_head2_kernel, dim3(nimg * tx * ty), dim3(256), 0, st, fh_sf, H, W, wsf, ldw, wscale, ep, tx, tx * ty);
-  ATDN_HIP(hipGetLastError());
-}
-
 // ---------------------------------------------------------------------------------------------- conv2 gather
 // out[p][o] = sum over taps t = (ty, tx) of G[p + (ty - 1, tx - 1)][t * 2 + o]   (conv2 3x3, pad 1: pixels outside
 // the map contribute nothing), then the flow update. One thread per pixel; G (4 MB at 8 pairs) is L2-resident.

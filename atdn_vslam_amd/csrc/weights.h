@@ -141,28 +141,7 @@ inline PackedConv pack_conv(WeightArena& A, const StateDict& sd, const std::vect
   return L;
 }
 
-// Fragment-major copy of an sf-packed weight matrix for conv_sf6.h: [ceil(N/32)][K/32][t = 0,1][hi, lo][lane] x 16 B.
-// Lane (r = lane & 31, h = lane >> 5) of the wave that owns output channels nt*32 .. nt*32+31 finds, for K chunk q and
-// K sub-step t, its hi operand (16-byte slot 2t+h of row nt*32+r, chunk q) and its lo operand (slot 4+2t+h) at
-// ((nt*nq + q)*4 + 2t + {0,1})*1024 + lane*16 bytes: every wave load is one contiguous KiB. Rows >= N are zero.
-inline void pack_fragment_major(WeightArena& A, PackedConv& L) {
-  const int nq = L.ldw / 32, ntile = (L.N + 31) / 32;
-  L.wf_off = A.alloc((long)ntile * nq * 1024);
-  const float* w = A.at(L.w_off);  // (alloc may have moved the arena: take the pointers after it)
-  float* f = A.at(L.wf_off);
-  for (int nt = 0; nt < ntile; ++nt)
-    for (int q = 0; q < nq; ++q)
-      for (int t = 0; t < 2; ++t)
-        for (int hl = 0; hl < 2; ++hl)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int r = lane & 31, h = lane >> 5, row = nt * 32 + r, slot = 4 * hl + 2 * t + h;
-            float* d = f + ((((long)nt * nq + q) * 4 + 2 * t + hl) * 64 + lane) * 4;
-            if (row < L.N) std::memcpy(d, w + (long)row * L.ldw + q * 32 + slot * 4, 16);
-            else std::memset(d, 0, 16);
-          }
-}
-
-// Fragment-major copy for the 16x16x32 loop of conv_sf6.h: [ceil(N/16)][K/32][hi, lo][lane] x 16 B. Lane (r = lane & 15,
+// Fragment-major copy of an sf-packed weight matrix for the 16x16x32 loop of conv_sf6.h: [ceil(N/16)][K/32][hi, lo][lane] x 16 B. Lane (r = lane & 15,
 // g = lane >> 4) of the wave that multiplies output channels nb*16 .. nb*16+15 finds, for K chunk q, its hi operand (16-byte
 // slot g of row nb*16+r, chunk q: halves 8g .. 8g+7) at ((nb*nq + q)*2 + 0)*1024 + lane*16 bytes and its lo operand (slot
 // 4+g) 1024 bytes further: every wave load is one contiguous KiB. Rows >= N are zero.
@@ -210,7 +189,6 @@ inline PackedConv pack_conv_sf(WeightArena& A, const StateDict& sd, const std::v
       }
   }
   if ((L.KH == 3 && L.KW == 3) || (L.KH == 1 && L.KW == 5) || (L.KH == 5 && L.KW == 1)) {
-    pack_fragment_major(A, L);
     pack_fragment_major16(A, L);
   }
   return L;

@@ -236,6 +236,11 @@ int atdn_conv2d_nhwc(const float* src, int nimg, int H, int W, int Cin, const fl
 int atdn_conv2d_nhwc_sf(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
                         const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, float* dst,
                         void* stream);
+/* ... with the epilogue named: sf_store = 0 writes fp32 (what atdn_conv2d_nhwc_sf does), sf_store = 1 writes the split-f16
+ * format through the channel-vector store the product's layers use (Cout % 32 == 0) and decodes it to fp32 `dst`. */
+int atdn_conv2d_nhwc_sf_epi(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
+                            const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, int sf_store,
+                            float* dst, void* stream);
 
 #ifdef __cplusplus
 }

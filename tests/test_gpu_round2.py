@@ -180,126 +180,91 @@ def test_split_f16_saturation_is_counted(gsd):
     assert float(net.debug_read("sf_clamped", (1,), 160, 512)[0]) > 0.0
 
 
-def test_fused_attention_agrees_with_the_separate_passes(gsd, monkeypatch):
-    """Round-2 attention (QK^T with the softmax fused in, fragment-major storage, streaming attention x V) against the
-    round-1 path it replaced (logits GEMM -> softmax pass -> generic GEMM kernel), which stays selectable
-    (ATDN_ATTN_LEGACY=1): attention rows, the aggregated motion features and the flow, at the plumbing size and a
-    ragged one (N = 23 * 41 = 943: partial last strip, odd chunk count)."""
+# The split-f16 pipeline against the exact-fp32 mode (precision="f32"): not one arithmetic in two places but two independent
+# implementations of every stage — fused attention (QK^T + softmax in one kernel, fragment-major 3-byte storage, streaming
+# attention x V) vs logits GEMM -> softmax pass -> GEMM; bricked pyramid from pooled FEATURES + lookup fused with convc1 vs
+# row-major pyramid pooled from the level-0 VOLUME + separate lookup and 1x1 conv; split-f16 7x7 stems with two-pass
+# InstanceNorm and normalise-on-load vs exact-fp32 ROW-mode stems and separate normalisation passes; flow head with conv2 in
+# conv1's epilogue + gather vs two convolutions. (Rounds 2-3 compared each new kernel with the one it replaced through
+# environment switches; those second implementations were deleted in round 4 — the classical data flow lives on in the
+# f32 mode, which is what they are compared with now.)
+def _both_modes(gsd, h, w, n_frames, iters, seed, max_batch, flow_init=None, reads=()):
     sd = {"module." + k: v for k, v in gsd.items()}
-
-    def run(h, w):
-        m = RAFTGMA(max_batch=2, precision="split_f16")
+    out = {}
+    for prec in ("split_f16", "f32"):
+        m = RAFTGMA(max_batch=max_batch, precision=prec)
         m.load_state_dict(sd)
         m = m.to(DEV).eval()
-        fr = torch.from_numpy(syn.make_frames(3, h, w, seed=29)).to(DEV)
-        low, up = m.forward_sequence(fr, iters=4)
-        n = (h // 8) * (w // 8)
-        ldn = (n + 31) // 32 * 32
-        attn = m.debug_read("attn", (2, n, ldn), h, w)[:, :, :n]
-        x = m.debug_read("x", (2 * n, 384), h, w)
-        return low.cpu(), up.cpu(), attn, x[:, 256:384]
-
-    for (h, w) in ((160, 512), (184, 328)):
-        new = run(h, w)
-        monkeypatch.setenv("ATDN_ATTN_LEGACY", "1")
-        old = run(h, w)
-        monkeypatch.delenv("ATDN_ATTN_LEGACY")
-        assert _maxerr(new[2].sum(-1), torch.ones_like(new[2].sum(-1))) < 1e-5
-        assert _maxerr(new[2], old[2]) < 1e-6 + 1e-4 * float(old[2].max())
-        assert _maxerr(new[3], old[3]) < 1e-4          # motion_features_global after the last iteration
-        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4
+        fr = torch.from_numpy(syn.make_frames(n_frames, h, w, seed=seed)).to(DEV)
+        fi = None if flow_init is None else flow_init.to(DEV)
+        low, up = m.forward_sequence(fr, iters=iters, flow_init=fi)
+        out[prec] = {"low": low.cpu(), "up": up.cpu()}
+        for ent in reads:   # (name, shape) or (name, shape in split_f16, shape in f32)
+            shape = ent[1] if (len(ent) == 2 or prec == "split_f16") else ent[2]
+            out[prec][ent[0]] = m.debug_read(ent[0], shape, h, w)
+        del m
+    return out["split_f16"], out["f32"]
 
 
-def test_bricked_pyramid_and_fused_lookup_agree_with_the_separate_kernels(gsd, monkeypatch):
-    """Round-2 lookup (bricked pyramid, every level a GEMM against pooled features, lookup fused with convc1) against the
-    round-1 path (row-major pyramid, pooled volume, separate lookup and 1x1 convolution; ATDN_LOOKUP_LEGACY=1): pyramid
-    levels, the 324 samples, and the flow, at the plumbing size and a ragged one with a non-zero flow_init (windows that
-    leave the map on every side)."""
-    sd = {"module." + k: v for k, v in gsd.items()}
-
-    def run(h, w):
-        m = RAFTGMA(max_batch=2, precision="split_f16")
-        m.load_state_dict(sd)
-        m = m.to(DEV).eval()
-        fr = torch.from_numpy(syn.make_frames(3, h, w, seed=31)).to(DEV)
-        h8, w8 = h // 8, w // 8
-        r = np.random.RandomState(5)
-        fi = torch.from_numpy(r.uniform(-0.7, 0.7, (2, 2, h8, w8)).astype(np.float32) * np.array([w8, h8], np.float32).reshape(1, 2, 1, 1))
-        low, up = m.forward_sequence(fr, iters=3, flow_init=fi.to(DEV))
-        n = h8 * w8
-        pyr = [m.debug_read("pyr%d" % l, (2 * n, (h8 >> l) * (w8 >> l)), h, w) for l in range(4)]
-        look = m.debug_read("corrfeat", (2 * n, 352), h, w)[:, :324]
-        return low.cpu(), up.cpu(), pyr, look
-
-    for (h, w) in ((160, 512), (184, 328)):
-        new = run(h, w)
-        monkeypatch.setenv("ATDN_LOOKUP_LEGACY", "1")
-        old = run(h, w)
-        monkeypatch.delenv("ATDN_LOOKUP_LEGACY")
-        for l in range(4):
-            assert _maxerr(new[2][l], old[2][l]) < 2e-5, l      # pooled features vs pooled volume: fp32 rounding only
-        assert _maxerr(new[3], old[3]) < 1e-4
-        assert float(old[3].abs().max()) > 0.1 and float((old[3] == 0).float().mean()) > 0.01   # inside AND outside the map
-        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4
+@pytest.mark.parametrize("h,w", [(160, 512), (184, 328)])
+def test_fused_attention_agrees_with_the_exact_fp32_mode(gsd, h, w):
+    """Attention rows, the aggregated motion features after the last iteration and the flow, at the plumbing size and a ragged
+    one (N = 23 * 41 = 943: partial last strip, odd chunk count)."""
+    n = (h // 8) * (w // 8)
+    ldn = (n + 31) // 32 * 32
+    new, old = _both_modes(gsd, h, w, 3, 4, 29, 2, reads=(("attn", (2, n, ldn)), ("x", (2 * n, 384))))
+    an, ao = new["attn"][:, :, :n], old["attn"][:, :, :n]
+    assert _maxerr(an.sum(-1), torch.ones_like(an.sum(-1))) < 1e-5
+    assert _maxerr(an, ao) < 1e-6 + 1e-4 * float(ao.max())
+    assert _maxerr(new["x"][:, 256:384], old["x"][:, 256:384]) < 2e-4          # motion_features_global
+    assert _maxerr(new["low"], old["low"]) < 2e-4 and _maxerr(new["up"], old["up"]) < 1e-3
 
 
-def test_split_f16_stem_agrees_with_the_exact_fp32_stem(gsd, monkeypatch):
-    """The 7x7 stems on the split-f16 engine (stem_sf.hip; InstanceNorm = statistics pass + recompute-and-normalise
-    pass, nothing raw in memory) against the exact-fp32 ROW-mode stem + separate normalisation they replaced
-    (ATDN_STEM_LEGACY=1): feature maps (fnet, InstanceNorm), hidden state / context (cnet, folded BatchNorm) and flow.
-    Sizes: the plumbing size, one whose half-resolution map has partial tiles in both directions (92 x 164: 92 % 8 = 4,
-    164 % 32 = 4), and KITTI (188 x 616)."""
-    sd = {"module." + k: v for k, v in gsd.items()}
-
-    def run(h, w):
-        m = RAFTGMA(max_batch=2, precision="split_f16")
-        m.load_state_dict(sd)
-        m = m.to(DEV).eval()
-        fr = torch.from_numpy(syn.make_frames(3, h, w, seed=37)).to(DEV)
-        low, up = m.forward_sequence(fr, iters=2)
-        n = (h // 8) * (w // 8)
-        fmap = m.debug_read("fmap", (3 * n, 256), h, w)
-        x = m.debug_read("x", (2 * n, 384), h, w)[:, :128]      # relu half of the context network's output
-        return low.cpu(), up.cpu(), fmap, x
-
-    for (h, w) in ((160, 512), (184, 328), (376, 1232)):
-        new = run(h, w)
-        monkeypatch.setenv("ATDN_STEM_LEGACY", "1")
-        old = run(h, w)
-        monkeypatch.delenv("ATDN_STEM_LEGACY")
-        assert float(old[2].abs().max()) > 0.1 and float(old[3].abs().max()) > 0.01
-        assert _maxerr(new[2], old[2]) < 2e-5 * max(1.0, float(old[2].abs().max())), (h, w)
-        assert _maxerr(new[3], old[3]) < 2e-5 * max(1.0, float(old[3].abs().max())), (h, w)
-        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4, (h, w)
+@pytest.mark.parametrize("h,w", [(160, 512), (184, 328)])
+def test_bricked_pyramid_and_fused_lookup_agree_with_the_exact_fp32_mode(gsd, h, w):
+    """Pyramid levels, the 324 samples and the flow with a non-zero flow_init (windows that leave the map on every side)."""
+    h8, w8 = h // 8, w // 8
+    n = h8 * w8
+    r = np.random.RandomState(5)
+    fi = torch.from_numpy(r.uniform(-0.7, 0.7, (2, 2, h8, w8)).astype(np.float32) * np.array([w8, h8], np.float32).reshape(1, 2, 1, 1))
+    reads = tuple(("pyr%d" % l, (2 * n, (h8 >> l) * (w8 >> l))) for l in range(4)) + (("corrfeat", (2 * n, 352)),)
+    new, old = _both_modes(gsd, h, w, 3, 1, 31, 2, flow_init=fi, reads=reads)
+    for l in range(4):
+        scale = max(1.0, float(old["pyr%d" % l].abs().max()))
+        assert _maxerr(new["pyr%d" % l], old["pyr%d" % l]) < 3e-5 * scale, l      # pooled features vs pooled volume
+    # one iteration: both modes sample at the same coordinates (coords0 + flow_init)
+    ln, lo = new["corrfeat"][:, :324], old["corrfeat"][:, :324]
+    assert _maxerr(ln, lo) < 1e-4 * max(1.0, float(lo.abs().max()))
+    assert float(lo.abs().max()) > 0.1 and float((lo == 0).float().mean()) > 0.01   # inside AND outside the map
+    assert _maxerr(new["low"], old["low"]) < 2e-4 and _maxerr(new["up"], old["up"]) < 1e-3
 
 
-def test_fused_flow_head_agrees_with_the_two_convolutions(gsd, monkeypatch):
-    """Flow head with conv2 folded into conv1's epilogue (18 partial sums per pixel + a 3 x 3 gather; used when one
-    256-wide block holds all of conv1's channels, i.e. at B = 8 KITTI) against conv1 -> sf tensor -> conv2 kernel
-    (ATDN_FLOWHEAD_FUSED=0): coordinates after 1 and after 4 iterations, the flow channels of the GRU input and the
-    upsampled flow. Batch 8 at KITTI size selects the fused path; a ragged size with B = 8 checks partial tiles (the
-    map's border pixels get fewer than nine taps)."""
-    sd = {"module." + k: v for k, v in gsd.items()}
+@pytest.mark.parametrize("h,w", [(160, 512), (184, 328), (376, 1232)])
+def test_split_f16_encoders_agree_with_the_exact_fp32_mode(gsd, h, w):
+    """Feature maps (fnet: stems with two-pass InstanceNorm, statistics epilogues, normalise-on-load), hidden state / context
+    (cnet: folded BatchNorm, residual epilogues) and the flow. Sizes: the plumbing size, one whose half-resolution map has
+    partial tiles in both directions (92 x 164), and KITTI (188 x 616)."""
+    n = (h // 8) * (w // 8)
+    # (sequence mode keeps one feature map per FRAME [f0, f1, f2]; the f32 mode runs pairs: [f0, f1 | f1, f2])
+    new, old = _both_modes(gsd, h, w, 3, 2, 37, 2, reads=(("fmap", (3 * n, 256), (4 * n, 256)), ("x", (2 * n, 384)), ("net", (2 * n, 128))))
+    old["fmap"] = torch.cat([old["fmap"][:2 * n], old["fmap"][3 * n:]])
+    assert float(old["fmap"].abs().max()) > 0.1 and float(old["x"][:, :128].abs().max()) > 0.01
+    assert _maxerr(new["fmap"], old["fmap"]) < 3e-5 * max(1.0, float(old["fmap"].abs().max())), (h, w)
+    assert _maxerr(new["x"][:, :128], old["x"][:, :128]) < 3e-5 * max(1.0, float(old["x"][:, :128].abs().max())), (h, w)
+    assert _maxerr(new["low"], old["low"]) < 2e-4 and _maxerr(new["up"], old["up"]) < 1e-3, (h, w)
 
-    def run(h, w, iters):
-        m = RAFTGMA(max_batch=8, precision="split_f16")
-        m.load_state_dict(sd)
-        m = m.to(DEV).eval()
-        fr = torch.from_numpy(syn.make_frames(9, h, w, seed=43)).to(DEV)
-        low, up = m.forward_sequence(fr, iters=iters)
-        n = (h // 8) * (w // 8)
-        c1 = m.debug_read("coords1", (8 * n, 2), h, w)
-        xf = m.debug_read("x", (8 * n, 384), h, w)[:, 254:256]
-        return low.cpu(), up.cpu(), c1, xf
 
-    for (h, w, iters) in ((376, 1232, 1), (376, 1232, 4), (360, 1000, 2)):
-        new = run(h, w, iters)
-        monkeypatch.setenv("ATDN_FLOWHEAD_FUSED", "0")
-        old = run(h, w, iters)
-        monkeypatch.delenv("ATDN_FLOWHEAD_FUSED")
-        assert float(old[0].abs().max()) > 1e-3
-        assert _maxerr(new[2], old[2]) < 1e-4 and _maxerr(new[3], old[3]) < 1e-4, (h, w, iters)
-        assert _maxerr(new[0], old[0]) < 1e-4 and _maxerr(new[1], old[1]) < 5e-4, (h, w, iters)
+@pytest.mark.parametrize("h,w,iters", [(376, 1232, 1), (376, 1232, 4), (360, 1000, 2)])
+def test_fused_flow_head_agrees_with_the_exact_fp32_mode(gsd, h, w, iters):
+    """Flow head with conv2 folded into conv1's epilogue (18 partial sums per pixel + a 3 x 3 gather) against the two
+    convolutions of the exact-fp32 mode: coordinates after 1 and after 4 iterations, the flow channels of the GRU input and
+    the upsampled flow; batch 4 at KITTI size and a ragged size (the map's border pixels get fewer than nine taps)."""
+    n = (h // 8) * (w // 8)
+    new, old = _both_modes(gsd, h, w, 5, iters, 43, 4, reads=(("coords1", (4 * n, 2)), ("x", (4 * n, 384))))
+    assert float(old["low"].abs().max()) > 1e-3
+    assert _maxerr(new["coords1"], old["coords1"]) < 2e-4, (h, w, iters)
+    assert _maxerr(new["x"][:, 254:256], old["x"][:, 254:256]) < 2e-4, (h, w, iters)
+    assert _maxerr(new["low"], old["low"]) < 2e-4 and _maxerr(new["up"], old["up"]) < 1e-3, (h, w, iters)
 
 
 def test_sequence_driver_from_host_uint8_matches_frame_by_frame(gsd, hsd):

@@ -274,32 +274,6 @@ def test_run_sequence_checks_every_lane_before_the_gather():
     assert tuple(poses.shape) == (9, 4, 4)
 
 
-# ------------------------------------------------------------------------------------------- MFMA shape of the halo convolutions
-def test_mfma_16x16x32_loop_agrees_with_the_32x32x16_loop(monkeypatch):
-    """Round 3 moved every halo-patch convolution (encoders incl. the InstanceNorm-statistics and normalise-on-load variants,
-    motion encoder, ConvGRU, flow head, mask head) to v_mfma_f32_16x16x32_f16: other operand lane map, other LDS pitch, other
-    fragment-major weight copy, other accumulator layout in every epilogue. The two loops sum the same products in fp32 in a
-    different order: flows agree to rounding, at the plumbing size and at a ragged size with partial tiles."""
-    gsd = syn.to_torch(syn.make_gma_state(seed=1))
-
-    def run(h, w, iters):
-        m = RAFTGMA(max_batch=2)
-        m.load_state_dict(gsd)
-        m = m.to(DEV).eval()
-        fr = torch.from_numpy(syn.make_frames(3, h, w, seed=29)).to(DEV)
-        low, up = m(fr[0:2], fr[1:3], iters=iters, test_mode=True)
-        fm = m.debug_read("fmap", (4, (h // 8) * (w // 8), 256), h, w)
-        return low.cpu(), up.cpu(), fm
-
-    for (h, w, iters) in ((160, 512, 6), (184, 328, 4)):
-        monkeypatch.delenv("ATDN_CONV_M32", raising=False)
-        new = run(h, w, iters)
-        monkeypatch.setenv("ATDN_CONV_M32", "1")
-        old = run(h, w, iters)
-        assert float((new[2] - old[2]).abs().max()) < 1e-5              # feature maps (statistics + normalise-on-load convs)
-        assert float((new[0] - old[0]).abs().max()) < 1e-4 and float((new[1] - old[1]).abs().max()) < 5e-4
-
-
 def test_clip_modes_are_bit_identical_to_pair_mode():
     """VERDICT r2 ("continued clips equal pair mode only up to kernel-selection rounding"): the statistics convolutions of
     the feature network now pick their tile height — which fixes the 32-pixel groups of the InstanceNorm partial sums — from

@@ -33,7 +33,7 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
     ConvShape s;
     s.src0 = x; s.ld0 = C; s.sb0 = (long)H * W * C; s.C0 = C; s.H = H; s.W = W;
     s.KH = KH; s.KW = KW; s.stride = 1; s.padH = KH / 2; s.padW = KW / 2;
-    s.w = w; s.wfrag = wf; s.ldw = K; s.N = N; s.nimg = nimg;
+    s.w = w; s.ldw = K; s.N = N; s.nimg = nimg;
     using E = SfBias<ACT_RELU>;
     E ep{bias, y, (long)H * W * N, N};
     auto time_it = [&](auto&& go) {
@@ -49,41 +49,30 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
       (void)hipEventDestroy(a); (void)hipEventDestroy(b);
       return ms * 1000.f / reps;
     };
-#define ATDN_MB_SF6(BN, WM, WN, ABL)                                                                   \
-    time_it([&]() {                                                                                \
-      if (KH == 3 && KW == 3) launch_conv_sf6<8, BN, WM, WN, 3, 3, E, ABL, true>(s, 1.f, ep, st);    \
-      else if (KH == 1 && KW == 5) launch_conv_sf6<8, BN, WM, WN, 1, 5, E, ABL, true>(s, 1.f, ep, st); \
-      else launch_conv_sf6<8, BN, WM, WN, 5, 1, E, ABL, true>(s, 1.f, ep, st);                       \
+    s.wfrag16 = wf;
+#define ATDN_MB_SF6(BN, WM, WN, ABL)                                                                              \
+    time_it([&]() {                                                                                               \
+      if (KH == 3 && KW == 3) launch_conv_sf6<8, BN, WM, WN, 3, 3, E, false, false, ABL>(s, 1.f, ep, st);         \
+      else if (KH == 1 && KW == 5) launch_conv_sf6<8, BN, WM, WN, 1, 5, E, false, false, ABL>(s, 1.f, ep, st);    \
+      else launch_conv_sf6<8, BN, WM, WN, 5, 1, E, false, false, ABL>(s, 1.f, ep, st);                            \
     })
     us_out[0] = ATDN_MB_SF6(256, 1, 8, 0);
     us_out[1] = ATDN_MB_SF6(128, 1, 4, 0);
     us_out[2] = ATDN_MB_SF6(64, 2, 2, 0);
-    if (getenv("ATDN_MB_WIDE_WAVE")) us_out[1] = ATDN_MB_SF6(256, 1, 4, 0);   // diagnostic: 128 px x 64 ch per wave, one wave per SIMD
-    us_out[3] = ATDN_MB_SF6(256, 1, 8, 8);    // no epilogue
-    us_out[4] = ATDN_MB_SF6(256, 1, 8, 9);    // ... and no weight loads in the loop
-    us_out[5] = ATDN_MB_SF6(256, 1, 8, 13);   // ... and no LDS reads in the loop
-    us_out[6] = ATDN_MB_SF6(256, 1, 8, 15);   // ... and no patch refresh: the bare MFMA stream of this tiling
+    us_out[3] = ATDN_MB_SF6(128, 1, 4, 8);    // 128-wide block, no epilogue
+    us_out[4] = ATDN_MB_SF6(128, 1, 4, 9);    // ... and no weight loads in the loop
+    us_out[5] = ATDN_MB_SF6(128, 1, 4, 13);   // ... and no LDS reads in the loop
+    us_out[6] = ATDN_MB_SF6(128, 1, 4, 15);   // ... and no patch refresh: the bare MFMA stream of this tiling
+    us_out[7] = us_out[8] = us_out[9] = 0.f;
 #undef ATDN_MB_SF6
-    // round 3: the same blocks on the 16x16x32 MFMA loop (weights: the same random bytes, order irrelevant for timing)
-    s.wfrag16 = wf;
-#define ATDN_MB_SF6M(BN, WM, WN)                                                                                      \
-    time_it([&]() {                                                                                                  \
-      if (KH == 3 && KW == 3) launch_conv_sf6<8, BN, WM, WN, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st);    \
-      else if (KH == 1 && KW == 5) launch_conv_sf6<8, BN, WM, WN, 1, 5, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); \
-      else launch_conv_sf6<8, BN, WM, WN, 5, 1, E, 0, true, false, 2, false, true>(s, 1.f, ep, st);                       \
-    })
-    us_out[7] = ATDN_MB_SF6M(256, 1, 8);
-    us_out[8] = ATDN_MB_SF6M(128, 1, 4);
-    us_out[9] = ATDN_MB_SF6M(64, 2, 2);
-#undef ATDN_MB_SF6M
     us_out[10] = us_out[11] = 0.f;
     us_out[12] = us_out[13] = us_out[14] = us_out[15] = 0.f;
     if (KH == 3 && KW == 3) {
       // 3x3 only: the tall (12x16 px) 64-wide block and the 96-wide 2x3-wave blocks (N = 192 as two of them)
-      us_out[12] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
+      us_out[12] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E>(s, 1.f, ep, st); });
       if (N % 96 == 0) {
-        us_out[13] = time_it([&]() { launch_conv_sf6<8, 96, 2, 3, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
-        us_out[14] = time_it([&]() { launch_conv_sf6<12, 96, 2, 3, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
+        us_out[13] = time_it([&]() { launch_conv_sf6<8, 96, 2, 3, 3, 3, E>(s, 1.f, ep, st); });
+        us_out[14] = time_it([&]() { launch_conv_sf6<12, 96, 2, 3, 3, 3, E>(s, 1.f, ep, st); });
       }
     }
     if (KH == 1 && KW == 5 && N == 256 && C == 384) {
@@ -93,8 +82,8 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
       ATDN_HIP(hipMalloc(&rhbuf, npix * 128 * 4)); ATDN_HIP(hipMalloc(&pre, npix * 256 * 4));
       ATDN_HIP(hipMemset(hbuf, 0, npix * 128 * 4)); ATDN_HIP(hipMemset(pre, 0, npix * 256 * 4));
       SfGruZR eg{bias, hbuf, zbuf, rhbuf, (long)H * W * 128, pre, (long)H * W * 256};
-      us_out[10] = time_it([&]() { launch_conv_sf6<8, 128, 1, 4, 1, 5, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
-      us_out[11] = time_it([&]() { launch_conv_sf6<8, 128, 1, 4, 1, 5, SfGruZR, 0, true, false, 2, false, true>(s, 1.f, eg, st); });
+      us_out[10] = time_it([&]() { launch_conv_sf6<8, 128, 1, 4, 1, 5, E>(s, 1.f, ep, st); });
+      us_out[11] = time_it([&]() { launch_conv_sf6<8, 128, 1, 4, 1, 5, SfGruZR>(s, 1.f, eg, st); });
       (void)hipFree(hbuf); (void)hipFree(zbuf); (void)hipFree(rhbuf); (void)hipFree(pre);
     }
     (void)hipFree(x); (void)hipFree(w); (void)hipFree(wf); (void)hipFree(y); (void)hipFree(bias);
@@ -127,7 +116,7 @@ extern "C" int atdn_microbench_conv_thin(int nimg, int H, int W, int C, int N, i
     ConvShape s;
     s.src0 = x; s.ld0 = C; s.sb0 = (long)H * W * C; s.C0 = C; s.H = H; s.W = W;
     s.KH = 3; s.KW = 3; s.stride = 1; s.padH = 1; s.padW = 1;
-    s.w = wf; s.wfrag = wf; s.ldw = K; s.N = N; s.nimg = nimg;
+    s.w = wf; s.ldw = K; s.N = N; s.nimg = nimg;
     using E = SfBias<ACT_RELU>;
     E ep{bias, y, (long)H * W * N, N};
     auto time_it = [&](auto&& go) {
@@ -144,18 +133,17 @@ extern "C" int atdn_microbench_conv_thin(int nimg, int H, int W, int C, int N, i
       return ms * 1000.f / reps;
     };
     s.wfrag16 = wf;
-    us_out[10] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
-    us_out[11] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true, false, 2, false, true>(s, 1.f, ep, st); });
-    us_out[0] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
-    us_out[1] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
-    us_out[2] = time_it([&]() { launch_conv_sf6<16, 64, 4, 2, 3, 3, E, 0, true>(s, 1.f, ep, st); });
-    us_out[8] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 0, true, false, 1>(s, 1.f, ep, st); });
-    us_out[9] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 0, true, false, 1>(s, 1.f, ep, st); });
-    us_out[3] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 8, true>(s, 1.f, ep, st); });
-    us_out[4] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 9, true>(s, 1.f, ep, st); });
-    us_out[5] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 13, true>(s, 1.f, ep, st); });
-    us_out[6] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E, 15, true>(s, 1.f, ep, st); });
-    us_out[7] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, 8, true>(s, 1.f, ep, st); });
+    us_out[0] = time_it([&]() { launch_conv_sf6<8, 64, 2, 2, 3, 3, E>(s, 1.f, ep, st); });
+    us_out[1] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E>(s, 1.f, ep, st); });
+    us_out[2] = time_it([&]() { launch_conv_sf6<16, 64, 4, 2, 3, 3, E>(s, 1.f, ep, st); });
+    us_out[3] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 8>(s, 1.f, ep, st); });    // no epilogue
+    us_out[4] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 9>(s, 1.f, ep, st); });    // ... no weight loads
+    us_out[5] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 13>(s, 1.f, ep, st); });   // ... no LDS reads
+    us_out[6] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 15>(s, 1.f, ep, st); });   // bare MFMA stream
+    us_out[7] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 1>(s, 1.f, ep, st); });    // only: no weight loads
+    us_out[8] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 2>(s, 1.f, ep, st); });    // only: no patch refresh
+    us_out[9] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 4>(s, 1.f, ep, st); });    // only: no LDS reads
+    us_out[10] = us_out[11] = 0.f;
     (void)hipFree(x); (void)hipFree(wf); (void)hipFree(y); (void)hipFree(bias);
     return 0;
   } catch (const std::exception& e) {
