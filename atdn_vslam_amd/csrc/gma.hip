@@ -29,7 +29,7 @@ extern template TileChoice conv_dispatch<MODE_ROW, SfBias<ACT_RELU>>(const ConvS
 #define ATDN_EXTERN_SF(EPI) extern template TileChoice conv_sf_dispatch<EPI>(const ConvShape&, float, EPI, hipStream_t);
 ATDN_EXTERN_SF(SfBias<ACT_NONE>) ATDN_EXTERN_SF(SfBias<ACT_RELU>) ATDN_EXTERN_SF(EpiBias<ACT_NONE>)
 ATDN_EXTERN_SF(EpiBiasStats) ATDN_EXTERN_SF(SfBiasReluAddRelu) ATDN_EXTERN_SF(SfContextSplit)
-ATDN_EXTERN_SF(EpiScale) ATDN_EXTERN_SF(SfQK) ATDN_EXTERN_SF(SfVT)
+ATDN_EXTERN_SF(SfQK) ATDN_EXTERN_SF(SfVT)
 ATDN_EXTERN_SF(SfGruZR) ATDN_EXTERN_SF(SfGruQ)
 
 namespace {
@@ -238,7 +238,8 @@ void GmaNet::finalize() {
   ATDN_CHECK(pyrH_[3] >= 2 && pyrW_[3] >= 2, "frame too small for a 4-level pyramid");
   for (int l = 0; l < 4; ++l) {
     brickBW_[l] = cdiv(pyrW_[l], 8); brickBH_[l] = cdiv(pyrH_[l], 4); brickNB_[l] = brickBW_[l] * brickBH_[l] * 32;
-    pyr_[l].alloc(n8 * (classic_ ? pyrH_[l] * pyrW_[l] : brickNB_[l]));
+    // (bricked: a pair's region holds whole 128-pixel strips, kernels.h: BrickPyramid)
+    pyr_[l].alloc(classic_ ? n8 * pyrH_[l] * pyrW_[l] : (long)B * brick_pixel_blocks(N) * kBrickPixelBlock * brickNB_[l]);
   }
   if (sf) {
     for (int l = 0; l < 4; ++l) fbrick_[l].alloc((long)B * brickNB_[l] * 256);
@@ -593,13 +594,11 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   conv_sf_dispatch(s, fnet_.head.wscale, SfBias<ACT_NONE>{fnet_.head.b, fdst, (long)N * 256, 256}, st);
   mark(ST_FNET, st);
 
-  ConvShape c;
-  c.src0 = fmap_.p; c.ld0 = 256; c.sb0 = (long)N * 256; c.C0 = 256; c.H = 1; c.W = N;
-  c.w = fmap_.p + (long)(seq_ ? 1 : B) * N * 256; c.wb = (long)N * 256; c.ldw = 256; c.N = N; c.nimg = B;
-  // every level = fmap1 x (target features of that level in BRICK order)^T: output column n' is the brick address of
-  // the target cell, padding cells are zero feature rows (lookup_fused.hip). Levels 1-3: 2x2-pooled features —
-  // correlation is linear in the target features, so avg_pool2d of corr.py:28-30 commutes with the dot product.
-  const float* target = c.w;
+  // all-pairs correlation (corr.py:55-63) and its pyramid (corr.py:16-30): every level = fmap1 x (target features of that level
+  // in BRICK order)^T, written by corr_bricks_kernel in the brick-major layout the lookup reads; padding cells are zero feature
+  // rows. Levels 1-3: 2x2-pooled features — correlation is linear in the target features, so avg_pool2d of corr.py:28-30
+  // commutes with the dot product. fmap_ slot b is frame b (sequence modes: pair b = frames b, b + 1) or [im1 batch | im2 batch].
+  const float* target = fmap_.p + (long)(seq_ ? 1 : B) * N * 256;
   for (int l = 0; l < 4; ++l) {
     const float* plain = target;
     long plain_sb = (long)N * 256;
@@ -611,9 +610,8 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
       plain = fplain_[l - 1].p;
     }
     launch_brick_rows(plain, plain_sb, B, pyrH_[l], pyrW_[l], 256, fbrick_[l].p, (long)brickNB_[l] * 256, st);
-    ConvShape cl = c;
-    cl.w = fbrick_[l].p; cl.wb = (long)brickNB_[l] * 256; cl.N = brickNB_[l];
-    conv_sf_dispatch(cl, 1.f, EpiScale{1.0f / sqrtf(256.0f), pyr_[l].p, (long)N * brickNB_[l], brickNB_[l]}, st);
+    launch_corr_bricks(fmap_.p, (long)N * 256, fbrick_[l].p, (long)brickNB_[l] * 256, B, N, brickNB_[l], 1.0f / sqrtf(256.0f), pyr_[l].p,
+                       sf_fast_mode(), st);
     if (l == 0) mark(ST_CORR, st);
   }
   mark(ST_POOL, st);
@@ -730,6 +728,7 @@ BrickPyramid GmaNet::brick_pyramid() const {
     bp.base[l] = pyr_[l].p; bp.H[l] = pyrH_[l]; bp.W[l] = pyrW_[l];
     bp.BW[l] = brickBW_[l]; bp.BH[l] = brickBH_[l]; bp.NB[l] = brickNB_[l];
   }
+  bp.N = N; bp.NPB = brick_pixel_blocks(N);
   return bp;
 }
 
@@ -740,7 +739,7 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
     const int l = k[3] - '0';
     const long rows = (long)maxB * N, total = rows * pyrH_[l] * pyrW_[l];
     if (scratch_.n < total) { scratch_.release(); scratch_.alloc(total); }
-    launch_unbrick(pyr_[l].p, brickNB_[l], pyrH_[l], pyrW_[l], rows, scratch_.p, st);
+    launch_unbrick(pyr_[l].p, brickNB_[l], N, pyrH_[l], pyrW_[l], rows, scratch_.p, st);
     ATDN_HIP(hipStreamSynchronize(st));
     const long n = std::min(capacity, total);
     ATDN_HIP(hipMemcpy(host, scratch_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));

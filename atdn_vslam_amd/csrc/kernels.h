@@ -96,16 +96,30 @@ void launch_init_coords_sf(const float* flow_init, int B, int H8, int W8, float*
 void launch_fill(float* p, long n, float v, hipStream_t st);
 
 // ---- bricked correlation pyramid + lookup fused with convc1 (lookup_fused.hip; split-f16 pipeline)
-// level l of ONE batch: [B*N][NB[l]] fp32, NB = BH * BW * 32; cell (y, x) of a pixel's map sits at
-// ((y >> 2) * BW + (x >> 3)) * 32 + (y & 3) * 8 + (x & 7); cells past H / W are zeros
+// level l of ONE batch in BRICKS of 4 rows x 8 columns of target cells (32 floats = one 128-byte line). Source pixels are
+// grouped in PIXEL BLOCKS of 64 consecutive pixels of a pair (NPB blocks per pair, padded to an even count so that a pair's region
+// covers whole 128-pixel strips); inside a pixel block the layout is brick-major:
+//   base[l][(((pair * NPB + (p >> 6)) * NBK_l + brick) * 64 + (p & 63)) * 32 + (y & 3) * 8 + (x & 7)],  brick = (y >> 2) * BW_l + (x >> 3),
+// NBK_l = BH_l * BW_l = NB[l] / 32; cells past H / W are zeros. (Round 4. The correlation kernel stores whole lines in 4 KB runs —
+// 32 pixels x one brick per wave and tile; a lookup block = one pixel block finds everything it reads inside NBK_l x 8 KB, and
+// its neighbouring pixels, whose windows share bricks, read neighbouring lines. Rounds 2-3 kept a pixel's whole map contiguous.)
+constexpr int kBrickPixelBlock = 64;
 struct BrickPyramid {
   const float* base[4];
   int H[4], W[4], BW[4], BH[4], NB[4];
+  int N;     // source pixels per pair
+  int NPB;   // pixel blocks per pair: 2 * ceil(N / 128)
 };
+inline int brick_pixel_blocks(int N) { return 2 * ((N + 127) / 128); }
 // feature rows [img][H*W][C] -> brick order [img][BH*BW*32][C] (zero rows for padding cells); sb / db per-image strides
 void launch_brick_rows(const float* src, long sb, int nimg, int H, int W, int C, float* dst, long db, hipStream_t st);
-// bricked level -> row-major [npix][H*W] (debug reads)
-void launch_unbrick(const float* src, long NB, int H, int W, long npix, float* dst, hipStream_t st);
+// one pyramid level in the layout above: out[...] = scale * <f1[pair][p], f2b[pair][n']> for brick n' / 32, cell n' % 32
+// (corr_bricks.hip); f1 sf [B][N][256] (per-pair stride sb1 floats), f2b sf [B][NB][256] in brick order (zero rows for padding
+// cells), out fp32 with brick_pixel_blocks(N) * 64 * NB floats per pair (rows N .. 64 * NPB - 1 of a pair are scratch)
+void launch_corr_bricks(const float* f1, long sb1, const float* f2b, long sb2, int B, int N, int NB, float scale, float* out,
+                        bool fast, hipStream_t st);
+// bricked level (pairs of N source pixels) -> row-major [npix][H*W] (debug reads)
+void launch_unbrick(const float* src, long NB, int N, int H, int W, long npix, float* dst, hipStream_t st);
 // cor1 = relu(convc1(lookup(coords1))) (corr.py:32-53 + update.py:76-78): out sf [npix][256]; wfrag = convc1 weights in
 // fragment-major order for v_mfma_f32_16x16x32_f16 (weights.h: pack_fragment_major16; K = 352), bias [256]; coords_used (optional) receives the coordinates that were sampled
 void launch_lookup_conv(const BrickPyramid& pyr, const float* coords1, long npix, float* coords_used, const float* wfrag,

@@ -7,12 +7,14 @@
 // (pixel, level) with scalar loads: twelve 48-byte row segments from rows 616 bytes apart, 3.7x the bytes the lookup
 // needs on the HBM side (PMC), then wrote the 324 samples (352-channel sf rows, 81.5 MB per iteration at 8 pairs) for
 // the 1x1 convolution to read back. Here
-//   * a level is stored in BRICKS of 4 rows x 8 columns = 32 floats = one 128-byte line:
-//       map[source pixel][(by * BW_l + bx) * 32 + (y & 3) * 8 + (x & 7)], by = y >> 2, bx = x >> 3,
-//     cells past H_l / W_l are zeros (they ARE grid_sample's zero padding for taps just outside). The correlation GEMM
-//     writes this layout by itself: its "target pixel" operand is a copy of the feature map in brick order with zero
-//     rows for the padding cells, so output column n' is the brick address and every row is 128-byte aligned. Levels 1-3
-//     come from 2x2-pooled features (correlation is linear in the target features) the same way.
+//   * a level is stored in BRICKS of 4 rows x 8 columns = 32 floats = one 128-byte line, brick-major inside PIXEL BLOCKS of 64
+//     consecutive source pixels of a pair (round 4; kernels.h: BrickPyramid) — a block of this kernel is one pixel block:
+//       level[(((pair * NPB + (p >> 6)) * NBK_l + by * BW_l + bx) * 64 + (p & 63)) * 32 + (y & 3) * 8 + (x & 7)], by = y >> 2, bx = x >> 3,
+//     cells past H_l / W_l are zeros (they ARE grid_sample's zero padding for taps just outside). The correlation kernel
+//     (corr_bricks.hip) writes this layout by itself: its "target pixel" operand is a copy of the feature map in brick order
+//     with zero rows for the padding cells, so output column n' is the brick address. Levels 1-3 come from 2x2-pooled
+//     features (correlation is linear in the target features) the same way. Neighbouring source pixels, whose windows
+//     mostly share bricks, read neighbouring lines.
 //   * a 12 x 12 window touches at most 3 x 4 bricks: one wave fetches them as whole lines (8 lanes x 16 B per brick, two
 //     load instructions), three (pixel, level) units ahead;
 //   * a block owns 64 source pixels (round 3; 32 before): its sixteen waves (level = wave & 3, sixteen pixels each) sample into
@@ -78,8 +80,13 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
   __shared__ __attribute__((aligned(16))) float2 ctab[NWAVE][2][64];   // per wave, two units: (weight, grid index) of the 18 chains
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (tells the compiler what the hardware guarantees: wave-uniform)
-  const long p0 = (long)blockIdx.x * TP;
-  const int np = (int)min((long)TP, npix - p0);
+  // block = one pixel block of one pair (the last block of a pair is partial when N % 64 != 0)
+  static_assert(TP == kBrickPixelBlock, "a block of this kernel is one pixel block of the bricked pyramid");
+  const int bpp = (pyr.N + TP - 1) / TP;                        // blocks per pair
+  const int pair = (int)blockIdx.x / bpp, pblk = (int)blockIdx.x - pair * bpp;
+  const long p0 = (long)pair * pyr.N + (long)pblk * TP;         // first pixel of the block in coords1 / out
+  const int np = min(TP, pyr.N - pblk * TP);
+  (void)npix;
 
   // pad channels 324..351 of every row are zero
   for (int i = tid; i < TP * 28; i += NWAVE * 64) {
@@ -124,13 +131,14 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
     const int nbx = (((u.wx0 & 7) + 11) >> 3) + 1, nby = (((u.wy0 & 3) + 11) >> 2) + 1;
     // the pixel's map of this level as a buffer: a lane whose brick is outside the window or outside the map gets an offset
     // past the end, and the load returns zeros by itself (they ARE grid_sample's zero padding): no select on the data
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pyr.base[l] + (p0 + pp) * NBl), 0,
-                                                                           (int)NBl * 4, 0x00020000);
+    // (the pixel block's level as a buffer of NBK x 64 lines; the unit's pixel selects the line inside a brick's 8 KB run)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(pyr.base[l] + ((long)pair * pyr.NPB + pblk) * NBl * TP), 0, (int)(NBl * TP * 4), 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int bx = u.bx0 + bxi[k], by = u.by0 + byi[k];
       const bool ok = (bxi[k] < nbx) & (byi[k] < nby) & ((unsigned)bx < (unsigned)BWl) & ((unsigned)by < (unsigned)BHl);
-      const int off = ok ? (by * BWl + bx) * 128 + (lane & 7) * 16 : 0x7FFFFFF0;
+      const int off = ok ? ((by * BWl + bx) * TP + pp) * 128 + (lane & 7) * 16 : 0x7FFFFFF0;
       bv[l][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
@@ -342,7 +350,7 @@ __global__ void brick_rows_kernel(const float* __restrict__ src, long sb, int H,
 }
 
 // bricked level -> row-major [pixels][H * W] (debug reads)
-__global__ void unbrick_kernel(const float* __restrict__ src, long NB, int H, int W, int BW, float* __restrict__ dst,
+__global__ void unbrick_kernel(const float* __restrict__ src, long NB, int N, int NPB, int H, int W, int BW, float* __restrict__ dst,
                                long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -350,7 +358,9 @@ __global__ void unbrick_kernel(const float* __restrict__ src, long NB, int H, in
   const long p = i / hw;
   const int c = (int)(i - p * hw);
   const int y = c / W, x = c - y * W;
-  dst[i] = src[p * NB + ((long)(y >> 2) * BW + (x >> 3)) * 32 + (y & 3) * 8 + (x & 7)];
+  const long pair = p / N, pin = p - pair * N;
+  const long brick = (long)(y >> 2) * BW + (x >> 3);
+  dst[i] = src[(((pair * NPB + (pin >> 6)) * (NB / 32) + brick) * 64 + (pin & 63)) * 32 + (y & 3) * 8 + (x & 7)];
 }
 
 }  // namespace
@@ -363,23 +373,26 @@ void launch_brick_rows(const float* src, long sb, int nimg, int H, int W, int C,
   ATDN_HIP(hipGetLastError());
 }
 
-void launch_unbrick(const float* src, long NB, int H, int W, long npix, float* dst, hipStream_t st) {
+void launch_unbrick(const float* src, long NB, int N, int H, int W, long npix, float* dst, hipStream_t st) {
   const long total = npix * H * W;
-  hipLaunchKernelGGL(unbrick_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, src, NB, H, W, (W + 7) / 8, dst, total);
+  hipLaunchKernelGGL(unbrick_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, src, NB, N, brick_pixel_blocks(N), H, W,
+                     (W + 7) / 8, dst, total);
   ATDN_HIP(hipGetLastError());
 }
 
 void launch_lookup_conv(const BrickPyramid& pyr, const float* coords1, long npix, float* coords_used, const float* wfrag,
                         float wscale, const float* bias, float* out, bool fast, hipStream_t st) {
   ATDN_CHECK(wfrag && bias && out, "lookup_conv: missing operand");
-  const dim3 grid((unsigned)cdivl(npix, TP));
+  ATDN_CHECK(pyr.N >= 1 && npix % pyr.N == 0, "lookup_conv: npix must be whole pairs of pyr.N pixels");
+  const dim3 grid((unsigned)((npix / pyr.N) * cdiv(pyr.N, TP)));
   if (fast) hipLaunchKernelGGL((lookup_conv_kernel<true, true>), grid, dim3(NWAVE * 64), 0, st, pyr, coords1, npix, coords_used, wfrag, wscale, bias, out);
   else hipLaunchKernelGGL((lookup_conv_kernel<true, false>), grid, dim3(NWAVE * 64), 0, st, pyr, coords1, npix, coords_used, wfrag, wscale, bias, out);
   ATDN_HIP(hipGetLastError());
 }
 
 void launch_lookup_bricks(const BrickPyramid& pyr, const float* coords1, long npix, float* out, hipStream_t st) {
-  hipLaunchKernelGGL((lookup_conv_kernel<false, false>), dim3((unsigned)cdivl(npix, TP)), dim3(NWAVE * 64), 0, st, pyr, coords1,
+  ATDN_CHECK(pyr.N >= 1 && npix % pyr.N == 0, "lookup_bricks: npix must be whole pairs of pyr.N pixels");
+  hipLaunchKernelGGL((lookup_conv_kernel<false, false>), dim3((unsigned)((npix / pyr.N) * cdiv(pyr.N, TP))), dim3(NWAVE * 64), 0, st, pyr, coords1,
                      npix, nullptr, nullptr, 1.f, nullptr, out);
   ATDN_HIP(hipGetLastError());
 }

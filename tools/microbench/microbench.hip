@@ -409,3 +409,79 @@ extern "C" int atdn_microbench_mfma_convlike(int steps, int launches, float* tf_
     return 1;
   }
 }
+
+// ---- HBM stream rates (round 4): what a kernel that WRITES a few GB can expect. The correlation volume (3.56 GB at 16 pairs)
+// and the attention matrix (2.5 GB) are written once per forward by MFMA-heavy kernels whose stores looked expensive; this
+// prices the stores alone: 16 bytes per lane, every CU, `bytes` per launch (> 256 MiB: past the Infinity Cache).
+// gb_out[7] (GB/s): plain store, non-temporal store, read (sum kept), copy (read + write bytes counted), store in 4 KB runs
+// scattered over the buffer (one wave writes 4 KB, the next wave's run is 30 KB further), the same with 128-byte runs, and
+// 64-byte half-line stores (16 per instruction, the other halves by the wave's next instruction).
+namespace atdn {
+typedef float v4s __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void stream_kernel(float* __restrict__ buf, const float* __restrict__ src, long n16, float* __restrict__ sink) {
+  const long stride = (long)gridDim.x * 256;
+  v4s acc = {0.f, 0.f, 0.f, 0.f};
+  const v4s val = {1.f, 2.f, 3.f, (float)blockIdx.x};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+    if (MODE == 0) reinterpret_cast<v4s*>(buf)[i] = val;
+    else if (MODE == 1) __builtin_nontemporal_store(val, reinterpret_cast<v4s*>(buf) + i);
+    else if (MODE == 2) acc += reinterpret_cast<const v4s*>(src)[i];
+    else if (MODE == 3) reinterpret_cast<v4s*>(buf)[i] = reinterpret_cast<const v4s*>(src)[i];
+    else if (MODE == 6) {
+      // half-line stores as an MFMA accumulator leaves them: one wave instruction = 16 segments of 64 B (4 lanes each), 128 B
+      // apart; the NEXT instruction of the wave fills the other halves of the same 16 lines
+      const long w = i >> 6;            // wave-instruction index
+      const int l = (int)(i & 63);
+      const long dst = (w >> 1) * 2048 + (l >> 2) * 128 + (w & 1) * 64 + (l & 3) * 16;
+      __builtin_nontemporal_store(val, reinterpret_cast<v4s*>(reinterpret_cast<char*>(buf) + dst));
+    } else {
+      // scattered runs: wave-instruction w (64 lanes x 16 B = 1 KB) belongs to run w / RUNK of RUN bytes; consecutive runs are
+      // ROWB bytes apart (a correlation row of 7680 floats), wrapping over the buffer
+      constexpr long RUN = MODE == 4 ? 4096 : 128, ROWB = 30720;
+      const long byte = i * 16;
+      const long run = byte / RUN, within = byte - run * RUN;
+      const long nrows = (n16 * 16) / ROWB;
+      const long row = run % nrows, col = (run / nrows) * RUN;
+      const long dst = row * ROWB + (col % ROWB) + within;
+      __builtin_nontemporal_store(val, reinterpret_cast<v4s*>(reinterpret_cast<char*>(buf) + (dst & ~15L)));
+    }
+  }
+  if (MODE == 2 && acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[0] = acc.x;
+}
+}  // namespace atdn
+
+extern "C" int atdn_microbench_stream(long bytes, int reps, float* gb_out) {
+  try {
+    hipStream_t st = nullptr;
+    float *a, *b, *sink;
+    ATDN_HIP(hipMalloc(&a, bytes)); ATDN_HIP(hipMalloc(&b, bytes)); ATDN_HIP(hipMalloc(&sink, 64));
+    ATDN_HIP(hipMemset(a, 0, bytes)); ATDN_HIP(hipMemset(b, 0, bytes));
+    const long n16 = bytes / 16;
+    auto run = [&](auto kern, double moved) {
+      hipEvent_t e0, e1;
+      ATDN_HIP(hipEventCreate(&e0)); ATDN_HIP(hipEventCreate(&e1));
+      for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(256 * 8), dim3(256), 0, st, a, b, n16, sink);
+      ATDN_HIP(hipEventRecord(e0, st));
+      for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(256 * 8), dim3(256), 0, st, a, b, n16, sink);
+      ATDN_HIP(hipEventRecord(e1, st));
+      ATDN_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      ATDN_HIP(hipEventElapsedTime(&ms, e0, e1));
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      return (float)(moved * reps / (ms * 1e-3) / 1e9);
+    };
+    gb_out[0] = run(atdn::stream_kernel<0>, (double)bytes);
+    gb_out[1] = run(atdn::stream_kernel<1>, (double)bytes);
+    gb_out[2] = run(atdn::stream_kernel<2>, (double)bytes);
+    gb_out[3] = run(atdn::stream_kernel<3>, 2.0 * bytes);
+    gb_out[4] = run(atdn::stream_kernel<4>, (double)bytes);
+    gb_out[5] = run(atdn::stream_kernel<5>, (double)bytes);
+    gb_out[6] = run(atdn::stream_kernel<6>, (double)bytes);
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  }
+}
