@@ -269,6 +269,9 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 // so the matrix pipe of a SIMD always has one wave issuing MFMAs and nothing else, while its partner's LDS / VALU / VMEM
 // work runs beside it. Measured (H3, 8 pairs, same box): 4-wave kernel 372 us, ping-pong 315 us; without the attention
 // stream (zero operands) the MFMA + LDS loop alone takes 257 us here against 339 us in the 4-wave kernel.
+// Round 4 measured, as library variants inside one job (profiles/r04_ab_attention.txt), and did not keep: s_setprio(1) around
+// the multiplying set's MFMAs (+1-2 % on the stage: slower) and the V^T staging split over both sets, two rows per thread
+// each, so that the two kinds of memory phase weigh the same (stage and benchmark unchanged).
 template <bool FAST>
 __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
                                                         const AttnGeom g, const float* __restrict__ vT,
@@ -314,15 +317,16 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   // SQ_LDS_BANK_CONFLICT at 17 % of the kernel's LDS cycles).
   const int lr = (tid & 255) >> 3, ls = tid & 7;
   const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
-  v4f breg[2][4];
+  constexpr int NSTG = 4;
+  v4f breg[2][NSTG];
   auto fetchB = [&](int q, int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) breg[set][i] = *reinterpret_cast<const v4f*>(vrow + (long)(32 * i) * g.ldN + min(q, Q - 1) * 32);
+    for (int i = 0; i < NSTG; ++i) breg[set][i] = *reinterpret_cast<const v4f*>(vrow + (long)(32 * i) * g.ldN + min(q, Q - 1) * 32);
   };
   const int boff = lr * VROW + 16 * ls;
   auto stashB = [&](int image, int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<v4f*>(lds + image * IMG + 32 * i * VROW + boff) = breg[set][i];
+    for (int i = 0; i < NSTG; ++i) *reinterpret_cast<v4f*>(lds + image * IMG + 32 * i * VROW + boff) = breg[set][i];
   };
 
   f32x4v acc[8][2];      // [channel block][row block]

@@ -82,7 +82,8 @@ struct SfAcc { f32x4v b[2][2]; };
 
 // ABL (tools/microbench only — diagnostic builds with WRONG results, timing only; the product instantiates ABL = 0): bit 0 no
 // weight loads in the loop, bit 1 no patch refresh (and no chunk-boundary barrier), bit 2 no LDS fragment reads in the loop,
-// bit 3 no epilogue
+// bit 3 no epilogue, bit 4 every block stores its tile to the SAME 192 pixels of image 0 (the epilogue's instructions all run,
+// the stores stay in L2: what the HBM write side of the epilogue costs)
 template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST = false, bool NORM = false, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
   static_assert(ABL == 0 || !NORM, "ablation builds exist for the plain patch loader");
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
     auto tile_pixel = [&](int i, int q) {
       const int p = (wm * TM + i) * 32 + 8 * q + trow;
       const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+      if constexpr ((ABL & 16) != 0) return p;
       return (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
     };
     // one 32-pixel x 32-channel accumulator tile -> the wave's slab [pixel][LDS_LD floats], scaled
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
           for (int q = 0; q < 4; ++q) {
             if (mq[q] < 0) continue;
             if (nb + 4 <= g.N) {
-              ep.store4(img, mq[q], nb, v[q], bj);
+              ep.store4((ABL & 16) ? 0 : img, mq[q], nb, v[q], bj);
             } else {  // N % 4 != 0: the last run is partial, element-wise
               const float e4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll

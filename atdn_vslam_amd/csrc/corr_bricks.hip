@@ -75,36 +75,15 @@ __global__ __launch_bounds__(256, 2) void corr_bricks_kernel(const CorrArgs a) {
   const int t0 = split * a.tiles_per_split;
   const int nt = min(a.tiles_per_split, a.NB / KT - t0);   // (>= 1: the host never launches an empty slice)
   v4f kreg[NC];
-#ifndef ATDN_CORR_VARIANT
-#define ATDN_CORR_VARIANT 2
-#endif
-  // The tile loads are inline asm (cdna_hip_programming.md 5.7, form (ii)): vmcnt retires in order and counts the result stores
-  // too, and with loads AND stores pending the compiler's wait-count pass gives up counting — it drained everything
-  // (vmcnt(0)) before the LDS writes of a tile, i.e. it waited for the HBM acknowledgement of the previous iteration's
-  // stores once per tile. Hidden from it, the loads are waited for with an exact count: the four stores of the previous
-  // iteration are the only younger operations (none in the first iteration).
+  // (Round 4 also built these loads as inline asm with an exactly counted wait, vmcnt(4), before a tile's LDS writes — with loads
+  // AND stores pending the compiler's wait-count pass drains everything, vmcnt(0), i.e. it also waits for the previous
+  // iteration's stores. Measured in one job: no difference, 1.19-1.23 ms either way; the compiler-counted form stays.)
   auto fetch = [&](int j) __attribute__((always_inline)) {
     const char* src = f2 + (long)((t0 + j) * KT + lr) * 1024 + 16 * ls;
-#if ATDN_CORR_VARIANT == 2
-#define ATDN_CORR_LD(C) asm volatile("global_load_dwordx4 %0, %1, off offset:" #C : "=v"(kreg[C / 128]) : "v"(src))
-    ATDN_CORR_LD(0); ATDN_CORR_LD(128); ATDN_CORR_LD(256); ATDN_CORR_LD(384);
-    ATDN_CORR_LD(512); ATDN_CORR_LD(640); ATDN_CORR_LD(768); ATDN_CORR_LD(896);
-#undef ATDN_CORR_LD
-#else
 #pragma unroll
     for (int c = 0; c < NC; ++c) kreg[c] = *reinterpret_cast<const v4f*>(src + c * 128);
-#endif
   };
-  auto stash = [&](int buf, bool first) __attribute__((always_inline)) {
-#if ATDN_CORR_VARIANT == 2
-    // every destination is named "+v": nothing that reads a tile register is scheduled above the wait
-    if (first)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(kreg[2]), "+v"(kreg[3]), "+v"(kreg[4]), "+v"(kreg[5]),
-                   "+v"(kreg[6]), "+v"(kreg[7]) :: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(kreg[2]), "+v"(kreg[3]), "+v"(kreg[4]), "+v"(kreg[5]),
-                   "+v"(kreg[6]), "+v"(kreg[7]) :: "memory");
-#endif
+  auto stash = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) *reinterpret_cast<v4f*>(lds + buf * IMG + c * CH + lr * KROW + 16 * ls) = kreg[c];
   };
@@ -131,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void corr_bricks_kernel(const CorrArgs a) {
     }
 
   fetch(0);
-  stash(0, true);
+  stash(0);
   __syncthreads();
   fetch(min(1, nt - 1));
   for (int j = 0; j < nt; ++j) {
@@ -174,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void corr_bricks_kernel(const CorrArgs a) {
     }
     // the next tile goes into the other image (last read in iteration j - 1; every wave has passed the barrier since); the
     // tile after that is requested now and lands during the stores and the next MFMA block
-    stash((j + 1) & 1, j == 0);
+    stash((j + 1) & 1);
     fetch(min(j + 2, nt - 1));
     // lane (n, g): source pixel 16 rb + n, brick cells 16 kb + 4 g + 0..3 of this tile (see above)
 #pragma unroll
@@ -189,13 +168,8 @@ __global__ __launch_bounds__(256, 2) void corr_bricks_kernel(const CorrArgs a) {
       f32x4v v1, v2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v1[e] = odd ? recv[e] : A[e]; v2[e] = odd ? Bv[e] : recv[e]; }
-#if ATDN_CORR_VARIANT == 1   // timing only: no result stores (a store that never executes keeps the accumulators alive)
-      if (a.scale == 1.2345e-30f)
-#endif
-      {
-        __builtin_nontemporal_store(v1, reinterpret_cast<gv4f*>(reinterpret_cast<uintptr_t>(a.out + orow[rb][0])));
-        __builtin_nontemporal_store(v2, reinterpret_cast<gv4f*>(reinterpret_cast<uintptr_t>(a.out + orow[rb][1])));
-      }
+      __builtin_nontemporal_store(v1, reinterpret_cast<gv4f*>(reinterpret_cast<uintptr_t>(a.out + orow[rb][0])));
+      __builtin_nontemporal_store(v2, reinterpret_cast<gv4f*>(reinterpret_cast<uintptr_t>(a.out + orow[rb][1])));
       orow[rb][0] += 64 * KT;   // the next brick of this pixel block: 64 pixels x 32 cells further
       orow[rb][1] += 64 * KT;
     }

@@ -143,7 +143,8 @@ extern "C" int atdn_microbench_conv_thin(int nimg, int H, int W, int C, int N, i
     us_out[7] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 1>(s, 1.f, ep, st); });    // only: no weight loads
     us_out[8] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 2>(s, 1.f, ep, st); });    // only: no patch refresh
     us_out[9] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 4>(s, 1.f, ep, st); });    // only: no LDS reads
-    us_out[10] = us_out[11] = 0.f;
+    us_out[10] = time_it([&]() { launch_conv_sf6<12, 64, 2, 2, 3, 3, E, false, false, 16>(s, 1.f, ep, st); });   // stores stay in L2
+    us_out[11] = 0.f;
     (void)hipFree(x); (void)hipFree(wf); (void)hipFree(y); (void)hipFree(bias);
     return 0;
   } catch (const std::exception& e) {
