@@ -92,7 +92,8 @@ def kernel_table(stages, B):
         ("gru_q_v", "q ConvGRU convolution, vertical 5x1 pass, K = 5*384", "5, 1, SfGruQ", ITERS, "mfma", 2.0 * N8 * 128 * 1920 * B),
         ("lookup", "correlation-pyramid lookup fused with convc1 (corr.py:32-53 + update.py:76-78); bytes = SURVEY's "
                    "lookup figure (<=400 cells read + 324 samples per pixel)", "lookup_conv_kernel", ITERS, "hbm", LOOKUP_BYTES * B),
-        ("corr", "all-pairs correlation volume, level 0 (corr.py:55-63), K = 256", "EpiScale", 1, "mfma", 2.0 * nn * 256 * B),
+        ("corr", "all-pairs correlation volume, level 0 (corr.py:55-63), K = 256, written in brick order (corr_bricks.hip; the stage "
+                 "also holds the ~40 us brick_rows copy of the target features)", "corr_bricks_kernel", 1, "mfma", 2.0 * nn * 256 * B),
         ("attention", "Q K^T with the row softmax fused in, full-precision sweep (gma.py:60-74), K = 128",
          "qk_softmax_kernel<false", 1, "mfma", 2.0 * nn * 128 * B),
     ]
@@ -125,7 +126,7 @@ def kernel_table(stages, B):
     return rows
 
 
-def pmc_traffic(kernel_fragment, batch):
+def pmc_traffic(kernel_fragment, batch, largest=False):
     """HBM-side bytes per launch of a kernel from the newest committed rocprofv3 PMC passes (profiles/*_pmc.json:
     2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs). Returns (bytes, file) or (None, None): NOT measured in this run."""
     import glob
@@ -137,7 +138,8 @@ def pmc_traffic(kernel_fragment, batch):
         return None, None
     for name, v in data.items():
         if kernel_fragment in name:
-            return v["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
+            key = "hbm_bytes_largest_launch" if largest and "hbm_bytes_largest_launch" in v else "hbm_bytes_per_launch"
+            return v[key], "profiles/" + os.path.basename(files[-1])
     return None, None
 
 
@@ -406,7 +408,8 @@ def main():
         # whose kernel the profile holds, and their ratio to the row's algorithmic bytes — the lookup and the level-0
         # correlation are the two kernels that move more than they must
         for r in rows:
-            tb, src = pmc_traffic(r["rocprof_name_contains"], B)
+            # (the correlation kernel runs once per pyramid level: level 0 is its largest launch)
+            tb, src = pmc_traffic(r["rocprof_name_contains"], B, largest=(r["stage"] == "corr"))
             if tb is not None:
                 r["traffic"], r["traffic_source"] = tb, src
                 ab = r.get("algorithmic_bytes_per_launch", r["algorithmic_per_launch"] if r["bound"] == "hbm" else None)

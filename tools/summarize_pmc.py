@@ -34,8 +34,11 @@ def main(fetch_csv, write_csv, prefix, batch=None):
     for k in sorted(set(f) | set(w)):
         fa = sum(f.get(k, [0.0])) / max(1, len(f.get(k, [])))
         wa = sum(w.get(k, [0.0])) / max(1, len(w.get(k, [])))
+        # (a kernel launched at several sizes — the correlation kernel runs once per pyramid level — also gets its LARGEST launch)
+        fm, wm = max(f.get(k, [0.0])), max(w.get(k, [0.0]))
         out[k.replace("atdn::", "")] = {"launches": len(f.get(k, [])), "fetch_size_kib_avg": fa, "write_size_kib_avg": wa,
-                                        "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
+                                        "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0,
+                                        "hbm_bytes_largest_launch": (2.0 * fm + wm) * 1024.0}
     js = dict(out)
     js["_batch"] = int(batch)
     json.dump(js, open(prefix + ".json", "w"), indent=1, sort_keys=True)
