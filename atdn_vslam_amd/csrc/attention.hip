@@ -66,20 +66,32 @@ __device__ __forceinline__ void h3_encode(const float* v, f16x8& hi, u32x2& byte
   bytes[1] = w1;
 }
 __device__ __forceinline__ f16x8 h3_decode_lo(f16x8 hi, u32x2 bytes) {
-  // through fp32: byte -> float (v_cvt_f32_ubyteN), minus 128, times 2^(E - 33), one conversion to f16. A packed-f16
-  // form (byte permute to 1024 + byte, v_pk_add_f16, v_pk_mul_f16: a third of the instructions) was measured 27 %
-  // SLOWER in the ping-pong kernel: packed VALU beside MFMAs is an anti-lever on this chip (MI355X_MICROARCH.md).
-  _Float16 mx = hi[0];
-#pragma unroll
-  for (int i = 1; i < 8; ++i) mx = hi[i] > mx ? hi[i] : mx;   // (values are non-negative)
-  const unsigned e = max((unsigned)(__builtin_bit_cast(unsigned short, mx) >> 10) & 31u, 1u);
+  // Round 4: the decode runs in a memory phase BESIDE the partner wave's MFMAs, and every vector instruction of it takes
+  // ~4 cycles of the SIMD's issue away from them (s_memtime stamps, DESIGN.md 8.7: a multiply phase took 1280-1350 cycles for
+  // 768 cycles of MFMAs). So the instruction count is what matters here:
+  //   * group maximum on the BIT PATTERNS (values are non-negative: f16 order = unsigned order) with integer maxima instead
+  //     of 7 compare + select pairs;
+  //   * residual byte -> float with v_cvt_f32_ubyteN, and the "- 128" folded into one FMA: (q - 128) * unit =
+  //     fma(q, unit, -128 unit), exact (|q - 128| <= 128 times a power of two) — written any other way the compiler
+  //     subtracts in the integer domain first (v_lshrrev + v_add_u32 + v_cvt_f32_i32 + v_mul).
+  // (A packed-f16 form — byte permute to 1024 + byte, v_pk_add_f16, v_pk_mul_f16 — was measured 27 % SLOWER in round 2:
+  // packed VALU beside MFMAs is an anti-lever on this chip, MI355X_MICROARCH.md.)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 hb = __builtin_bit_cast(u32x4, hi);
+  // sign bits are clear, so an unsigned 32-bit maximum picks the dword with the largest UPPER half; the lower halves separately
+  const unsigned up = max(max(hb[0], hb[1]), max(hb[2], hb[3]));
+  const unsigned lw = max(max(hb[0] & 0xFFFFu, hb[1] & 0xFFFFu), max(hb[2] & 0xFFFFu, hb[3] & 0xFFFFu));
+  const unsigned e = max(max(up >> 26, lw >> 10), 1u);
   const float unit = __uint_as_float((e + 94u) << 23);        // 2^(E - 33)
+  const float off = -128.f * unit;
   f16x8 lo;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const unsigned w = bytes[i >> 2];
-    const float q = (float)((w >> (8 * (i & 3))) & 255u) - 128.f;
-    lo[i] = (_Float16)(q * unit);   // exact while representable: |q| <= 128 times a power of two
+    const float q = (float)((w >> (8 * (i & 3))) & 255u);
+    float r = __builtin_fmaf(q, unit, off);   // exact while representable
+    asm("" : "+v"(r));                         // opaque: keeps the SLP vectoriser from pairing the FMAs into v_pk_fma_f32 (below)
+    lo[i] = (_Float16)r;
   }
   return lo;
 }
@@ -255,23 +267,33 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ attention x V
-// ---- attention x V as a two-set ping-pong (MI355X_MICROARCH.md, "Two waves per SIMD"). The timing ladder of the 4-wave
-// kernel this replaced said its MFMA + LDS-read loop alone took 339 of 362 us: every wave interleaved its own fragment
-// reads, decode VALU and loads with its own MFMAs, and both waves of a SIMD did the same thing at the same time. Here a block
-// is EIGHT waves (one strip each): waves 0-3 (set A) and 4-7 (set B) share the four SIMDs pairwise and alternate roles
-// every phase, separated by a barrier:
-//     phase 2q    : A multiplies chunk q (24 MFMAs back to back, every operand already in registers)
-//                   B does memory work: attention loads two chunks ahead, V^T fragments of chunk q from LDS into
-//                     registers, decode of the H3 residuals of chunk q (VALU beside A's MFMAs)
-//     phase 2q + 1: B multiplies chunk q
-//                   A does memory work: stages V^T chunk q + 2 into the LDS ring (three images), attention loads,
-//                     fragments + decode for chunk q + 1
-// so the matrix pipe of a SIMD always has one wave issuing MFMAs and nothing else, while its partner's LDS / VALU / VMEM
-// work runs beside it. Measured (H3, 8 pairs, same box): 4-wave kernel 372 us, ping-pong 315 us; without the attention
-// stream (zero operands) the MFMA + LDS loop alone takes 257 us here against 339 us in the 4-wave kernel.
-// Round 4 measured, as library variants inside one job (profiles/r04_ab_attention.txt), and did not keep: s_setprio(1) around
-// the multiplying set's MFMAs (+1-2 % on the stage: slower) and the V^T staging split over both sets, two rows per thread
-// each, so that the two kinds of memory phase weigh the same (stage and benchmark unchanged).
+// ---- attention x V as a two-set ping-pong (MI355X_MICROARCH.md, "Two waves per SIMD"). A block is EIGHT waves (one strip
+// each, 256 registers: ONE block per CU — 16 pairs are two rounds of blocks): waves 0-3 (set A) and 4-7 (set B) share the
+// four SIMDs pairwise and alternate roles every phase, separated by a barrier:
+//     phase 2q    : A multiplies chunk q (48 MFMAs, every operand already in registers) and, in the gaps between them,
+//                     decodes the H3 residuals of ITS chunk q + 1
+//                   B does memory work: attention loads two chunks ahead, V^T fragments of chunk q from LDS into registers
+//     phase 2q + 1: B multiplies chunk q and decodes its chunk q + 1
+//                   A does memory work: stages V^T chunk q + 2 into the LDS ring (three images), attention loads, fragments
+//                     for chunk q + 1
+// Round 4 put s_memtime stamps around the segments of a phase (tools/diag/attn_stamps.py, profiles/r04_attn_stamps*.txt).
+// Before: a multiply phase took 1280-1350 cycles for 768 cycles of MFMAs, and it was what the barrier waited for. Two causes:
+// (1) the ~100 vector instructions of the partner's decode — the two waves of a SIMD share its vector issue, and an MFMA
+// itself holds it for 8 of its 16 cycles; (2) for set B the compiler had SUNK the whole decode behind the barrier into the
+// `if (q < Q)` block, in front of the wave's own MFMAs. Now the decode is 62 instructions (h3_decode_lo) and rides in the MFMA
+// gaps of the wave that owns it (one or two per gap: 'vector-instruction ISSUE cost' of the guide says that is nearly free),
+// and the memory phases carry loads, LDS traffic and barriers only: 632 -> 526 us per launch at 16 pairs (same job).
+// History: the 4-wave kernel this replaced (every wave interleaving its own memory work with its own MFMAs) ran 372 us at 8
+// pairs against 315 for the first ping-pong. Measured in round 4 and not kept (profiles/r04_ab_attention.txt): s_setprio(1)
+// around the multiplying set's MFMAs; the V^T staging split over both sets (it only moves work between two memory phases).
+#ifdef ATDN_ATTN_STAMP   // diagnostic: s_memtime stamps around the segments of a phase, summed per wave (waves 0 and 4 of every block)
+__device__ unsigned atdn_attn_stamps_dev[1024][2][8];
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    seg[k] += (unsigned)(t_ - tlast); tlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 template <bool FAST>
 __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
                                                         const AttnGeom g, const float* __restrict__ vT,
@@ -285,7 +307,8 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   constexpr int VROW = 160;
   constexpr int IMG = 128 * VROW;      // V^T chunk: [128 channels][160 B]
   constexpr int BLK = AT_BLK_BYTES;
-  constexpr int D = 3;                 // attention chunks resident per wave (ring of register sets; 4 measured 2 % slower)
+  constexpr int D = 3;                 // attention chunks resident per wave (ring of register sets; 4 measured 1-2 % slower, twice)
+  constexpr int DEC2 = 14;             // MFMA gaps that carry two instructions of the decode (the other 34 carry one: 62 in all)
   __shared__ __attribute__((aligned(16))) char lds[3 * IMG];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,6 +321,8 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   const int n16 = lane & 15, g16 = lane >> 4;
   const int Q = g.Q;
 
+  // (address arithmetic of the two streams on the scalar unit — wave index through readfirstlane, uniform bases + 32-bit lane
+  // offsets — was measured in round 4: 1-3 % SLOWER on the stage, not kept)
   const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * BLK;
   f16x8 ring[D][2];      // [slot][row block]
   u32x2 ringb[D][2];
@@ -354,6 +379,8 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
       ph[rb] = ring[slot][rb];
       if (!FAST) pl[rb] = h3_decode_lo(ph[rb], ringb[slot][rb]);
     }
+    // (pinned here: the results are only used inside `if (q < Q)`, and left alone the compiler sinks the decode into that block)
+    if (!FAST) asm volatile("" :: "v"(pl[0]), "v"(pl[1]));
   };
   auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -369,8 +396,41 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
         acc[cb][rb] = c;
       }
   };
+  // multiply chunk q AND decode the residuals of chunk q + 1 (ring slot `next`) in the gaps between the MFMAs: a 16x16x32 MFMA
+  // holds the SIMD's vector issue for 8 of its 16 cycles, so one or two vector instructions of the SAME wave ride in every gap
+  // nearly free (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'), where the same instructions in the partner's memory
+  // phase lengthen that phase — which is what the barrier waits for once the decode is short
+  auto multiply_next = [&](int next) __attribute__((always_inline)) {
+    f16x8 pln[2];
+    if (!FAST) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) pln[rb] = h3_decode_lo(ring[next][rb], ringb[next][rb]);
+    }
+    multiply();
+    if (!FAST) {
+#pragma unroll
+      for (int k = 0; k < DEC2; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#pragma unroll
+      for (int k = DEC2; k < 48; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      ph[rb] = ring[next][rb];
+      if (!FAST) pl[rb] = pln[rb];
+    }
+  };
 
   constexpr int U = (D % 2) ? 2 * D : D;        // unroll: ring slots (D) x V^T register sets (2)
+#ifdef ATDN_ATTN_STAMP
+  unsigned seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = 0;
+#endif
   const int nq = (Q + U - 1) / U * U;           // surplus chunks multiply nothing (uniform branch), barriers still match
   if (setA) {
     // prologue: V^T chunks 0, 1 -> images 0, 1; chunks 2, 3 wait in the register sets; attention chunks 0..2
@@ -386,6 +446,9 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
     read_frags(0);
     take_chunk(0);
     int image = 0;                              // LDS image of chunk q: q % 3
+#ifdef ATDN_ATTN_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tlast = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     for (int q0 = 0; q0 < nq; q0 += U) {
 #pragma unroll
       for (int d = 0; d < U; ++d) {
@@ -393,44 +456,62 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
         const int image1 = image == 2 ? 0 : image + 1, image2 = image1 == 2 ? 0 : image1 + 1;
         // phase 2q: multiply chunk q
         __builtin_amdgcn_sched_barrier(0);
-        if (q < Q) multiply();
+        if (q < Q) multiply_next((d + 1) % D);
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(0);
         __syncthreads();
+        STAMP(1);
         // phase 2q + 1: memory work. V^T chunk q + 2 (requested two iterations ago) -> image (q + 2) % 3, last read in
         // phase 2q - 2; its register set takes chunk q + 4; the ring slot of chunk q takes chunk q + 3
         stashB(image2, d & 1);
         fetchB(q + 4, d & 1);
         loadP(q + D, d % D);
+        STAMP(2);
         read_frags(image1);                     // chunk q + 1: staged in phase 2q - 1, published by its barrier
-        take_chunk((d + 1) % D);
         image = image1;
+        STAMP(3);
         __syncthreads();
+        STAMP(5);
       }
     }
   } else {
 #pragma unroll
     for (int c = 0; c < D - 1; ++c) loadP(c, c);
+    take_chunk(0);
     __syncthreads();                            // (1)
     int image = 0;
+#ifdef ATDN_ATTN_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tlast = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     for (int q0 = 0; q0 < nq; q0 += U) {
 #pragma unroll
       for (int d = 0; d < U; ++d) {
         const int q = q0 + d;
         // phase 2q: memory work: attention chunk q + 2 into the slot chunk q - 1 left, operands of chunk q
         loadP(q + D - 1, (d + D - 1) % D);
+        STAMP(0);
         read_frags(image);
-        take_chunk(d % D);
         image = image == 2 ? 0 : image + 1;
+        STAMP(1);
         __syncthreads();
+        STAMP(3);
         // phase 2q + 1: multiply chunk q
         __builtin_amdgcn_sched_barrier(0);
-        if (q < Q) multiply();
+        if (q < Q) multiply_next((d + 1) % D);
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
       }
     }
   }
 
+#ifdef ATDN_ATTN_STAMP
+  if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 1024) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atdn_attn_stamps_dev[blockIdx.x][wave >> 2][k] = seg[k];
+  }
+#endif
   // lane (n, g) holds, for query rows 32 strip + 16 rb + n, channels 16 cb + 4 g + 0..3
   const float gam = gamma[0];
   const float* mfb = mf + (long)b * sb;
@@ -476,6 +557,12 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict
 }
 
 }  // namespace
+
+#ifdef ATDN_ATTN_STAMP
+extern "C" int atdn_attn_stamps(unsigned* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(atdn_attn_stamps_dev), sizeof(unsigned) * 1024 * 2 * 8);
+}
+#endif
 
 void launch_qk_rowmax(const float* qk, const AttnGeom& g, float* rowmax, hipStream_t st) {
   const int nblk = g.B * ((g.RT + 3) / 4);

@@ -486,3 +486,90 @@ extern "C" int atdn_microbench_stream(long bytes, int reps, float* gb_out) {
     return 1;
   }
 }
+
+// ---- strip streams (round 4): the read pattern of attention x V. Every wave of a 512-thread block (two blocks per CU) streams ITS
+// OWN contiguous run of `run_bytes` in 3 KB steps (2 x 1 KB as 16 B per lane + 2 x 512 B as 8 B per lane), three steps ahead,
+// straight into registers — 3,712 concurrent sequential streams 0.7 MB apart. The plain read test above has all waves marching
+// through the buffer together. Modes: 0 as the kernel does it (non-temporal); 1 the eight runs of a block interleaved per step
+// (a block reads 24 KB contiguous per step); 2 default cache policy; 3 the step as 3 x 1 KB of 16-B loads; 4 mode 0 with two
+// block barriers per step (the ping-pong's coupling); 5 mode 1 with the barriers; 6 mode 0, ring six steps deep.
+namespace atdn {
+typedef unsigned int u2s __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void strip_stream_kernel(const char* __restrict__ buf, long run_bytes, int nstep, float* __restrict__ sink) {
+  constexpr int D = MODE == 6 ? 6 : 3;
+  constexpr bool INTER = MODE == 1 || MODE == 5, NT = MODE != 2, BAR = MODE == 4 || MODE == 5;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const char* base = buf + (long)blockIdx.x * 8 * run_bytes + (INTER ? (long)wave * 3072 : (long)wave * run_bytes);
+  const long step = INTER ? 8L * 3072 : 3072L;
+  v4s r16[D][3];
+  u2s r8[D][2];
+  auto load = [&](int q, int slot) __attribute__((always_inline)) {
+    const char* p = base + (long)min(q, nstep - 1) * step;
+    if (MODE == 3) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r16[slot][k] = __builtin_nontemporal_load(reinterpret_cast<const v4s*>(p + k * 1024 + lane * 16));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        r16[slot][k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4s*>(p + k * 1024 + lane * 16))
+                          : *reinterpret_cast<const v4s*>(p + k * 1024 + lane * 16);
+        r8[slot][k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u2s*>(p + 2048 + k * 512 + lane * 8))
+                         : *reinterpret_cast<const u2s*>(p + 2048 + k * 512 + lane * 8);
+      }
+    }
+  };
+  v4s acc = {0.f, 0.f, 0.f, 0.f};
+  unsigned acci = 0;
+#pragma unroll
+  for (int c = 0; c < D; ++c) load(c, c);
+  for (int q0 = 0; q0 < nstep; q0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (MODE == 3) acc += r16[d][0] + r16[d][1] + r16[d][2];
+      else { acc += r16[d][0] + r16[d][1]; acci += r8[d][0][0] ^ r8[d][0][1] ^ r8[d][1][0] ^ r8[d][1][1]; }
+      load(q0 + d + D, d);
+      if (BAR) { __syncthreads(); __syncthreads(); }
+    }
+  }
+  if (acc.x + acc.y + acc.z + acc.w + (float)acci == 1.2345e-30f) sink[0] = acc.x;
+}
+}  // namespace atdn
+
+// gb_out[7]: GB/s of modes 0..6 over nblocks x 8 runs of run_bytes (rounded down to whole 3 KB steps, a multiple of 6)
+extern "C" int atdn_microbench_strips(long run_bytes, int nblocks, int reps, float* gb_out) {
+  try {
+    hipStream_t st = nullptr;
+    const int nstep = (int)(run_bytes / 3072) / 6 * 6;
+    run_bytes = (long)nstep * 3072;
+    const long bytes = run_bytes * 8 * nblocks;
+    char* a; float* sink;
+    ATDN_HIP(hipMalloc(&a, bytes)); ATDN_HIP(hipMalloc(&sink, 64));
+    ATDN_HIP(hipMemset(a, 0, bytes));
+    auto run = [&](auto kern) {
+      hipEvent_t e0, e1;
+      ATDN_HIP(hipEventCreate(&e0)); ATDN_HIP(hipEventCreate(&e1));
+      for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), 0, st, a, run_bytes, nstep, sink);
+      ATDN_HIP(hipEventRecord(e0, st));
+      for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), 0, st, a, run_bytes, nstep, sink);
+      ATDN_HIP(hipEventRecord(e1, st));
+      ATDN_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      ATDN_HIP(hipEventElapsedTime(&ms, e0, e1));
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      return (float)((double)bytes * reps / (ms * 1e-3) / 1e9);
+    };
+    gb_out[0] = run(atdn::strip_stream_kernel<0>);
+    gb_out[1] = run(atdn::strip_stream_kernel<1>);
+    gb_out[2] = run(atdn::strip_stream_kernel<2>);
+    gb_out[3] = run(atdn::strip_stream_kernel<3>);
+    gb_out[4] = run(atdn::strip_stream_kernel<4>);
+    gb_out[5] = run(atdn::strip_stream_kernel<5>);
+    gb_out[6] = run(atdn::strip_stream_kernel<6>);
+    (void)hipFree(a); (void)hipFree(sink);
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  }
+}
