@@ -19,7 +19,7 @@ namespace atdn {
 // the true maximum gives the same probabilities and keeps e inside the f16 range (largest element of a row ~ 2^10).
 // Element format H3, 3 bytes: hi = f16(e), residual as ONE BYTE in units of the group's ulp / 256 (group = a lane's eight
 //   values of one k-step): e = hi + (byte - 128) * 2^(E - 33), E = f16 exponent of the group's largest hi.
-//   block = [rb][lane][16 B] hi, then [rb][lane][8 B] residual bytes = 3072 B.
+//   block = [rb][lane][16 B] hi, then [lane][rb][8 B] residual bytes (both row blocks of a lane adjacent: one 16-byte access) = 3072 B.
 //   H3 carries 19 significant bits of every value within 2^-8 of its group's maximum and an ABSOLUTE error below
 //   2^-20 of the group maximum everywhere — what matters for sum_k e_k v_k with fp32 accumulation (the residual of a
 //   4-byte hi | lo pair is an f16 subnormal for everything below 2^-4 of the row maximum, i.e. no better) — and moves 25 %

@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 #pragma unroll
     for (int cq = 0; cq < 2; ++cq) {        // the two 32-key chunks of the tile
       const int key0 = j * KT + 32 * cq + 4 * g16;
+      u32x2 bytes2[2] = {{0u, 0u}, {0u, 0u}};   // residual bytes of both row blocks: one 16-byte store (and one load in the consumer)
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         if (STATS) {
@@ -243,9 +244,14 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
             u32x2 bytes;
             h3_encode(v, hi, bytes, clamped);
             st_frag_nt(d + rb * 1024 + lane * 16, hi);
-            __builtin_nontemporal_store(bytes, reinterpret_cast<u32x2*>(d + 2048 + rb * 512 + lane * 8));
+            bytes2[rb] = bytes;
           }
         }
+      }
+      if (!STATS && strip_ok && 2 * j + cq < g.Q) {
+        typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+        const u32x4s bb = {bytes2[0][0], bytes2[0][1], bytes2[1][0], bytes2[1][1]};
+        __builtin_nontemporal_store(bb, reinterpret_cast<u32x4s*>(pdst + (long)(2 * j + cq) * BLK + 2048 + lane * 16));
       }
     }
     __syncthreads();
@@ -324,16 +330,16 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   // (address arithmetic of the two streams on the scalar unit — wave index through readfirstlane, uniform bases + 32-bit lane
   // offsets — was measured in round 4: 1-3 % SLOWER on the stage, not kept)
   const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * BLK;
+  typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
   f16x8 ring[D][2];      // [slot][row block]
-  u32x2 ringb[D][2];
+  u32x4s ringb[D];       // residual bytes of both row blocks: one load
   auto loadP = [&](int q, int slot) __attribute__((always_inline)) {
     const char* p = pblk + (long)min(q, Q - 1) * BLK;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      ring[slot][rb] = ld_frag_nt(p + rb * 1024 + lane * 16);
-      ringb[slot][rb] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 2048 + rb * 512 + lane * 8));
-    }
+    for (int rb = 0; rb < 2; ++rb) ring[slot][rb] = ld_frag_nt(p + rb * 1024 + lane * 16);
+    ringb[slot] = __builtin_nontemporal_load(reinterpret_cast<const u32x4s*>(p + 2048 + lane * 16));
   };
+  auto bytes_of = [&](int slot, int rb) __attribute__((always_inline)) { return u32x2{ringb[slot][2 * rb], ringb[slot][2 * rb + 1]}; };
 
   // V^T staging (set A only: tid < 256): rows lr + 32 i, 16-byte slot ls of the row's 128-byte [32 hi | 32 lo] chunk. The
   // producer of V^T (epilogues_sf.h: SfVT) already stores the keys of a chunk in operand order — slot g = keys
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       ph[rb] = ring[slot][rb];
-      if (!FAST) pl[rb] = h3_decode_lo(ph[rb], ringb[slot][rb]);
+      if (!FAST) pl[rb] = h3_decode_lo(ph[rb], bytes_of(slot, rb));
     }
     // (pinned here: the results are only used inside `if (q < Q)`, and left alone the compiler sinks the decode into that block)
     if (!FAST) asm volatile("" :: "v"(pl[0]), "v"(pl[1]));
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
     f16x8 pln[2];
     if (!FAST) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) pln[rb] = h3_decode_lo(ring[next][rb], ringb[next][rb]);
+      for (int rb = 0; rb < 2; ++rb) pln[rb] = h3_decode_lo(ring[next][rb], bytes_of(next, rb));
     }
     multiply();
     if (!FAST) {
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* __restrict
     const float rv = rinv[(long)b * g.Npad + m];
     float* row = rows + ((long)b * g.N + m) * g.ldN + q * 32;
     const f16x8 hi = ld_frag(p + rb * 1024 + lane * 16);
-    const f16x8 lo = h3_decode_lo(hi, *reinterpret_cast<const u32x2*>(p + 2048 + rb * 512 + lane * 8));
+    const f16x8 lo = h3_decode_lo(hi, *reinterpret_cast<const u32x2*>(p + 2048 + lane * 16 + rb * 8));
     // key group g of the producer: keys 4 g + (i & 3) + 16 (i >> 2)
 #pragma unroll
     for (int i = 0; i < 8; ++i) row[4 * gq + (i & 3) + 16 * (i >> 2)] = ((float)hi[i] + (float)lo[i]) * rv;

@@ -63,6 +63,9 @@ extern "C" int atdn_microbench_conv(int nimg, int H, int W, int C, int N, int KH
     us_out[4] = ATDN_MB_SF6(128, 1, 4, 9);    // ... and no weight loads in the loop
     us_out[5] = ATDN_MB_SF6(128, 1, 4, 13);   // ... and no LDS reads in the loop
     us_out[6] = ATDN_MB_SF6(128, 1, 4, 15);   // ... and no patch refresh: the bare MFMA stream of this tiling
+    // (round 4 also timed wave tiles of 64 px x 64 ch — <128, 2, 2> at two waves per SIMD, <256, 2, 4> — against the 128 px x 32 ch
+    // ones: half the LDS fragment reads per MFMA for twice the weight loads. Equal within 1 % on every shape:
+    // profiles/r04_microbench_conv_tiles.txt. The rows were removed again, the kernel keeps its (threads, 1) launch bounds.)
     us_out[7] = us_out[8] = us_out[9] = 0.f;
 #undef ATDN_MB_SF6
     us_out[10] = us_out[11] = 0.f;
