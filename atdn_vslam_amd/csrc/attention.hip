@@ -522,6 +522,7 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   const float gam = gamma[0];
   const float* mfb = mf + (long)b * sb;
   float* ob = out + (long)b * sb;
+  bool clamped = false;
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     const int m = strip * 32 + 16 * rb + n16;
@@ -533,10 +534,11 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
         const float4 x = sf_load4(mfb, (long)m * ld, c);
         const float4 o = make_float4(x.x + rv * acc[cb][rb][0], x.y + rv * acc[cb][rb][1], x.z + rv * acc[cb][rb][2],
                                      x.w + rv * acc[cb][rb][3]);
-        sf_store4(ob, (long)m * ld, c, o);
+        sf_store4_flag(ob, (long)m * ld, c, o, clamped);
       }
     }
   }
+  sf_report(clamped);
 }
 
 // one wave per (pair, strip, chunk) block: normalised probabilities as fp32 rows (tests / debug only)

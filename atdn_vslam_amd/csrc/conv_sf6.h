@@ -436,6 +436,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
     // 128-wide block from three to two resident blocks per CU)
     constexpr bool PIPE = Epi::kPrefetch && sizeof(AuxT) <= 2 * sizeof(float4);
     AuxT aux_next[PIPE ? 4 : 1];
+    bool clamped = false;   // saturation of the sf stores: flagged in a register, reported once (sf.h: sf_store4_flag)
     if constexpr (PIPE) {
       const int nb0 = n0 + (wn * TN) * 32 + tcol;
 #pragma unroll
@@ -477,13 +478,13 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (mq[q] >= 0 && nb < g.N) ep.apply4(img, mq[q], nb, v[q], aux[q], bj);
+            if (mq[q] >= 0 && nb < g.N) ep.apply4(img, mq[q], nb, v[q], aux[q], bj, clamped);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             if (mq[q] < 0) continue;
             if (nb + 4 <= g.N) {
-              ep.store4((ABL & 16) ? 0 : img, mq[q], nb, v[q], bj);
+              ep.store4((ABL & 16) ? 0 : img, mq[q], nb, v[q], bj, clamped);
             } else {  // N % 4 != 0: the last run is partial, element-wise
               const float e4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
         }
       }
     }
+    sf_report(clamped);
     return;
   }
   // ---- pixel-major epilogue (TM x TN tiles per wave). A lane owns NSET = 2 channel columns of a 32 x 32 tile (channel

@@ -32,7 +32,7 @@ struct EpiBias {
   __device__ __forceinline__ float4 bias4(int n) const {
     return bias ? make_float4(bias[n], bias[n + 1], bias[n + 2], bias[n + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __device__ __forceinline__ void store4(int img, int m, int n, float4 a, float4 b) const {
+  __device__ __forceinline__ void store4(int img, int m, int n, float4 a, float4 b, bool& /*clamped: sf epilogues only*/) const {
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     if (ACT == ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
     float* d = dst + (long)img * ob + (long)m * ld + n;
@@ -171,7 +171,7 @@ struct EpiGruQ {
   }
   __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float q = tanhf(a + bias[n]);
-    hout[(long)img * ob + (long)m * 128 + n] = (1.f - x.z) * x.h + x.z * q;
+    hout[(long)img * ob + (long)m * 128 + n] = __builtin_fmaf(x.z, q, (1.f - x.z) * x.h);   // one explicit fma: see SfGruQ::blend
   }
 };
 

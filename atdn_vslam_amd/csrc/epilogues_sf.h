@@ -32,10 +32,11 @@ struct SfBias {
   __device__ __forceinline__ float4 bias4(int n) const {
     return bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __device__ __forceinline__ void store4(int img, int m, int n, float4 a, float4 b) const {
+  // (`clamped`: the kernel's saturation flag, reported once after its loops — sf.h, sf_store4_flag)
+  __device__ __forceinline__ void store4(int img, int m, int n, float4 a, float4 b, bool& clamped) const {
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     if (ACT == ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-    sf_store4(dst, (long)img * ob + (long)m * ld, n, a);
+    sf_store4_flag(dst, (long)img * ob + (long)m * ld, n, a, clamped);
   }
 };
 
@@ -57,13 +58,13 @@ struct SfBiasReluAddRelu {
   struct Aux4 { float4 r; };
   __device__ __forceinline__ Aux4 load4(int img, int m, int n) const { return {sf_load4(res, (long)img * rb + (long)m * ldr, n)}; }
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b) const {
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped) const {
     float4 o;
     o.x = fmaxf(x.r.x + fmaxf(a.x + b.x, 0.f), 0.f);
     o.y = fmaxf(x.r.y + fmaxf(a.y + b.y, 0.f), 0.f);
     o.z = fmaxf(x.r.z + fmaxf(a.z + b.z, 0.f), 0.f);
     o.w = fmaxf(x.r.w + fmaxf(a.w + b.w, 0.f), 0.f);
-    sf_store4(dst, (long)img * ob + (long)m * ld, n, o);
+    sf_store4_flag(dst, (long)img * ob + (long)m * ld, n, o, clamped);
   }
 };
 
@@ -134,7 +135,7 @@ struct SfGruZR {
             *reinterpret_cast<const float4*>(pre + (long)img * pb + (long)m * 256 + n)};
   }
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b) const {
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped) const {
     float4 v;
     v.x = sigmoid_fast_((a.x + x.p.x) + b.x);
     v.y = sigmoid_fast_((a.y + x.p.y) + b.y);
@@ -142,7 +143,7 @@ struct SfGruZR {
     v.w = sigmoid_fast_((a.w + x.p.w) + b.w);
     const long o = (long)img * ob + (long)m * 128;
     if (n < 128) *reinterpret_cast<float4*>(z + o + n) = v;
-    else sf_store4(rh, o, n - 128, make_float4(v.x * x.h.x, v.y * x.h.y, v.z * x.h.z, v.w * x.h.w));
+    else sf_store4_flag(rh, o, n - 128, make_float4(v.x * x.h.x, v.y * x.h.y, v.z * x.h.z, v.w * x.h.w), clamped);
   }
 };
 
@@ -160,9 +161,14 @@ struct SfGruQ {
     const long o = (long)img * ob + (long)m * 128;
     return {sf_load(h, o, n), z[o + n], pre[o + n]};
   }
+  // h' = (1 - z) h + z q, written as ONE explicit fma on a rounded product: "a*b + c*d" leaves the compiler the choice of which
+  // product to fuse, and it chose differently in two instantiations of the same kernel (64- and 128-wide blocks) once the
+  // surrounding code changed — a pair then came out differently alone and inside an 8-pair launch
+  // (tests/test_gpu_parity.py: test_large_batch_tile_path_matches_single_pairs, round 4)
+  __device__ __forceinline__ static float blend(float z, float h, float q) { return __builtin_fmaf(z, q, (1.f - z) * h); }
   __device__ __forceinline__ void apply(int img, int m, int n, float a, Aux x) const {
     const float q = tanh_fast_((a + x.p) + bias[n]);
-    sf_store(hout, (long)img * ob + (long)m * 128, n, (1.f - x.z) * x.h + x.z * q);
+    sf_store(hout, (long)img * ob + (long)m * 128, n, blend(x.z, x.h, q));
   }
   static constexpr bool kVec4 = true;
   static constexpr int kGen6 = 2;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
@@ -172,13 +178,13 @@ struct SfGruQ {
     return {sf_load4(h, o, n), *reinterpret_cast<const float4*>(z + o + n), *reinterpret_cast<const float4*>(pre + o + n)};
   }
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b) const {
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped) const {
     float4 o;
-    o.x = (1.f - x.z.x) * x.h.x + x.z.x * tanh_fast_((a.x + x.p.x) + b.x);
-    o.y = (1.f - x.z.y) * x.h.y + x.z.y * tanh_fast_((a.y + x.p.y) + b.y);
-    o.z = (1.f - x.z.z) * x.h.z + x.z.z * tanh_fast_((a.z + x.p.z) + b.z);
-    o.w = (1.f - x.z.w) * x.h.w + x.z.w * tanh_fast_((a.w + x.p.w) + b.w);
-    sf_store4(hout, (long)img * ob + (long)m * 128, n, o);
+    o.x = blend(x.z.x, x.h.x, tanh_fast_((a.x + x.p.x) + b.x));
+    o.y = blend(x.z.y, x.h.y, tanh_fast_((a.y + x.p.y) + b.y));
+    o.z = blend(x.z.z, x.h.z, tanh_fast_((a.z + x.p.z) + b.z));
+    o.w = blend(x.z.w, x.h.w, tanh_fast_((a.w + x.p.w) + b.w));
+    sf_store4_flag(hout, (long)img * ob + (long)m * 128, n, o, clamped);
   }
 };
 
@@ -217,7 +223,7 @@ struct SfFlowHeadPartial {
   const float* w2;     // conv2 weights, fp32 [18][256]: row tap * 2 + output
   float* G; long npix; // [img][pix][18]
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-  __device__ __forceinline__ void store4(int, int, int, float4, float4) const {}
+  __device__ __forceinline__ void store4(int, int, int, float4, float4, bool&) const {}
   __device__ __forceinline__ void operator()(int, int, int, float) const {}
 };
 

@@ -174,13 +174,32 @@ void GmaNet::finalize() {
   if (sf) pack_fragment_major16(arena_, convc1_);   // the fused lookup kernel loads operand-order weights (16x16x32)
   convc2_ = tap({u + "encoder.convc2"});
   convf1_ = pack_conv(arena_, sd_, {u + "encoder.convf1"}, MODE_ROW, 4);
-  {  // the same weights as [(ky*7 + kx)*2 + c][128] for the register-tiled VALU kernel (small_convs.hip)
+  {  // the same weights in split-f16 fragment order for flow_conv7_sf_kernel (small_convs.hip): K = 8 rows x (8 taps x 2
+     // channels), the eighth row and tap zero; [wave][channel block][step][hi, lo][lane (n, g)] x 8 f16, lane (n, g) = channel
+     // 32 wave + 16 block + n, filter row 2 step + (g >> 1), taps 4 (g & 1) .. + 3; scaled by 2^p so that max |w| is in [1, 2)
     const HostTensor& w = sd_.get(u + "encoder.convf1.weight");
     ATDN_CHECK(w.shape[0] == 128 && w.shape[1] == 2 && w.shape[2] == 7 && w.shape[3] == 7, "convf1 is 7x7, 2 -> 128");
-    convf1_vw_off_ = arena_.alloc(98 * 128);
-    for (int n = 0; n < 128; ++n)
-      for (int c = 0; c < 2; ++c)
-        for (int t = 0; t < 49; ++t) arena_.at(convf1_vw_off_)[(t * 2 + c) * 128 + n] = w.data[((long)n * 2 + c) * 49 + t];
+    float mx = 0.f;
+    for (float v : w.data) mx = std::max(mx, std::fabs(v));
+    int e = 0;
+    if (mx > 0.f) (void)std::frexp(mx, &e);
+    const int p = 1 - e;
+    convf1_wscale_ = std::ldexp(1.0f, -p);
+    convf1_sf_off_ = arena_.alloc(4L * 2 * 4 * 2 * 64 * 4);
+    _Float16* f = reinterpret_cast<_Float16*>(arena_.at(convf1_sf_off_));
+    for (int wv = 0; wv < 4; ++wv)
+      for (int cb = 0; cb < 2; ++cb)
+        for (int s = 0; s < 4; ++s)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 8; ++i) {
+              const int n = 32 * wv + 16 * cb + (lane & 15), g = lane >> 4;
+              const int ky = 2 * s + (g >> 1), kx = 4 * (g & 1) + (i >> 1), c = i & 1;
+              const float v = (ky < 7 && kx < 7) ? std::ldexp(w.data[(((long)n * 2 + c) * 7 + ky) * 7 + kx], p) : 0.f;
+              const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+              const long frag = (((long)wv * 2 + cb) * 4 + s) * 2;
+              f[(frag * 64 + lane) * 8 + i] = hi;
+              f[((frag + 1) * 64 + lane) * 8 + i] = lo;
+            }
   }
   convf2_ = tap({u + "encoder.convf2"});
   convm_ = tap({u + "encoder.conv"});
@@ -538,7 +557,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   // (Round 3 captured the flow branch — convf1, convf2: independent of the correlation branch — as a parallel branch of the
   // graph on a second stream: +0.3 % on bench.py's two-stream loop, but -3 % in the sequence driver, whose lane streams then
   // share hardware queues with the branch streams of the two graphs. Removed: one stream per clip, one queue per stream.)
-  launch_flow_conv7(flow4_.p, B, H8, W8, arena_.dev(convf1_vw_off_), convf1_.b, flo1_.p, st);
+  launch_flow_conv7_sf(flow4_.p, B, H8, W8, arena_.dev(convf1_sf_off_), convf1_wscale_, convf1_.b, flo1_.p, sf_fast_mode(), st);
   s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
   s = conv_shape(convm_, corflo_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);

@@ -114,6 +114,20 @@ __device__ __forceinline__ void sf_store4(float* base, long off, int c, float4 v
   *reinterpret_cast<f16x4*>(q) = f16x4{a.hi, b.hi, d.hi, e.hi};
   *reinterpret_cast<f16x4*>(q + 32) = f16x4{a.lo, b.lo, d.lo, e.lo};
 }
+// The same store for loops that keep memory operations in flight (convolution epilogues, attention x V, lookup): branch-free,
+// the clamp goes into a register flag that the kernel reports once per wave after the loop (sf_report). sf_store4's counted
+// cold path — a pointer load and an atomic behind a branch — makes the wait-count pass drain every outstanding store and
+// prefetched operand at the join: the ConvGRU epilogues carried an s_waitcnt vmcnt(0) per pixel group (round 4).
+__device__ __forceinline__ void sf_store4_flag(float* base, long off, int c, float4 v, bool& clamped) {
+  clamped |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) <= 65504.f);   // bounds every value; a NaN fails the test
+  const float lim = 65504.f;
+  v.x = fminf(fmaxf(v.x, -lim), lim); v.y = fminf(fmaxf(v.y, -lim), lim);
+  v.z = fminf(fmaxf(v.z, -lim), lim); v.w = fminf(fmaxf(v.w, -lim), lim);
+  const SfPair a = sf_split_nocheck_(v.x), b = sf_split_nocheck_(v.y), d = sf_split_nocheck_(v.z), e = sf_split_nocheck_(v.w);
+  _Float16* q = sf_ptr(base, off, c);
+  *reinterpret_cast<f16x4*>(q) = f16x4{a.hi, b.hi, d.hi, e.hi};
+  *reinterpret_cast<f16x4*>(q + 32) = f16x4{a.lo, b.lo, d.lo, e.lo};
+}
 __device__ __forceinline__ float4 sf_load4(const float* base, long off, int c) {
   const _Float16* q = sf_ptr(base, off, c);
   const f16x4 hi = *reinterpret_cast<const f16x4*>(q), lo = *reinterpret_cast<const f16x4*>(q + 32);
