@@ -285,7 +285,12 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
           __builtin_amdgcn_sched_barrier(0);
           if (!(ABL & 2) && hs == 0) { fetch_patch(cn); if constexpr (NORM) fetch_norm(cn); }   // lands during this chunk's taps
           // weights of K step st + RT - 1: channel block `half` in this half-step, into the slot K step st - 1 released
-          if (!(ABL & 1)) load_w(wr[(st + RT - 1) % RT], c0, st + RT - 1, half);
+          // two-slot ring (1x5 / 5x1): both channel blocks of K step st + 1 in half-step 0 — block 1 loaded in half-step 1 would
+          // be needed one half-step later (both blocks are multiplied in every half-step): q gate -1.5 %, z|r -0.6 % (round 4)
+          if (!(ABL & 1)) {
+            if (RT == 2) { if (half == 0) { load_w(wr[(st + 1) % RT], c0, st + 1, 0); load_w(wr[(st + 1) % RT], c0, st + 1, 1); } }
+            else load_w(wr[(st + RT - 1) % RT], c0, st + RT - 1, half);
+          }
           if (!(ABL & 4) && hs + 1 < NH) read_a((hs + 1) & 1, (hs + 1) >> 1);
           if constexpr (NORM) {
             if (hs >= NH - 1 - NP && hs <= NH - 2) store_row_norm((c + 1) & 1, hs - (NH - 1 - NP), nmu, nrs);
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
           if (live) mfma_half(half, wr[st % RT]);
           {
             constexpr int nds = 2 * TM;
-            const int nvm = 2 * TN + (hs == 0 ? NP : 0);
+            const int nvm = (RT == 2 ? (half == 0 ? 4 * TN : 0) : 2 * TN) + (hs == 0 ? NP : 0);
             const int ndw = NORM ? ((hs >= NH - 1 - NP && hs <= NH - 2) ? 2 : 0) : ((hs == NH - 2) ? NP : 0);
 #pragma unroll
             for (int k = 0; k < NMF; ++k) {
