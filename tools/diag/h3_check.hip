@@ -11,7 +11,8 @@ __global__ void rt_kernel(const float* v, float* out_hi, float* out_lo, unsigned
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   f16x8 hi; u32x2 b;
-  h3_encode(v + 8 * i, hi, b);
+  bool clamped = false;
+  h3_encode(v + 8 * i, hi, b, clamped);
   const f16x8 lo = h3_decode_lo(hi, b);
   for (int k = 0; k < 8; ++k) { out_hi[8 * i + k] = (float)hi[k]; out_lo[8 * i + k] = (float)lo[k]; }
   out_b[2 * i] = b[0]; out_b[2 * i + 1] = b[1];
@@ -39,6 +40,19 @@ int main() {
     }
   }
   printf("hi-only err / group max %.3e ; hi+lo err / group max %.3e\n", worst_hi, worst);
+  // the decode against its definition, bit for bit: lo = f16((byte - 128) * 2^(E - 33)), E = f16 exponent (>= 1) of the group's largest hi
+  long bad = 0;
+  for (int i = 0; i < n8; ++i) {
+    float mx = 0; for (int k = 0; k < 8; ++k) mx = fmaxf(mx, hi[8 * i + k]);
+    int e = 0; (void)frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1): f16 exponent field = e + 14
+    const int E = mx > 0.f ? (e + 14 < 1 ? 1 : e + 14) : 1;
+    for (int k = 0; k < 8; ++k) {
+      const int byte = (bb[2 * i + (k >> 2)] >> (8 * (k & 3))) & 255;
+      const float ref = (float)(_Float16)ldexpf((float)(byte - 128), E - 33);
+      if (ref != lo[8 * i + k]) ++bad;
+    }
+  }
+  printf("decode vs definition: %ld mismatches of %d\n", bad, 8 * n8);
   for (int i = 0; i < 2; ++i) { printf("group %d:", i); for (int k = 0; k < 8; ++k) printf(" v %.6g hi %.6g lo %.3g |", v[8*i+k], hi[8*i+k], lo[8*i+k]); printf(" bytes %08x %08x\n", bb[2*i], bb[2*i+1]); }
   return 0;
 }
