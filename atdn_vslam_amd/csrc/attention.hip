@@ -41,25 +41,39 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // (values past the f16 range — a full-precision logit more than ~4.16 above the first pass's f16 x f16 row maximum — are
 // clamped to 65504 and flagged: the caller reports them through the sf saturation counter, sf_report)
-__device__ __forceinline__ void h3_encode(const float* v, f16x8& hi, u32x2& bytes, bool& clamped) {
+// Round 4: the encode is the vector-instruction bulk of the softmax kernel (6.4 vector instructions per MFMA on the SQ counters),
+// so it is written for instruction count: `gsum` = the sum of the group's eight values (the caller needs it for the row sum
+// anyway) bounds every one of them and carries a NaN, so ONE test per group replaces eight and the clamp moves to a cold path;
+// the group maximum is two v_max3 levels; the residual byte is v_cvt_pk_u8_f32(fma(v - hi, 2^(33 - E), 128)) — that conversion
+// rounds to nearest even and saturates to [0, 255] (tools/diag/cvt_u8_check.hip), which is what rint, min(., 127) and "+ 128"
+// spelt out before (a tie rounds the same way; a quotient of +128 still stores 127).
+__device__ __forceinline__ void h3_encode(const float* v_in, float gsum, f16x8& hi, u32x2& bytes, bool& clamped) {
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = v_in[i];
+  if (__builtin_expect(!(gsum <= 65504.f), 0)) {   // rare: some value may be past the f16 range (or a NaN)
+    asm volatile("; h3_encode: saturated group");   // (keeps this a branch: if-converted, its 8 tests and 8 clamps run for every group)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      clamped |= !(v[i] <= 65504.f);
+      v[i] = fminf(v[i], 65504.f);
+    }
+  }
   float hf[8];
-  float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    clamped |= !(v[i] <= 65504.f);
-    hi[i] = (_Float16)fminf(v[i], 65504.f);
+    hi[i] = (_Float16)v[i];
     hf[i] = (float)hi[i];
-    mx = fmaxf(mx, hf[i]);
   }
+  const float mx = fmaxf(fmaxf(fmaxf(hf[0], hf[1]), fmaxf(hf[2], hf[3])), fmaxf(fmaxf(hf[4], hf[5]), fmaxf(hf[6], hf[7])));
   // exponent field of the float = f16 exponent + 112; f16 subnormals (and zero) count as E = 1
   const unsigned ef = max(__float_as_uint(mx) >> 23, 113u);
   const float inv_unit = __uint_as_float((272u - ef) << 23);   // 2^(33 - E)
   unsigned w0 = 0, w1 = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    // |v - hi| <= ulp(hi) / 2 <= ulp(group) / 2: the quotient lies in [-128, 128]; +128 (a tie rounded down) is
-    // stored as 127, one unit = 2^-9 ulp off
-    const float q = fminf(rintf((fminf(v[i], 65504.f) - hf[i]) * inv_unit), 127.f) + 128.f;
+    // |v - hi| <= ulp(hi) / 2 <= ulp(group) / 2: the quotient lies in [-128, 128]
+    const float q = __builtin_fmaf(v[i] - hf[i], inv_unit, 128.f);
     if (i < 4) w0 = __builtin_amdgcn_cvt_pk_u8_f32(q, i, w0); else w1 = __builtin_amdgcn_cvt_pk_u8_f32(q, i - 4, w1);
   }
   bytes[0] = w0;
@@ -235,14 +249,16 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
             const bool ok = m_ok[rb] && (key0 + (i & 3) + 16 * (i >> 2) < g.N);
             const float x = __builtin_amdgcn_exp2f(fmaf(acc[2 * cq + (i >> 2)][rb][i & 3], LOG2E, c0[rb]));
             v[i] = ok ? x : 0.f;
-            run[rb] += v[i];
           }
+          // the group's sum: its share of the row sum, and the bound h3_encode tests the group's range with
+          const float gsum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          run[rb] += gsum;
           const int q = 2 * j + cq;
           if (strip_ok && q < g.Q) {
             char* d = pdst + (long)q * BLK;
             f16x8 hi;
             u32x2 bytes;
-            h3_encode(v, hi, bytes, clamped);
+            h3_encode(v, gsum, hi, bytes, clamped);
             st_frag_nt(d + rb * 1024 + lane * 16, hi);
             bytes2[rb] = bytes;
           }

@@ -12,7 +12,9 @@ __global__ void rt_kernel(const float* v, float* out_hi, float* out_lo, unsigned
   if (i >= n8) return;
   f16x8 hi; u32x2 b;
   bool clamped = false;
-  h3_encode(v + 8 * i, hi, b, clamped);
+  float gs = 0.f;
+  for (int k = 0; k < 8; ++k) gs += v[8 * i + k];
+  h3_encode(v + 8 * i, gs, hi, b, clamped);
   const f16x8 lo = h3_decode_lo(hi, b);
   for (int k = 0; k < 8; ++k) { out_hi[8 * i + k] = (float)hi[k]; out_lo[8 * i + k] = (float)lo[k]; }
   out_b[2 * i] = b[0]; out_b[2 * i + 1] = b[1];
