@@ -14,6 +14,8 @@
 //       deleted in round 3 after their A/B tests; measurements in DESIGN.md 3.6.)
 #include "attention.h"
 
+#include <type_traits>
+
 #include "conv_mfma.h"
 #include "sf.h"
 
@@ -141,11 +143,9 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   // query fragments (the column operand), resident for the whole sweep: [row block][channel chunk]
   f16x8 qh[2][4], ql[2][4];
   int mrow[2];
-  bool m_ok[2];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     mrow[rb] = strip * 32 + 16 * rb + n16;
-    m_ok[rb] = strip_ok && mrow[rb] < g.N;
     const char* qrow = qkb + (long)min(mrow[rb], g.N - 1) * 1024 + 16 * g16;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -232,43 +232,54 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
     // barrier since; the tile after that is requested now and lands during the epilogue and the next MFMA block
     stash((j + 1) & 1);
     fetch(min(j + 2, NHT - 1));
+    // Only the LAST tile of a sweep can hold keys past N: every other tile takes the body without the per-value key test (a
+    // compare and a select per value in the kernel's vector-instruction-bound epilogue). Rows past N (the padding rows of the
+    // last strip: copies of row N - 1, never read back — rinv is 0 for them and the consumer drops them) are not masked at all.
+    auto epilogue = [&](auto tail_tag) __attribute__((always_inline)) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
-    for (int cq = 0; cq < 2; ++cq) {        // the two 32-key chunks of the tile
-      const int key0 = j * KT + 32 * cq + 4 * g16;
-      u32x2 bytes2[2] = {{0u, 0u}, {0u, 0u}};   // residual bytes of both row blocks: one 16-byte store (and one load in the consumer)
+      for (int cq = 0; cq < 2; ++cq) {        // the two 32-key chunks of the tile
+        const int key0 = j * KT + 32 * cq + 4 * g16;
+        u32x2 bytes2[2] = {{0u, 0u}, {0u, 0u}};   // residual bytes of both row blocks: one 16-byte store (and one load in the consumer)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        if (STATS) {
+        for (int rb = 0; rb < 2; ++rb) {
+          if (STATS) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (key0 + (i & 3) + 16 * (i >> 2) < g.N) run[rb] = fmaxf(run[rb], acc[2 * cq + (i >> 2)][rb][i & 3]);
-        } else {
-          float v[8];
+            for (int i = 0; i < 8; ++i)
+              if (!TAIL || key0 + (i & 3) + 16 * (i >> 2) < g.N) run[rb] = fmaxf(run[rb], acc[2 * cq + (i >> 2)][rb][i & 3]);
+          } else {
+            float v[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const bool ok = m_ok[rb] && (key0 + (i & 3) + 16 * (i >> 2) < g.N);
-            const float x = __builtin_amdgcn_exp2f(fmaf(acc[2 * cq + (i >> 2)][rb][i & 3], LOG2E, c0[rb]));
-            v[i] = ok ? x : 0.f;
-          }
-          // the group's sum: its share of the row sum, and the bound h3_encode tests the group's range with
-          const float gsum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-          run[rb] += gsum;
-          const int q = 2 * j + cq;
-          if (strip_ok && q < g.Q) {
-            char* d = pdst + (long)q * BLK;
-            f16x8 hi;
-            u32x2 bytes;
-            h3_encode(v, gsum, hi, bytes, clamped);
-            st_frag_nt(d + rb * 1024 + lane * 16, hi);
-            bytes2[rb] = bytes;
+            for (int i = 0; i < 8; ++i) {
+              const float x = __builtin_amdgcn_exp2f(fmaf(acc[2 * cq + (i >> 2)][rb][i & 3], LOG2E, c0[rb]));
+              v[i] = (!TAIL || key0 + (i & 3) + 16 * (i >> 2) < g.N) ? x : 0.f;
+            }
+            // the group's sum: its share of the row sum, and the bound h3_encode tests the group's range with
+            const float gsum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            run[rb] += gsum;
+            const int q = 2 * j + cq;
+            if (strip_ok && q < g.Q) {
+              char* d = pdst + (long)q * BLK;
+              f16x8 hi;
+              u32x2 bytes;
+              h3_encode(v, gsum, hi, bytes, clamped);
+              st_frag_nt(d + rb * 1024 + lane * 16, hi);
+              bytes2[rb] = bytes;
+            }
           }
         }
+        if (!STATS && strip_ok && 2 * j + cq < g.Q) {
+          typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+          const u32x4s bb = {bytes2[0][0], bytes2[0][1], bytes2[1][0], bytes2[1][1]};
+          __builtin_nontemporal_store(bb, reinterpret_cast<u32x4s*>(pdst + (long)(2 * j + cq) * BLK + 2048 + lane * 16));
+        }
       }
-      if (!STATS && strip_ok && 2 * j + cq < g.Q) {
-        typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
-        const u32x4s bb = {bytes2[0][0], bytes2[0][1], bytes2[1][0], bytes2[1][1]};
-        __builtin_nontemporal_store(bb, reinterpret_cast<u32x4s*>(pdst + (long)(2 * j + cq) * BLK + 2048 + lane * 16));
-      }
+    };
+    if ((j + 1) * KT > g.N) {
+      asm volatile("; qk_softmax: tail tile");   // (a real branch: if-converted, the tail's tests would run for every tile)
+      epilogue(std::true_type{});
+    } else {
+      epilogue(std::false_type{});
     }
     __syncthreads();
   }
