@@ -1,6 +1,6 @@
 """Builds libatdn_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m atdn_vslam_amd.build [--force] [--microbench] [--variant NAME -DMACRO[=V] ...]
+    python -m atdn_vslam_amd.build [--force] [--microbench] [--variant NAME -DMACRO[=V] -Xhipcc-flag ...]
 
 --microbench also builds the diagnostic micro-benchmark library (tools/microbench/, ablation builds of the kernels): it is
 not part of the product and a break in it must not fail the product build, so it is only built on request
@@ -22,7 +22,11 @@ LIB = os.path.join(HERE, "libatdn_hip.so")
 MB_SRC = os.path.join(os.path.dirname(HERE), "tools", "microbench", "microbench.hip")
 MB_LIB = os.path.join(HERE, "libatdn_microbench.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 operations into v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32. In the
+# epilogues that run beside other waves' MFMAs those are no faster than the scalar forms (MI355X_MICROARCH.md, constants table),
+# and the register-pair shuffles they need are extra instructions in loops bound by instruction issue. Whole forward, same job:
+# 41.67 -> 41.35 ms per 16 pairs (cnet -3 %, motion encoder -2 %, lookup -3 %, flow head -1.5 %; q gate +0.7 %, softmax +1 %).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _sources():
@@ -44,7 +48,8 @@ def _compile(src, objdir=OBJ, defines=()):
     newest = max([_mtime(os.path.join(CSRC, src))] + [_mtime(h) for h in _headers()])
     if _mtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = ([HIPCC] + FLAGS + [d[5:] if d.startswith("FLAG:") else "-D" + d for d in defines] +
+           ["-c", os.path.join(CSRC, src), "-o", obj])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stdout))
@@ -97,5 +102,6 @@ def build_microbench():
 
 if __name__ == "__main__":
     _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
-    _defs = [a[2:] for a in sys.argv if a.startswith("-D")]
+    # -DMACRO[=V] defines; -Xflag passes `flag` to hipcc as it is (variant builds only: e.g. -X-fno-slp-vectorize)
+    _defs = [a[2:] for a in sys.argv if a.startswith("-D")] + ["FLAG:" + a[2:] for a in sys.argv if a.startswith("-X")]
     print(build(force="--force" in sys.argv, microbench="--microbench" in sys.argv, variant=_variant, defines=_defs))
