@@ -364,72 +364,87 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
               make_float4(a.b[hh][cb][0] * g.wscale, a.b[hh][cb][1] * g.wscale, a.b[hh][cb][2] * g.wscale, a.b[hh][cb][3] * g.wscale);
     };
     if constexpr (epi_flowhead<Epi>::value) {
-      // ---- flow head: relu(conv1) x conv2's weights, reduced to 18 partial sums per pixel (epilogues_sf.h).
-      // Per (row tile, q) a lane holds 4 channels of one pixel: 9 packed FMAs x 4 give its share of the 9 taps x 2 outputs,
-      // three DPP adds per value (half-row mirror, quad swaps: no LDS, no selects — the first version's ds_bpermute
-      // reduce-scatter cost 21 us per launch) sum the pixel's 8 lanes, the lane at channel 0 writes the 18 sums into
-      // the wave's own (already consumed) transpose slab, and after a barrier the block adds the 8 waves in fixed order.
+      // ---- flow head: relu(conv1) x conv2's weights, reduced to 18 partial sums per pixel (epilogues_sf.h), then the block adds
+      // its 8 waves in fixed order. (Rounds 2-4 did the products on the vector pipe — 36 packed FMAs and 54 DPP adds per group of 8
+      // pixels, ~1,600 vector instructions per wave — and the epilogue was a quarter of the kernel: 2.56 -> 2.28 ms per forward.)
       static_assert(!epi_flowhead<Epi>::value || (WM == 1 && TN == 1 && TW == 16), "one block holds all output channels of its pixels");
-      typedef float v2f __attribute__((ext_vector_type(2)));
       constexpr int RP = 20;                                    // floats per pixel row of the exchange (16-byte aligned rows)
       static_assert(32 * RP <= 32 * LDS_LD, "the exchange rows live inside the wave's slab");
-      const int cl = n0 + wn * 32 + tcol;                       // this lane's 4 channels
-      const float4 bj = ep.bias4(min(cl, g.N - 4));
-      v2f w2r[9][4];                                            // [tap][channel] x (output 0, output 1)
+      // conv2's 18 partial sums on the matrix engine: [18 -> 32 rows of conv2's weights] x [the wave's 32 channels] x [32 pixels]
+      // = two row blocks x two pixel blocks of v_mfma_f32_16x16x32_f16 (K = the wave's 32 channels), three products each.
+      // Lane (n, g) of the pixel operand holds relu(conv1 + bias) of pixel 16 pb + n, channels 8 g .. 8 g + 7, read from the
+      // transpose slab as two 16-byte pieces; the weight operand (row u = 16 rbk + n, the same 8 channels) lives in registers.
+      {
+        const int n16 = lane & 15, g16 = lane >> 4;
+        const int c8 = n0 + wn * 32 + 8 * g16;
+        const float4 bq0 = *reinterpret_cast<const float4*>(ep.bias + c8), bq1 = *reinterpret_cast<const float4*>(ep.bias + c8 + 4);
+        const float b8[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
+        f16x8 w2h[2], w2l[2];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float4 o0 = *reinterpret_cast<const float4*>(ep.w2 + (long)(2 * t) * g.N + min(cl, g.N - 4));
-        const float4 o1 = *reinterpret_cast<const float4*>(ep.w2 + (long)(2 * t + 1) * g.N + min(cl, g.N - 4));
-        w2r[t][0] = v2f{o0.x, o1.x}; w2r[t][1] = v2f{o0.y, o1.y}; w2r[t][2] = v2f{o0.z, o1.z}; w2r[t][3] = v2f{o0.w, o1.w};
-      }
-      auto dpp_sum8 = [](float v) __attribute__((always_inline)) {
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror: l <-> 7 - l
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-        return v;
-      };
+        for (int rbk = 0; rbk < 2; ++rbk) {
+          const int u = 16 * rbk + n16;
+          const float* wr = ep.w2 + (long)min(u, 17) * g.N + c8;
+          const float4 wa = *reinterpret_cast<const float4*>(wr), wb = *reinterpret_cast<const float4*>(wr + 4);
+          const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {   // (unrolled: a run-time index into the accumulators would put them in scratch)
-        slab_write(acc[i][0]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        float4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(tb + (8 * q + trow) * LDS_LD + tcol);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();   // the slab is consumed: its rows now carry the partial sums
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const v2f x0 = v2f{fmaxf(v[q].x + bj.x, 0.f), fmaxf(v[q].x + bj.x, 0.f)}, x1 = v2f{fmaxf(v[q].y + bj.y, 0.f), fmaxf(v[q].y + bj.y, 0.f)};
-          const v2f x2 = v2f{fmaxf(v[q].z + bj.z, 0.f), fmaxf(v[q].z + bj.z, 0.f)}, x3 = v2f{fmaxf(v[q].w + bj.w, 0.f), fmaxf(v[q].w + bj.w, 0.f)};
-          float a18[20];
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            const v2f a = ((x0 * w2r[t][0] + x1 * w2r[t][1]) + x2 * w2r[t][2]) + x3 * w2r[t][3];
-            a18[2 * t] = dpp_sum8(a.x);
-            a18[2 * t + 1] = dpp_sum8(a.y);
-          }
-          a18[18] = 0.f; a18[19] = 0.f;
-          if ((lane & 7) == 0) {
-            float* rp = tb + (8 * q + trow) * RP;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) *reinterpret_cast<float4*>(rp + 4 * k) = make_float4(a18[4 * k], a18[4 * k + 1], a18[4 * k + 2], a18[4 * k + 3]);
+          for (int e = 0; e < 8; ++e) {
+            const float w = u < 18 ? w8[e] * ep.w2mul : 0.f;
+            w2h[rbk][e] = (_Float16)w;
+            w2l[rbk][e] = (_Float16)(w - (float)w2h[rbk][e]);
           }
         }
-        __syncthreads();   // every wave's partial sums of row tile i are in LDS
-        for (int idx = tid; idx < 32 * 18; idx += NT) {
-          const int px = idx / 18, u = idx - px * 18;
-          const float* rq = reinterpret_cast<const float*>(Pbytes) + px * RP + u;
-          float sum = 0.f;
+        bool sat = false;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) sum += rq[w * (32 * LDS_LD)];   // fixed order: deterministic
-          const int p = i * 32 + px;
-          const int oy = ty0 + p / TW, ox = tx0 + p % TW;
-          if (oy < g.Ho && ox < g.Wo) ep.G[((long)img * ep.npix + (long)oy * g.Wo + ox) * 18 + u] = sum;
+        for (int i = 0; i < TM; ++i) {
+          slab_write(acc[i][0]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          f16x8 xh[2], xl[2];
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const float* src = tb + (16 * pb + n16) * LDS_LD + 8 * g16;
+            const float4 xa = *reinterpret_cast<const float4*>(src), xb = *reinterpret_cast<const float4*>(src + 4);
+            const float x8[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const SfPair sp = sf_split_flag(fmaxf(x8[e] + b8[e], 0.f), sat);
+              xh[pb][e] = sp.hi; xl[pb][e] = sp.lo;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();   // the slab is consumed: its rows now carry the partial sums
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            f32x4v d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!FAST) {
+              d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[0], xl[pb], d0, 0, 0, 0);
+              d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[0], xh[pb], d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[1], xl[pb], d1, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[1], xh[pb], d1, 0, 0, 0);
+            }
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[0], xh[pb], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[1], xh[pb], d1, 0, 0, 0);
+            // lane (n, g): sums u = 4 g + e (d0) and 16 + 4 g + e (d1: only u = 16, 17 exist) of pixel 16 pb + n
+            float* rp = tb + (16 * pb + n16) * RP;
+            *reinterpret_cast<float4*>(rp + 4 * g16) = make_float4(d0[0] * ep.w2inv, d0[1] * ep.w2inv, d0[2] * ep.w2inv, d0[3] * ep.w2inv);
+            if (g16 == 0) *reinterpret_cast<float2*>(rp + 16) = make_float2(d1[0] * ep.w2inv, d1[1] * ep.w2inv);
+          }
+          __syncthreads();   // every wave's partial sums of row tile i are in LDS
+          for (int idx = tid; idx < 32 * 18; idx += NT) {
+            const int px = idx / 18, u = idx - px * 18;
+            const float* rq = reinterpret_cast<const float*>(Pbytes) + px * RP + u;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += rq[w * (32 * LDS_LD)];   // fixed order: deterministic
+            const int p = i * 32 + px;
+            const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+            if (oy < g.Ho && ox < g.Wo) ep.G[((long)img * ep.npix + (long)oy * g.Wo + ox) * 18 + u] = sum;
+          }
+          __syncthreads();   // the slabs are rewritten by the next row tile
         }
-        __syncthreads();   // the slabs are rewritten by the next row tile
+        sf_report(sat);
+        return;
       }
-      return;
     }
     // Epilogues with operand loads (GRU gates, residual adds) are software-pipelined over the wave's tiles: the
     // operands of tile t + 1 are requested BEFORE the stores of tile t are issued. vmcnt retires in order, so a load

@@ -208,11 +208,12 @@ struct SfFlowDelta {
 };
 
 // Flow head, both convolutions in one pass over the hidden state (update.py:8-16: conv2(relu(conv1(h)))). conv1's
-// 256-channel output of a pixel never leaves the block: every lane multiplies the 4 channels it holds with conv2's
-// weights for the 9 taps x 2 outputs, the 18 partial sums are reduced over the pixel's lanes and the block's waves
-// (conv_sf6.h, the kFlowHead branch of the channel-vector epilogue) and written as G[pixel][tap * 2 + output]; a gather
-// over each pixel's 3 x 3 neighbourhood (small_convs.hip: flow_gather_kernel) finishes conv2 and applies the flow
-// update. Saves the 58 MB round trip of conv1's output per iteration (8 pairs) and the separate conv2 kernel.
+// 256-channel output of a pixel never leaves the block: every wave multiplies relu(conv1 + bias) of its 32 channels with
+// conv2's weights for the 9 taps x 2 outputs on the matrix engine (conv_sf6.h, the kFlowHead branch of the channel-vector
+// epilogue: split-f16 products, conv2's weights pre-scaled by the power of two `w2mul`), the block adds its waves' 18 partial
+// sums per pixel in fixed order and writes G[pixel][tap * 2 + output]; a gather over each pixel's 3 x 3 neighbourhood
+// (small_convs.hip: flow_gather_kernel) finishes conv2 and applies the flow update. Saves the 58 MB round trip of conv1's
+// output per iteration (8 pairs) and the separate conv2 kernel.
 struct SfFlowHeadPartial {
   static constexpr bool kStats = false;
   static constexpr bool kPrefetch = false;
@@ -222,6 +223,7 @@ struct SfFlowHeadPartial {
   const float* bias;   // conv1 bias [256]
   const float* w2;     // conv2 weights, fp32 [18][256]: row tap * 2 + output
   float* G; long npix; // [img][pix][18]
+  float w2mul, w2inv;  // power-of-two scale of conv2's weights for the split-f16 product (max |w| in [1, 2)) and its inverse
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
   __device__ __forceinline__ void store4(int, int, int, float4, float4, bool&) const {}
   __device__ __forceinline__ void operator()(int, int, int, float) const {}

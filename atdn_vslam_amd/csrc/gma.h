@@ -88,6 +88,7 @@ class GmaNet {
   PackedConv convc1_, convc2_, convf1_, convf2_, convm_, to_v_, to_qk_;
   long convf1_sf_off_ = -1;  // convf1 weights in split-f16 fragment order for small_convs.hip (flow_conv7_sf_kernel)
   float convf1_wscale_ = 1.f;
+  float fh2_mul_ = 1.f;      // power-of-two scale of the flow head's conv2 weights (split-f16 product in conv1's epilogue)
   long fh2_w32_off_ = -1;    // flow head conv2 weights as fp32 [tap*2 + output][256] for the fused flow head
   DeviceBuf fhG_;            // conv2 partial sums [maxB * N][18]
   PackedConv gru_zr_[2], gru_q_[2], fh1_, fh2_, mask0_, mask2_;

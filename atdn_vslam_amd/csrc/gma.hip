@@ -229,6 +229,11 @@ void GmaNet::finalize() {
     for (int o = 0; o < 2; ++o)
       for (int c = 0; c < 256; ++c)
         for (int t = 0; t < 9; ++t) arena_.at(fh2_w32_off_)[(t * 2 + o) * 256 + c] = w.data[((long)o * 256 + c) * 9 + t];
+    float mx = 0.f;
+    for (float v : w.data) mx = std::max(mx, std::fabs(v));
+    int e = 0;
+    if (mx > 0.f) (void)std::frexp(mx, &e);
+    fh2_mul_ = std::ldexp(1.0f, 1 - e);
   }
   mask0_ = tap({u + "mask.0"});
   mask2_ = tap({u + "mask.2"});
@@ -593,7 +598,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   const SfFlowDelta fd{fh2_.b, coords1_.p, flow4_.p, x_.p, XLD, (long)N * XLD, 254, W8, (long)N};
   // conv1 with conv2's partial sums in its epilogue, then the 3 x 3 gather (small_convs.h)
-  launch_flow_head_fused(s, fh1_.wscale, SfFlowHeadPartial{fh1_.b, arena_.dev(fh2_w32_off_), fhG_.p, (long)N}, st);
+  launch_flow_head_fused(s, fh1_.wscale, SfFlowHeadPartial{fh1_.b, arena_.dev(fh2_w32_off_), fhG_.p, (long)N, fh2_mul_, 1.0f / fh2_mul_}, st);
   launch_flow_gather(fhG_.p, B, H8, W8, fd, st);
   mark(ST_FLOWHEAD, st);
 }
