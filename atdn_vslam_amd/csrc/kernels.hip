@@ -316,7 +316,9 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   for (int k = 0; k < 9; ++k) { e[k] = mk[k * 64]; mx = fmaxf(mx, e[k]); }
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { e[k] = expf(e[k] - mx); s += e[k]; }
+  // (v_exp_f32 and ONE division per output pixel: the libm expf and nine IEEE divisions were ~225 vector instructions per lane)
+  for (int k = 0; k < 9; ++k) { e[k] = __builtin_amdgcn_exp2f((e[k] - mx) * 1.4426950408889634f); s += e[k]; }
+  const float rs = 1.0f / s;
   float ux = 0.f, uy = 0.f;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
       const float4 f = reinterpret_cast<const float4*>(flow4)[img * N + (long)yy * W8 + xx];
       fx = 8.f * f.x; fy = 8.f * f.y;
     }
-    const float wk = e[k] / s;
+    const float wk = e[k] * rs;
     ux += wk * fx;
     uy += wk * fy;
   }
