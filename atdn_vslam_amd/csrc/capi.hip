@@ -313,6 +313,93 @@ int atdn_corr_pyramid(const float* fmap1, const float* fmap2, int B, int H8, int
   ATDN_API_END
 }
 
+// The PRODUCT kernels of the default (split-f16) path on caller-supplied features — corr_bricks_kernel for the four levels
+// (levels 1-3 from 2x2-pooled target features), the brick-major pyramid, lookup_conv_kernel in both instantiations — so that the
+// reference's own CorrBlock probe set reaches the kernels the benchmark times. Scratch is allocated per call:
+// a unit-test entry, not a hot path.
+int atdn_corr_lookup_bricks(const float* fmap1, const float* fmap2, int B, int H8, int W8, int C, const float* coords,
+                            float* pyr0, float* pyr1, float* pyr2, float* pyr3, float* samples,
+                            const float* convc1_weight_host, const float* convc1_bias_host, float* cor1, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(fmap1 && fmap2 && B >= 1 && H8 >= 1 && W8 >= 1, "bad argument");
+  ATDN_CHECK(C == 256, "the correlation kernel keeps a source strip's whole K = 256 in registers: C must be 256");
+  ATDN_CHECK((H8 >> 3) >= 2 && (W8 >> 3) >= 2, "map too small for four pyramid levels");
+  ATDN_CHECK(!(samples || cor1) || coords, "a lookup needs coordinates");
+  ATDN_CHECK(!cor1 || (convc1_weight_host && convc1_bias_host), "cor1 needs convc1's weight [256][324] and bias [256]");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = H8 * W8;
+  const long n8 = (long)B * N;
+  BrickPyramid bp;
+  bp.N = N; bp.NPB = brick_pixel_blocks(N);
+  DeviceBuf f1, f2, plain[3], fbrick[4], pyr[4], scratch, outsf;
+  DeviceBuf* all[] = {&f1, &f2, &plain[0], &plain[1], &plain[2], &fbrick[0], &fbrick[1], &fbrick[2], &fbrick[3],
+                      &pyr[0], &pyr[1], &pyr[2], &pyr[3], &scratch, &outsf};
+  WeightArena A;
+  try {
+    sf_counter_attach();
+    f1.alloc(n8 * 256); f2.alloc(n8 * 256);
+    launch_to_sf(fmap1, f1.p, n8, 256, st);
+    launch_to_sf(fmap2, f2.p, n8, 256, st);
+    float* rowmajor[4] = {pyr0, pyr1, pyr2, pyr3};
+    int pH[4], pW[4];
+    for (int l = 0; l < 4; ++l) {   // the same sequence as GmaNet::run_body_sf
+      pH[l] = H8 >> l; pW[l] = W8 >> l;
+      bp.H[l] = pH[l]; bp.W[l] = pW[l]; bp.BW[l] = cdiv(pW[l], 8); bp.BH[l] = cdiv(pH[l], 4); bp.NB[l] = bp.BW[l] * bp.BH[l] * 32;
+      const float* src = f2.p;
+      long src_sb = (long)N * 256;
+      if (l > 0) {
+        const float* prev = l == 1 ? f2.p : plain[l - 2].p;
+        const long prev_sb = l == 1 ? (long)N * 256 : (long)pH[l - 1] * pW[l - 1] * 256;
+        src_sb = (long)pH[l] * pW[l] * 256;
+        plain[l - 1].alloc((long)B * src_sb);
+        launch_pool_features_sf(prev, B, pH[l - 1], pW[l - 1], 256, prev_sb, plain[l - 1].p, src_sb, st);
+        src = plain[l - 1].p;
+      }
+      fbrick[l].alloc((long)B * bp.NB[l] * 256);
+      launch_brick_rows(src, src_sb, B, pH[l], pW[l], 256, fbrick[l].p, (long)bp.NB[l] * 256, st);
+      pyr[l].alloc((long)B * bp.NPB * kBrickPixelBlock * bp.NB[l]);
+      launch_corr_bricks(f1.p, (long)N * 256, fbrick[l].p, (long)bp.NB[l] * 256, B, N, bp.NB[l], 1.0f / sqrtf(256.0f), pyr[l].p, false, st);
+      bp.base[l] = pyr[l].p;
+      if (rowmajor[l]) launch_unbrick(pyr[l].p, bp.NB[l], N, pH[l], pW[l], n8, rowmajor[l], st);
+    }
+    if (samples) {   // lookup_conv_kernel<FUSED = false>: the sampling code of the fused kernel, samples to memory
+      outsf.alloc(n8 * 352);
+      launch_lookup_bricks(bp, coords, n8, outsf.p, st);
+      scratch.alloc(n8 * 352);
+      launch_from_sf(outsf.p, scratch.p, n8, 352, st);
+      ATDN_HIP(hipMemcpy2DAsync(samples, 324 * sizeof(float), scratch.p, 352 * sizeof(float), 324 * sizeof(float), (size_t)n8,
+                                hipMemcpyDeviceToDevice, st));
+    }
+    if (cor1) {      // lookup_conv_kernel<FUSED = true>: what GmaNet::iteration_sf launches
+      StateDict sd;
+      const int64_t ws[4] = {256, 324, 1, 1}, bs[1] = {256};
+      sd.put("c.weight", convc1_weight_host, ws, 4);
+      sd.put("c.bias", convc1_bias_host, bs, 1);
+      PackedConv L = pack_conv_sf(A, sd, {"c"});
+      pack_fragment_major16(A, L);
+      A.upload();
+      resolve(A, L);
+      DeviceBuf csf;
+      csf.alloc(n8 * 256);
+      try {
+        launch_lookup_conv(bp, coords, n8, nullptr, L.wf16, L.wscale, L.b, csf.p, false, st);
+        launch_from_sf(csf.p, cor1, n8, 256, st);
+        ATDN_HIP(hipStreamSynchronize(st));
+      } catch (...) { csf.release(); throw; }
+      csf.release();
+    }
+    ATDN_HIP(hipStreamSynchronize(st));
+  } catch (...) {
+    (void)hipDeviceSynchronize();
+    for (auto* b : all) b->release();
+    A.release();
+    throw;
+  }
+  for (auto* b : all) b->release();
+  A.release();
+  ATDN_API_END
+}
+
 int atdn_conv2d_nhwc(const float* src, int nimg, int H, int W, int Cin, const float* weight_host,
                      const float* bias_host, int Cout, int KH, int KW, int stride, int padH, int padW, int relu,
                      float* dst, void* stream) {

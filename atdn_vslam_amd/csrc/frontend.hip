@@ -162,8 +162,12 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const T* __restrict__ 
   if (x < Wout) {
     const ResizeTable* t = tx + x;
     start = t->start - smin; count = t->count;
-    const float4 wa = *reinterpret_cast<const float4*>(t->w), wb = *reinterpret_cast<const float4*>(t->w + 4);
-    w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w; w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
+    // (a table entry is 40 bytes with the weights at offset 8: 8-byte aligned, so four float2 loads, not two float4)
+#pragma unroll
+    for (int k = 0; k < RESIZE_TAPS; k += 2) {
+      const float2 wk = *reinterpret_cast<const float2*>(t->w + k);
+      w[k] = wk.x; w[k + 1] = wk.y;
+    }
   }
   __syncthreads();
   if (x >= Wout) return;
@@ -180,7 +184,8 @@ template <class T>
 void launch_resize(const T* src, int planes, int Hin, int Win, int Hout, int Wout, int antialias, float* dst,
                    hipStream_t st) {
   const ResizePlanRef p = resize_plan(Hin, Win, Hout, Wout, antialias);
-  static_assert(sizeof(ResizeTable) == 8 + 4 * RESIZE_TAPS && RESIZE_TAPS == 8, "the row kernel reads the weights as two float4");
+  static_assert(sizeof(ResizeTable) == 8 + 4 * RESIZE_TAPS && RESIZE_TAPS % 2 == 0 && alignof(ResizeTable) >= 4 &&
+                sizeof(ResizeTable) % 8 == 0, "the row kernel reads the weights as float2 pairs at offset 8 of 40-byte entries");
   if (Hin == Hout && (long)Win * 4 <= (long)Wout * 5 && planes <= 65535) {
     hipLaunchKernelGGL((resize_rows_kernel<T>), dim3((unsigned)cdiv(Wout, 256), (unsigned)cdiv(Hout, RZ_ROWS), (unsigned)planes), dim3(256),
                        0, st, src, p.tx, Hin, Win, Wout, dst);

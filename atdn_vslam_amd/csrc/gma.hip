@@ -784,6 +784,7 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
   else if (k == "x") b = &x_; else if (k == "attn") b = &attn_; else if (k == "corrfeat") b = &corrfeat_;
   else if (k == "mask") b = &mask_; else if (k == "coords1") b = &coords1_; else if (k == "flow4") b = &flow4_;
   else if (k == "qk") b = &qk_; else if (k == "img4") b = &img4_;
+  else if (k == "cor1") b = &cor1_;   // relu(convc1(lookup)) of the last iteration: the fused kernel's product phase
   if (!b) return -1;
   long n = std::min(capacity, b->n);
   if (k == "attn" && !classic_) {   // fragment-major exp(s - max) + row sums -> normalised fp32 rows [maxB][N][ldN]
@@ -796,7 +797,7 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
     ATDN_HIP(hipMemcpy(host, scratch_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return n;
   }
-  const bool is_sf = precision >= 1 && (k == "fmap" || k == "net" || k == "x" || k == "attn" || k == "corrfeat" || k == "qk");
+  const bool is_sf = precision >= 1 && (k == "fmap" || k == "net" || k == "x" || k == "attn" || k == "corrfeat" || k == "qk" || k == "cor1");
   const float* src = b->p;
   if (is_sf) {  // decode the split-f16 tensor into a scratch fp32 copy first
     if (scratch_.n < b->n) { scratch_.release(); scratch_.alloc(b->n); }

@@ -579,8 +579,10 @@ unsigned int* sf_counter_for_current_device(bool create) {
   for (auto& c : g_sf_counters) if (c.dev == dev) return c.ptr;
   if (!create) return nullptr;
   unsigned int* p = nullptr;
-  ATDN_HIP(hipMalloc(&p, sizeof(unsigned int)));
-  ATDN_HIP(hipMemset(p, 0, sizeof(unsigned int)));
+  // p[0] = the counter, p[1] = the result slot of read-and-reset (allocated once: a hipMalloc / hipFree pair per read would
+  // synchronise the whole device, every lane stream and the ingest stream, at each saturation check — ADVICE r4)
+  ATDN_HIP(hipMalloc(&p, 2 * sizeof(unsigned int)));
+  ATDN_HIP(hipMemset(p, 0, 2 * sizeof(unsigned int)));
   for (auto set : sf_counter_setters()) {   // one per translation unit that includes sf.h
     set(p);
     ATDN_HIP(hipGetLastError());
@@ -602,15 +604,12 @@ __global__ void sf_counter_exchange_kernel(unsigned int* counter, unsigned int* 
 unsigned int sf_counter_read_reset(hipStream_t st) {
   std::lock_guard<std::mutex> lock(g_sf_counter_mutex);
   unsigned int* p = sf_counter_for_current_device(true);
-  unsigned int* slot = nullptr;
+  unsigned int* slot = p + 1;   // (the mutex is held until the copy has landed: one reader at a time owns the slot)
   unsigned int v = 0;
-  ATDN_HIP(hipMalloc(&slot, sizeof(unsigned int)));
   hipLaunchKernelGGL(sf_counter_exchange_kernel, dim3(1), dim3(1), 0, st, p, slot);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(&v, slot, sizeof(v), hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(slot);
-  ATDN_HIP(e);
+  ATDN_HIP(hipGetLastError());
+  ATDN_HIP(hipMemcpyAsync(&v, slot, sizeof(v), hipMemcpyDeviceToHost, st));
+  ATDN_HIP(hipStreamSynchronize(st));
   return v;
 }
 

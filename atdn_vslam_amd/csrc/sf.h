@@ -119,8 +119,12 @@ __device__ __forceinline__ void sf_store4(float* base, long off, int c, float4 v
 // cold path — a pointer load and an atomic behind a branch — makes the wait-count pass drain every outstanding store and
 // prefetched operand at the join: the ConvGRU epilogues carried an s_waitcnt vmcnt(0) per pixel group (round 4).
 __device__ __forceinline__ void sf_store4_flag(float* base, long off, int c, float4 v, bool& clamped) {
-  clamped |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) <= 65504.f);   // bounds every value; a NaN fails the test
+  // exact: the largest magnitude of the four against the limit (v_max3 + v_max with |.| source modifiers + one compare), and
+  // two unordered compares for NaNs, which v_max drops. (Round 4 tested the SUM of the magnitudes here: four in-range values
+  // of ~17000 each raised the alarm although nothing was clamped)
   const float lim = 65504.f;
+  const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  clamped |= !(m <= lim) | __builtin_isunordered(v.x, v.y) | __builtin_isunordered(v.z, v.w);
   v.x = fminf(fmaxf(v.x, -lim), lim); v.y = fminf(fmaxf(v.y, -lim), lim);
   v.z = fminf(fmaxf(v.z, -lim), lim); v.w = fminf(fmaxf(v.w, -lim), lim);
   const SfPair a = sf_split_nocheck_(v.x), b = sf_split_nocheck_(v.y), d = sf_split_nocheck_(v.z), e = sf_split_nocheck_(v.w);

@@ -185,9 +185,17 @@ class OdometryPipeline:
             # counter is per device and whoever reads first takes the count: modules.RAFTGMA.check_saturation publishes it in a
             # per-device ledger, so no lane can swallow another lane's clamp), and a SplitF16RangeError raised here travels
             # through the gather to every rank (sharding.gather_features) instead of leaving them blocked in it
+            # (every lane is read before anything is raised: a lane left unread would keep a stale ledger position and raise
+            # for this same event at the end of the NEXT, clean, sequence — ADVICE r4)
             join()
+            first = None
             for p in pipes:
-                p.flow_net.check_saturation()
+                try:
+                    p.flow_net.check_saturation()
+                except Exception as e:   # noqa: BLE001 - re-raised below, after the other lanes have been read
+                    first = first or e
+            if first is not None:
+                raise first
 
         encode_clip.device = self.device
         encode_clip.join = join
@@ -205,6 +213,9 @@ class VisualOdometry:
 
     def __init__(self, gma_state, clvo_state, device="cuda:0", iters=12):
         self.pipe = OdometryPipeline(gma_state, clvo_state, device=device, max_batch=1, iters=iters)
+        # frame-by-frame caller: every call ends in a device synchronisation anyway (the pose goes to the host), so the
+        # split-f16 range guard is read on EVERY forward — no pose computed from clamped activations is ever handed out
+        self.pipe.flow_net.saturation_check_every = 1
         self.device = self.pipe.device
         self.reset()
 

@@ -83,13 +83,20 @@ def rendezvous(error=None, group=None, device="cpu"):
     _raise_agreed(out.cpu(), dist.get_rank(group), error)
 
 
-def gather_features(local, n_pairs, group=None, error=None, device=None, dim=512):
+FEATURE_DIM, FEATURE_DTYPE = 512, torch.float32   # the block every rank of the sequence drivers contributes: [*, 512] fp32
+
+
+def gather_features(local, n_pairs, group=None, error=None, device=None, dim=None, dtype=None):
     """local [p_r, D] (this rank's shard, in sequence order) -> [n_pairs, D] in global sequence order on every
     rank. One all_gather of equally sized (padded) blocks; ragged and empty shards are handled.
     error: the exception this rank's local work raised, or None. A failed rank passes it (with local=None) and still joins
     the collective; its status travels in one extra row of the SAME padded block, and every rank then raises ShardError with
     the first failing rank's message. Nobody blocks in the all-gather because a peer raised before reaching it.
-    device / dim: where and how wide a rank WITHOUT a local tensor builds its block (every rank's block must have one shape)."""
+    device / dim / dtype: where, how wide and of which type a rank WITHOUT a local tensor builds its block (default: the
+    [*, 512] fp32 contract of the pose head's features). Every rank's block must have ONE shape and type or the collective
+    hangs or corrupts — the very thing this path exists to prevent — so when dim / dtype are given (the sequence drivers pass
+    them) a healthy rank's `local` is checked against them BEFORE the collective, and a mismatch travels as that rank's
+    error."""
     import os
     # (ATDN_FORCE_COLLECTIVE=1: a one-rank group still goes through the collective — a plumbing test of the backend)
     if not (dist.is_available() and dist.is_initialized()) or \
@@ -102,12 +109,21 @@ def gather_features(local, n_pairs, group=None, error=None, device=None, dim=512
     rank = dist.get_rank(group)
     lo, hi = shard_range(n_pairs, rank, world)
     width = -(-n_pairs // world)  # ceil
+    want_D = int(dim) if dim is not None else None
+    if error is None and local is not None:
+        # checked here, on the healthy path, so that a wrong block becomes a carried error instead of a mismatched collective
+        if local.dim() != 2 or local.shape[0] != hi - lo:
+            error = ValueError("shard of rank %d has shape %s, shard_range says %d rows" % (rank, tuple(local.shape), hi - lo))
+        elif (want_D is not None and local.shape[1] != want_D) or (dtype is not None and local.dtype != dtype):
+            error = ValueError("features of rank %d are %s %s, the gather contract is [*, %s] %s"
+                               % (rank, tuple(local.shape), local.dtype, want_D, dtype))
     if error is not None or local is None:
-        D, dtype = (local.shape[1], local.dtype) if local is not None else (int(dim), torch.float32)
+        # a failed (or empty-handed) rank: a zero block of the agreed shape, NOT of whatever its half-finished tensor has
+        D = want_D if want_D is not None else (local.shape[1] if local is not None and local.dim() == 2 else FEATURE_DIM)
+        dtype = dtype if dtype is not None else (local.dtype if local is not None else FEATURE_DTYPE)
         dev = local.device if local is not None else torch.device(device if device is not None else "cpu")
         block = torch.zeros((width + 1, D), dtype=dtype, device=dev)
     else:
-        assert local.shape[0] == hi - lo, "shard length does not match shard_range"
         D, dtype, dev = local.shape[1], local.dtype, local.device
         block = torch.zeros((width + 1, D), dtype=dtype, device=dev)
         block[: hi - lo] = local
@@ -141,7 +157,7 @@ def sharded_odometry(n_pairs, encode_pairs, scan, group=None, device=None):
         local = encode_pairs(lo, hi)
     except Exception as e:   # noqa: BLE001 — carried to every rank through the gather
         error = e
-    feats = gather_features(local, n_pairs, group, error=error, device=device)
+    feats = gather_features(local, n_pairs, group, error=error, device=device, dim=FEATURE_DIM, dtype=FEATURE_DTYPE)
     return scan(feats)
 
 
@@ -226,9 +242,12 @@ def sharded_sequence(n_frames, encode_clip, scan, batch, group=None, lanes=1, ti
             except Exception:        # noqa: BLE001
                 pass
     if timing is not None:
-        fence()
+        try:
+            fence()   # (a device error of the failed walk re-raised by this synchronisation must not skip the gather either)
+        except Exception as e:   # noqa: BLE001
+            local, error = None, (error or e)
         t1 = time.perf_counter()
-    feats = gather_features(local, n_pairs, group, error=error, device=dev)
+    feats = gather_features(local, n_pairs, group, error=error, device=dev, dim=FEATURE_DIM, dtype=FEATURE_DTYPE)
     if timing is not None:
         fence()
         t2 = time.perf_counter()

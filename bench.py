@@ -23,6 +23,21 @@ import os
 import sys
 import time
 
+# N > 1: the ranks of one node share its host cores. Cap every rank's CPU thread pools BEFORE torch (OpenMP / MKL) starts
+# them — 8 ranks x torch's default of one thread per core would oversubscribe a 16-core box 8-fold around every host-side
+# step of the timed loop (torch.distributed.run sets OMP_NUM_THREADS=1 itself when it is unset; this makes it explicit and
+# gives each rank its fair share instead).
+_WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+if _WORLD > 1:
+    try:
+        _cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        _cores = os.cpu_count() or 1
+    _share = str(max(1, _cores // _WORLD))
+    if os.environ.get("OMP_NUM_THREADS", "1") == "1":      # unset, or the launcher's default of 1
+        os.environ["OMP_NUM_THREADS"] = _share
+    os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -235,6 +250,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    if world > 1:
+        torch.set_num_threads(max(1, usable_cores() // world))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     B, K, Wm = args.batch, args.steps, args.warmup

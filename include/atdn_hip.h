@@ -74,7 +74,7 @@ int atdn_gma_forward_sequence_continued(atdn_gma* h, const float* frames, int B,
                                         float* flow_low, float* flow_up, void* stream);
 
 /* Copies an internal activation to a HOST buffer for parity tests ("fmap", "pyr0".."pyr3", "attn", "net",
- * "x", "corrfeat", "mask", "coords1", "flow4", "qk", "img4"). Returns the number of floats copied, -1 on error.
+ * "x", "corrfeat", "cor1" (relu(convc1(lookup)) of the last iteration), "mask", "coords1", "flow4", "qk", "img4"). Returns the number of floats copied, -1 on error.
  * "sf_clamped" returns ONE float: how many values the split-f16 storage format had to clamp (|x| > 65504, or NaN)
  * on this device since the last such read, and resets the count — non-zero means the activations of this checkpoint
  * left the format's range and results are not fp32-grade (use ATDN_PRECISION_F32). */
@@ -223,6 +223,19 @@ int atdn_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, co
  * pyr0..pyr3 as above. */
 int atdn_corr_pyramid(const float* fmap1, const float* fmap2, int B, int H8, int W8, int C, float* pyr0, float* pyr1,
                       float* pyr2, float* pyr3, void* stream);
+
+/* The same two operations through the kernels of the DEFAULT (split-f16) path — what atdn_gma_forward launches and
+ * bench.py times: corr_bricks_kernel for all four levels (corr.py:16-30,55-63; levels 1-3 from 2x2-pooled target features,
+ * avg_pool2d commutes with the dot product), the brick-major pyramid, and lookup_conv_kernel (corr.py:32-53 +
+ * utils/utils.py:59-73 bilinear_sampler; fused with convc1 of update.py:76-78). fmap1, fmap2 fp32 channels-last
+ * [B][H8*W8][256] (C must be 256); coords [B*H8*W8][2] (x, y) or NULL when no lookup is wanted. Every output is optional
+ * (NULL skips it): pyr0..pyr3 = the levels un-bricked to the reference's row-major [B*H8*W8][H_l*W_l]; samples
+ * [B*H8*W8][324], channel l*81 + i*9 + j (the FUSED = false instantiation of the sampling code); cor1 [B*H8*W8][256] =
+ * relu(convc1(samples)) from the fused instantiation, with convc1's HOST weight [256][324] (torch layout [256,324,1,1])
+ * and HOST bias [256]. Synchronises the stream before returning. */
+int atdn_corr_lookup_bricks(const float* fmap1, const float* fmap2, int B, int H8, int W8, int C, const float* coords,
+                            float* pyr0, float* pyr1, float* pyr2, float* pyr3, float* samples,
+                            const float* convc1_weight_host, const float* convc1_bias_host, float* cor1, void* stream);
 
 /* Generic NHWC convolution through the implicit-GEMM MFMA engine: src [nimg][H][W][Cin] (Cin % 32 == 0 or
  * Cin in {4,16}), HOST weight in torch layout [Cout][Cin][KH][KW] (+ HOST bias or NULL), dst

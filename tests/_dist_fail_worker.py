@@ -19,8 +19,8 @@ def main():
     out_dir, bad_rank, kind = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    n_pairs = 4 * world + 1          # ragged: the first rank has one pair more
-    batch = 2
+    n_pairs = int(sys.argv[4]) if len(sys.argv) > 4 else 4 * world + 1          # default: ragged, the first rank has one pair more
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     exc = SplitF16RangeError if kind == "SplitF16RangeError" else RuntimeError
     text = "synthetic failure of rank %d (%s)" % (bad_rank, kind)
     report = {"rank": rank}
@@ -64,6 +64,28 @@ def main():
         report["gather"] = "no error"
     except ShardError as e:
         report["gather"] = {"rank": e.rank, "type": e.remote_type}
+    # 2b) a rank whose features have the wrong width / type (mismatched blocks hang or corrupt the collective): the
+    # contract [*, 512] fp32 is checked before the gather and the mismatch travels like any other failure
+    def encode_wrong(lo, hi):
+        return torch.zeros((hi - lo, 256), dtype=torch.float64) if rank == bad_rank else torch.zeros((hi - lo, 512))
+    try:
+        sharded_odometry(n_pairs, encode_wrong, scan)
+        report["wrong_block"] = "no error"
+    except ShardError as e:
+        report["wrong_block"] = {"rank": e.rank, "type": e.remote_type}
+    # 2c) timing mode: the device fence after a failed walk raises too (a sticky device error) — the rank must still reach
+    # the gather
+    enc = make_encode(True)
+
+    def bad_sync():
+        if rank == bad_rank:
+            raise RuntimeError("device fence failed")
+    enc.sync = bad_sync
+    try:
+        sharded_sequence(n_pairs + 1, enc, scan, batch, timing={})
+        report["fence"] = "no error"
+    except ShardError as e:
+        report["fence"] = {"rank": e.rank, "type": e.remote_type}
     # 3) the failure-agreeing barrier
     try:
         rendezvous(exc(text) if rank == bad_rank else None)
@@ -72,8 +94,10 @@ def main():
         report["rendezvous"] = {"rank": e.rank, "type": e.remote_type, "msg": e.remote_message}
     rendezvous(None)     # and it is a plain barrier when nobody failed
     # 4) the group is still in step: a clean run gives the right answer on every rank
-    rot, tr = sharded_sequence(n_pairs + 1, make_encode(False), scan, batch)
+    timing = {}
+    rot, tr = sharded_sequence(n_pairs + 1, make_encode(False), scan, batch, lanes=2, timing=timing)
     report["clean_ok"] = bool(torch.equal(rot[:, 0], torch.arange(n_pairs, dtype=torch.float32)))
+    report["local_pairs"] = timing["local_pairs"]
     json.dump(report, open(os.path.join(out_dir, "fail_rank%d.json" % rank), "w"))
     dist.barrier()
     dist.destroy_process_group()

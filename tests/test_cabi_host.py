@@ -29,6 +29,60 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().atdn_version() >= 100
 
 
+def _prototypes():
+    """{name: (return type, [parameter types])} parsed from include/atdn_hip.h (comments stripped; types as written, with the
+    parameter names removed)."""
+    text = open(os.path.join(ROOT, "include", "atdn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for ret, name, params in re.findall(r"([A-Za-z_][A-Za-z0-9_ ]*?\**)\s*\b(atdn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        plist = []
+        for prm in [x.strip() for x in " ".join(params.split()).split(",")]:
+            if prm in ("void", ""):
+                continue
+            m = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)$", prm)      # the last identifier is the parameter's name
+            plist.append(m.group(1).replace(" ", ""))
+        protos[name] = (ret.replace(" ", ""), plist)
+    return protos
+
+
+def _ctype_kind(t):
+    """A ctypes argtype / restype as the C type class it can bind: 'ptr' or the scalar's C name."""
+    if t is None:
+        return "void"
+    if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or getattr(t, "_type_", None) == "P":
+        return "ptr"
+    return {C.c_int: "int", C.c_long: "long", C.c_float: "float", C.c_double: "double", C.c_size_t: "size_t",
+            C.c_int64: "int64_t"}[t]
+
+
+def _c_kind(t):
+    if t.endswith("*"):
+        return "ptr"
+    t = t.replace("const", "")
+    return {"int": "int", "long": "long", "float": "float", "double": "double", "size_t": "size_t", "int64_t": "int64_t",
+            "void": "void"}[t]
+
+
+def test_ctypes_argument_lists_match_the_header_prototypes():
+    """names alone do not catch a drifted `argtypes` (it would only surface as a crash in a GPU test). Every
+    prototype of include/atdn_hip.h is parsed and compared with _lib.SIGNATURES parameter by parameter: count, pointer vs
+    scalar, and the scalar's C type; the return type too."""
+    protos = _prototypes()
+    assert sorted(protos) == sorted(_lib.SIGNATURES)
+    for name, (ret, params) in sorted(protos.items()):
+        res, args = _lib.SIGNATURES[name]
+        assert len(args) == len(params), "%s: header has %d parameters, ctypes table %d" % (name, len(params), len(args))
+        for i, (ct, pt) in enumerate(zip(args, params)):
+            a, b = _ctype_kind(ct), _c_kind(pt)
+            assert a == b or {a, b} <= {"long", "int64_t"}, "%s: parameter %d is `%s` in the header, %s in the ctypes table" % (name, i, pt, ct)
+        # (on LP64, size_t / long / int64_t all bind 8-byte integers; ctypes aliases c_int64 to c_long there)
+        want = _c_kind(ret)
+        got = _ctype_kind(res)
+        assert got == want or {got, want} <= {"long", "int64_t"}, "%s: returns `%s` in the header, %s in the table" % (name, ret, res)
+
+
 def test_pose_algebra_matches_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "pose.npz"))
     for i in range(16):

@@ -209,6 +209,93 @@ def test_lookup_matches_reference_golden(golden_dir):
     assert _maxerr(got[0], torch.from_numpy(g["lookup"])) < 5e-5
 
 
+def _product_corr_on_gpu(f1, f2, coords=None, convc1=None, want_pyr=True):
+    """The DEFAULT path's kernels (corr_bricks_kernel x4 on pooled target features, brick-major pyramid, lookup_conv_kernel
+    with FUSED = false for the samples and FUSED = true for cor1) on caller features, through atdn_corr_lookup_bricks.
+    f1, f2 [B,256,H8,W8] CPU; coords [B,2,H8,W8] CPU or None; convc1 = (weight [256,324,1,1], bias [256]) or None.
+    -> (pyramid levels as row-major device tensors or None, samples [B,324,H8,W8] or None, cor1 [B,256,H8,W8] or None)."""
+    B, Cc, H8, W8 = f1.shape
+    N = H8 * W8
+    a = f1.permute(0, 2, 3, 1).reshape(B, N, Cc).contiguous().to(DEV)
+    b = f2.permute(0, 2, 3, 1).reshape(B, N, Cc).contiguous().to(DEV)
+    pyr = [torch.full((B * N, (H8 >> l) * (W8 >> l)), float("nan"), device=DEV) for l in range(4)] if want_pyr else [None] * 4
+    c = samples = cor1 = None
+    wv = bv = None
+    if coords is not None:
+        c = coords.permute(0, 2, 3, 1).reshape(B * N, 2).contiguous().to(DEV)
+        samples = torch.full((B * N, 324), float("nan"), device=DEV)
+    if convc1 is not None:
+        wv, bv = convc1[0].reshape(256, 324).contiguous().float(), convc1[1].contiguous().float()
+        cor1 = torch.full((B * N, 256), float("nan"), device=DEV)
+    null = C.c_void_p(None)
+    _lib.check(_lib.lib().atdn_corr_lookup_bricks(
+        _vp(a), _vp(b), B, H8, W8, Cc, _vp(c) if c is not None else null, *[_vp(p) if p is not None else null for p in pyr],
+        _vp(samples) if samples is not None else null, _vp(wv) if wv is not None else null, _vp(bv) if bv is not None else null,
+        _vp(cor1) if cor1 is not None else null, _stream()))
+    torch.cuda.synchronize()
+    if samples is not None:
+        samples = samples.cpu().reshape(B, H8, W8, 324).permute(0, 3, 1, 2)
+    if cor1 is not None:
+        cor1 = cor1.cpu().reshape(B, H8, W8, 256).permute(0, 3, 1, 2)
+    return pyr, samples, cor1
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 20, 64), (1, 256, 47, 154)])
+def test_product_corr_kernels_match_oracle(shape):
+    """the same probes as test_corr_pyramid_and_lookup_match_oracle — partly outside, +-5000, the last cell, exact
+    integers, random offsets of +-9 px — through the kernels the default path launches and bench.py times (corr_bricks_kernel,
+    lookup_conv_kernel), not the f32-mode ones; and the fused convc1 phase against relu(convc1(lookup)) of the oracle."""
+    from oracle import gma_ref
+    B, Cc, H8, W8 = shape
+    r = np.random.RandomState(11)
+    f1 = torch.from_numpy(r.normal(0, 1, shape).astype(np.float32))
+    f2 = torch.from_numpy(r.normal(0, 1, shape).astype(np.float32))
+    ref_pyr = gma_ref.corr_pyramid(f1, f2)
+    coords = gma_ref.coords_grid(B, H8, W8) + torch.from_numpy(r.uniform(-9, 9, (B, 2, H8, W8)).astype(np.float32))
+    coords[0, :, 0, 0] = torch.tensor([-7.5, 3.25])          # partly outside
+    coords[0, :, 0, 1] = torch.tensor([5000.0, -5000.0])     # far outside: zeros
+    coords[0, :, 0, 2] = torch.tensor([float(W8 - 1), float(H8 - 1)])
+    coords[0, :, 0, 3] = torch.tensor([0.0, 0.0])            # exact integers (iteration 0 situation)
+    coords[0, :, 0, 4] = torch.tensor([-5000.0, 5000.0])
+    coords[0, :, 1, 0] = torch.tensor([float(W8 - 1) + 4.5, float(H8 - 1) + 4.5])   # window leaves through the far corner
+    coords[0, :, 1, 1] = torch.tensor([-4.0, -4.0])          # window's last cell is the map's first, integer
+    wc = torch.from_numpy((r.uniform(-1, 1, (256, 324, 1, 1)) * np.sqrt(3.0 / 324)).astype(np.float32))
+    bc = torch.from_numpy(r.uniform(-0.5, 0.5, (256,)).astype(np.float32))
+    pyr, got, cor1 = _product_corr_on_gpu(f1, f2, coords, (wc, bc))
+    for l in range(4):
+        ref = ref_pyr[l].reshape(B * H8 * W8, -1)
+        assert pyr[l].shape == ref.shape
+        # levels 1-3 come from pooled FEATURES (the reference pools the volume): equal up to fp32 summation order
+        assert _maxerr(pyr[l].cpu(), ref) < 5e-5 * (Cc / 64) ** 0.5, l
+    ref = gma_ref.corr_lookup(ref_pyr, coords)
+    assert torch.isfinite(got).all()
+    assert torch.all(got[0, :, 0, 1] == 0) and torch.all(got[0, :, 0, 4] == 0)
+    scale = float(ref.abs().max())
+    assert _maxerr(got, ref) < 2e-5 * max(1.0, scale)
+    ref_cor1 = F.relu(F.conv2d(ref.double(), wc.double(), bc.double()))
+    assert torch.isfinite(cor1).all()
+    assert _maxerr(cor1, ref_cor1) < 5e-5 * max(1.0, scale)
+    assert torch.equal(cor1[0, :, 0, 1], F.relu(bc))         # all-zero samples: relu(bias) exactly
+
+
+def test_product_lookup_matches_reference_golden(golden_dir, gsd):
+    """The reference's own CorrBlock output on its own fmaps (gma_c1.npz: probe / lookup, with out-of-range and integer
+    coordinates) reproduced by the PRODUCT kernels; and cor1 of the fused kernel against relu(convc1(.)) of that golden lookup
+    with the checkpoint's convc1."""
+    from oracle import gma_ref
+    g = np.load(os.path.join(golden_dir, "gma_c1.npz"))
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=int(g["seed_frames"])))
+    taps = {}
+    gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=1, taps=taps)
+    wc, bc = gsd["update_block.encoder.convc1.weight"], gsd["update_block.encoder.convc1.bias"]
+    _, got, cor1 = _product_corr_on_gpu(taps["fmap1"], taps["fmap2"], torch.from_numpy(g["probe"])[None], (wc, bc), want_pyr=False)
+    want = torch.from_numpy(g["lookup"])
+    assert _maxerr(got[0], want) < 5e-5
+    ref_cor1 = F.relu(F.conv2d(want[None].double(), wc.double(), bc.double()))
+    assert _maxerr(cor1, ref_cor1) < 5e-5
+
+
+
 # ----------------------------------------------------------------------------- GMA forward
 @pytest.fixture(scope="module")
 def gsd():
@@ -257,6 +344,11 @@ def test_gma_c1_stages_match_oracle_and_golden(golden_dir, gsd, flow_net):
     # first update-block pass
     look = _nchw_from(flow_net.debug_read("corrfeat", (N, 352), 160, 512)[:, :324], 1, H8, W8, 324)
     assert _maxerr(look, taps["lookup0"]) < 1e-4
+    # ... and the product phase of the fused lookup kernel (what the iteration really consumed), against the oracle's lookup
+    # pushed through the checkpoint's convc1 (update.py:76-78)
+    cor1 = _nchw_from(flow_net.debug_read("cor1", (N, 256), 160, 512), 1, H8, W8, 256)
+    ref_cor1 = F.relu(F.conv2d(taps["lookup0"], gsd["update_block.encoder.convc1.weight"], gsd["update_block.encoder.convc1.bias"]))
+    assert _maxerr(cor1, ref_cor1) < 1e-4
     mf = _nchw_from(x[:, 128:256], 1, H8, W8, 128)
     mfg = _nchw_from(x[:, 256:384], 1, H8, W8, 128)
     # after the iteration the flow slots hold the UPDATED flow; compare the 126 conv channels

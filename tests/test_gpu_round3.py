@@ -85,6 +85,30 @@ def test_saturation_guard_raises_through_the_product_path():
     assert bool(torch.isfinite(up).all())
 
 
+def test_per_frame_callers_check_the_range_guard_on_every_call():
+    """RAFTGMA alone reads the saturation counter after the first forward of a checkpoint and then every 512
+    forwards; the frame-by-frame callers (pipeline.VisualOdometry, slam.NeuralSLAM), which synchronise per frame anyway to
+    hand a pose to the host, read it on EVERY call — a sequence whose frame 3 alone drives the activations out of the
+    split-f16 range raises on frame 3, not up to 511 poses later."""
+    from atdn_vslam_amd.pipeline import VisualOdometry
+    gsd = syn.to_torch(syn.make_gma_state(seed=1))
+    hsd = syn.to_torch(syn.make_clvo_state(seed=1))
+    vo = VisualOdometry(gsd, hsd, device=DEV, iters=2)
+    assert vo.pipe.flow_net.saturation_check_every == 1
+    fr = torch.from_numpy(syn.make_frames(5, 376, 1241, seed=21))
+    fr[3] = fr[3] * 1e7                                        # a broken frame: the context network (BatchNorm folded) overflows
+    for k in range(3):
+        pose = vo(fr[k])
+        assert tuple(pose.shape) == (4, 4) and bool(torch.isfinite(pose).all())
+    assert vo.pipe.flow_net.saturation_checks == 2            # one read per forward (calls 1 and 2; call 0 has no pair yet)
+    with pytest.raises(SplitF16RangeError):
+        vo(fr[3])                                              # raised by the call that computed from clamped activations
+    # the same contract in the SLAM caller's constructor
+    import inspect
+    from atdn_vslam_amd import slam
+    assert "saturation_check_every=1" in inspect.getsource(slam.NeuralSLAM.__init__)
+
+
 def test_saturation_fallback_recomputes_in_f32():
     """Opt-in self-healing: with saturation_fallback=True the module that detects clamped activations switches itself to the
     exact-fp32 matrix core (new handle, same process), warns, and recomputes the forward — the caller gets the f32 result."""
@@ -198,6 +222,45 @@ def test_h3_encode_saturation_is_counted():
     net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=2, test_mode=True)
     with pytest.raises(SplitF16RangeError):
         net.check_saturation()
+
+
+def test_in_range_values_of_tens_of_thousands_raise_no_alarm():
+    """the branch-free store of the conv / GRU / attention epilogues (sf_store4_flag) flagged a clamp when
+    the SUM of four adjacent magnitudes passed 65504 — four in-range values of ~17000 each set the flag although nothing was
+    clamped, so the guard's threshold was effectively 16.4k per value. The flag is exact now: outputs of 30000 +- 3000 (every
+    group of four sums to ~120000) are stored without an alarm and round-trip at fp32 grade; outputs of 70000 +- 3000 are
+    clamped AND counted."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from atdn_vslam_amd import _lib
+    net = RAFTGMA(saturation_check_every=0)
+    net.load_state_dict(syn.to_torch(syn.make_gma_state(seed=1)))
+    net = net.to(DEV).eval()
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=3)).to(DEV)
+    net(fr[0:1], fr[1:2], iters=1, test_mode=True)          # a live handle: the counter is read through it
+    assert net.check_saturation() == 0
+    r = np.random.RandomState(5)
+    nimg, cin, cout, H, W = 3, 64, 64, 23, 37
+    x = torch.from_numpy(r.normal(0, 1, (nimg, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((r.uniform(-1, 1, (cout, cin, 3, 3)) * np.sqrt(3.0 / (cin * 9)) * 1000.0).astype(np.float32))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for level, expect_clamp in ((30000.0, False), (70000.0, True)):
+        b = torch.full((cout,), level, dtype=torch.float32)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        assert float((ref.abs() - level).abs().max()) < 0.2 * level
+        out = torch.full((nimg, H, W, cout), float("nan"), dtype=torch.float32, device=DEV)
+        _lib.check(_lib.lib().atdn_conv2d_nhwc_sf_epi(C.c_void_p(xd.data_ptr()), nimg, H, W, cin, C.c_void_p(w.data_ptr()),
+                                                      C.c_void_p(b.data_ptr()), cout, 3, 3, 1, 1, 1, 1,
+                                                      C.c_void_p(out.data_ptr()), st))
+        torch.cuda.synchronize()
+        got = out.cpu().permute(0, 3, 1, 2).double()
+        n = net.check_saturation(raise_on_clamp=False)
+        if expect_clamp:
+            assert n > 0 and float(got.max()) <= 65504.0
+        else:
+            assert n == 0, n
+            assert float((got - ref).abs().max()) < 2e-5 * level / 4      # ~2^-22 relative, like O(5) outputs at 2e-5
 
 
 def test_split_f16_validity_c2_one_hot_attention_rows():

@@ -116,9 +116,36 @@ def test_a_failing_rank_raises_on_every_rank(tmp_path, world, bad_rank, kind):
             assert got["rank"] == bad_rank and got["type"] == kind and "synthetic failure of rank %d" % bad_rank in got["msg"]
             assert got["s"] < 20.0, got                              # and did not wait for a watchdog
             assert got["cause"] == (kind if rank == bad_rank else None)   # the failing rank keeps its own traceback
-        for key in ("odo", "gather", "rendezvous"):
+        for key in ("odo", "gather", "rendezvous", "fence"):
             assert isinstance(rep[key], dict) and rep[key]["rank"] == bad_rank and rep[key]["type"] == kind, (rank, key, rep[key])
+        # a block of the wrong width / dtype is caught before the collective and reported like any failure
+        assert rep["wrong_block"] == {"rank": bad_rank, "type": "ValueError"}, (rank, rep["wrong_block"])
         assert rep["clean_ok"] is True
+
+
+@pytest.mark.timeout(420)
+def test_world_8_kitti00_shards_with_a_failing_rank(tmp_path):
+    """VERDICT r4 #5b: the first 8-GPU run should be boring. Eight gloo ranks on KITTI-00's 4,540 pairs (568 x 4 + 567 x 4),
+    clips of 16, two lanes per rank: rank 5 fails in its second clip — all eight raise ShardError naming it through every entry
+    point — and the clean two-lane run afterwards puts every pair in its place on every rank."""
+    import json
+    world, bad_rank, kind = 8, 5, "SplitF16RangeError"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", "29791",
+           os.path.join(ROOT, "tests", "_dist_fail_worker.py"), str(tmp_path), str(bad_rank), kind, "4540", "16"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    sizes = []
+    for rank in range(world):
+        rep = json.load(open(os.path.join(str(tmp_path), "fail_rank%d.json" % rank)))
+        for key in ("seq1", "seq2", "odo", "gather", "rendezvous", "fence"):
+            assert isinstance(rep[key], dict) and rep[key]["rank"] == bad_rank and rep[key]["type"] == kind, (rank, key, rep[key])
+        assert rep["seq2"]["s"] < 30.0
+        assert rep["wrong_block"] == {"rank": bad_rank, "type": "ValueError"}
+        assert rep["clean_ok"] is True
+        sizes.append(rep["local_pairs"])
+    assert sizes == [568] * 4 + [567] * 4
 
 
 def test_failure_status_row_roundtrip():
