@@ -79,6 +79,7 @@ class GmaNet {
   int seq_ = 0;        // 0: pair mode; 1: sequence (B+1 frames, every frame through fnet once); 2: sequence continued
                        //    (frame 0 is the previous call's last frame: its features are reused, fnet sees B frames)
   int last_frame_ = -1;  // fmap_ slot of the last frame of the previous sequence call
+  int last_B_ = 0;       // pairs of the last forward (debug reads that recompute something do so for these pairs only)
 
   StateDict sd_;
   WeightArena arena_;

@@ -722,6 +722,7 @@ void GmaNet::forward_sequence(const float* frames, int B, int iters, const float
 }
 
 void GmaNet::launch_body(int B, int iters, hipStream_t st) {
+  last_B_ = B;
   if (use_graph_) {
     auto key = std::make_pair(B, iters * 4 + seq_);
     if (!graphs_.count(key)) capture(B, iters);
@@ -770,8 +771,10 @@ long GmaNet::debug_read(const char* name, float* host, long capacity, hipStream_
     return n;
   }
   if (!classic_ && k == "corrfeat") {
-    // the fused kernel keeps the samples on chip: recompute them at the coordinates the last lookup used
-    launch_lookup_bricks(brick_pyramid(), coords_used_.p, (long)maxB * N, corrfeat_.p, st);
+    // the fused kernel keeps the samples on chip: recompute them at the coordinates the last lookup used — for the pairs of the
+    // last forward only: the pyramid and the coordinates of the handle's other pairs are whatever an earlier call (or the
+    // allocator) left there, and sampling that raised the format's saturation alarm behind a parity test (round 5)
+    launch_lookup_bricks(brick_pyramid(), coords_used_.p, (long)(last_B_ > 0 ? last_B_ : maxB) * N, corrfeat_.p, st);
   }
   if (k == "sf_clamped") {   // values the split-f16 format had to clamp (|x| > 65504 or NaN) since the last read
     ATDN_CHECK(capacity >= 1, "sf_clamped needs room for one float");

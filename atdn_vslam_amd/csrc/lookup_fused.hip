@@ -34,36 +34,39 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int TP = 64;            // source pixels per block (round 3: 64 — the convc1 phase was bound by the L1 rate of its weight loads,
                                   // a block multiplies twice the pixels with every weight fragment it fetches)
 constexpr int NCH = 352;          // 4 * 81 samples padded to a multiple of 32
-constexpr int APITCH = 1440;      // bytes per pixel row of the A tile: 11 x 128 + 32 = 90 slots of 16 B, 90 = 2 (mod 4): conflict-free
-                                  // ds_read_b128 for the operand lane map of v_mfma_f32_16x16x32_f16 (16 pixels x 4 slots per instruction)
+constexpr int APITCH = 1504;      // bytes per pixel row of the A tile: 11 x 128 + 96 = 94 slots of 16 B, 94 = 2 (mod 4): conflict-free
+                                  // ds_read_b128 for the operand lane map of v_mfma_f32_16x16x32_f16 (16 pixels x 4 slots per instruction).
+                                  // The 96 bytes behind the 11 chunks are never read: bytes 1408-1439 and 1472-1503 are the DUMP of the
+                                  // lanes without a sample (their hi / lo stores, 64 bytes apart like everybody's)
+constexpr int ADUMP = 1408;
 constexpr int GW = 24, GH = 24;   // per-wave window grid: 3 x 4 bricks (24 x 16 cells). Pitch 24 dwords = -8 (mod 32 banks): the four
                                   // rows x two 16-byte halves a brick's eight lanes write (ds_write_b128: groups of 8 lanes) are eight
                                   // distinct bank quads, and a 32-lane group of sample reads (ds_read_b32) laid out as 8 x-positions x 4
                                   // rows is 32 distinct banks. (Pitch 28 with samples in channel order: SQ_LDS_BANK_CONFLICT = 25 % of
-                                  // the kernel's LDS cycles.) Rows 16-23 are a dump for the lanes without a brick / a sample: the unit
+                                  // the kernel's LDS cycles.) Rows 16-23 are a dump for the lanes without a brick: the unit
                                   // body has NO branch (a branch around an LDS store made the compiler drain every prefetched load,
                                   // vmcnt(0), per unit)
 constexpr int DEPTH = 4;          // (pixel, level) units in flight per wave
 constexpr int NWAVE = 16;         // waves per block (one 1024-thread block per CU): wave w samples all four levels of pixels 4 w .. 4 w + 3
 constexpr int UPW = TP * 4 / NWAVE;   // units (pixels of its level) per wave
 
-// One (pixel, level) unit. Everything here is wave-uniform: the integers are forced into scalar registers
-// (v_readfirstlane), so the brick range, the grid origin and the buffer descriptor of the unit are computed on the scalar
-// unit and cost the vector pipe nothing (SQ counters of the round-3 kernel: the sampling phase is VALU-issue bound,
-// ~180 vector instructions per unit; this and the chain table below took it to ~95).
-struct Unit { float xc, yc; int sane; int wx0, wy0, bx0, by0; };
-
-__device__ __forceinline__ Unit unit_origin(float cx, float cy, float inv) {
-  Unit u;
-  u.xc = cx * inv; u.yc = cy * inv;
-  const bool sane = (fabsf(u.xc) < 1.0e6f) && (fabsf(u.yc) < 1.0e6f);   // also rejects NaN
-  u.sane = __builtin_amdgcn_readfirstlane((int)sane);
-  const int fx = __builtin_amdgcn_readfirstlane((int)floorf(u.xc)), fy = __builtin_amdgcn_readfirstlane((int)floorf(u.yc));
-  u.wx0 = u.sane ? fx - 5 : -(1 << 24);
-  u.wy0 = u.sane ? fy - 5 : -(1 << 24);
-  u.bx0 = u.wx0 >> 3; u.by0 = u.wy0 >> 2;                       // arithmetic shifts: floor for negative origins
-  return u;
-}
+// One (pixel, level) unit — round 5: the sampling unit on an instruction diet (rounds 3-4: ~101 vector ALU + 15 LDS instructions
+// per unit in the ISA, the kernel's bound; now ~35 + 10).
+//  * ONE x chain and ONE y chain per unit (the reference's arithmetic, corr.py:43-49 and utils.py:63-70, evaluated for the window's
+//    centre, offset 0) instead of nine + nine: all 81 samples of a unit share one integer origin and — up to the last bits of the
+//    reference's normalise / denormalise round trip, which differ from offset to offset by a few ulp of the coordinate — one
+//    fractional part. The four bilinear products are therefore ONE set of numbers per unit, a lane's grid address is a per-lane
+//    constant plus a scalar, and the window is 10 x 10 cells (origin = floor - 4), not 12 x 12: fewer bricks fetched.
+//  * Those per-unit numbers are computed ONCE PER WAVE, lane u = unit u (16 units: 4 pixels x 4 levels), before the loop — not
+//    by all 64 lanes redundantly, unit after unit — and reach the unit that needs them as scalars (v_readlane): the origin for
+//    the scalar-unit arithmetic of the brick range, the four products as scalar operands of the sample FMAs.
+//  * Which of a unit's 3 x 4 bricks exist (inside the window AND inside the map) is a 12-bit scalar mask, blown up to a lane
+//    mask by s_bitreplicate; a lane's load offset is a per-level lane constant plus a scalar and ONE select.
+//  * saturation: the largest sample magnitude is tracked (one v_max3 per unit) and compared once, after the loop.
+//  * the residual of the split, lo = f16(v - hi), is one v_fma_mixlo_f16 (bit-identical to convert-subtract-convert:
+//    tools/diag/sf_mix_check.hip).
+// Rounds 3-4 evaluated the 18 chains on lanes 0-17 into an LDS table (one ds_write_b64, four ds_read_b64 and two fences per
+// unit) and formed the four products in every lane, twice.
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -77,7 +80,6 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
   __shared__ __attribute__((aligned(16))) char atile[TP * APITCH];
   __shared__ __attribute__((aligned(16))) float grid[NWAVE][GH * GW];
 
-  __shared__ __attribute__((aligned(16))) float2 ctab[NWAVE][2][64];   // per wave, two units: (weight, grid index) of the 18 chains
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (tells the compiler what the hardware guarantees: wave-uniform)
   // block = one pixel block of one pair (the last block of a pair is partial when N % 64 != 0)
@@ -103,59 +105,112 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
   // level-dependent quantity is indexed by a compile-time slot.
   static_assert(DEPTH == 4, "unit pi has level pi & 3 = pi % DEPTH");
   const int pbase = wave * (UPW / 4);
-  float wm1[4], hm1[4];
-#pragma unroll
-  for (int l = 0; l < 4; ++l) { wm1[l] = (float)(pyr.W[l] - 1); hm1[l] = (float)(pyr.H[l] - 1); }
   // coordinates of the block's pixels: lane i holds pixel i (pixels past the end repeat the last one; never stored)
   static_assert(TP == 64, "one lane per pixel of the block");
   const long pc = p0 + min(lane, np - 1);
   const float2 cmine = *reinterpret_cast<const float2*>(coords1 + pc * 2);
   if (wave == 0 && lane < np && coords_used) *reinterpret_cast<float2*>(coords_used + (p0 + lane) * 2) = cmine;
 
-  Unit un[DEPTH];
+  // ---- the wave's 16 units at once: lane u (and u + 16, u + 32, u + 48: copies) = unit u = (pixel pbase + (u >> 2), level u & 3)
+  // per unit: P_m12 = which of its 3 x 4 bricks exist (bit 3 r + c), P_sb = byte offset of its window's first brick in the pixel
+  // block's level (without the pixel's line), P_gb = byte offset of its window's first cell in the wave's grid, and the four
+  // bilinear products
+  int P_m12, P_sb, P_gb;
+  float P_w00, P_w01, P_w10, P_w11;
+  {
+#pragma clang fp contract(off)   // the reference's roundings, one operation at a time
+    const int myu = lane & 15, lev = myu & 3;
+    const int mypp = min(pbase + (myu >> 2), np - 1);
+    const float cx = __shfl(cmine.x, mypp), cy = __shfl(cmine.y, mypp);
+    const int Wl = lev == 0 ? pyr.W[0] : lev == 1 ? pyr.W[1] : lev == 2 ? pyr.W[2] : pyr.W[3];
+    const int Hl = lev == 0 ? pyr.H[0] : lev == 1 ? pyr.H[1] : lev == 2 ? pyr.H[2] : pyr.H[3];
+    const float inv = lev == 0 ? 1.0f : lev == 1 ? 0.5f : lev == 2 ? 0.25f : 0.125f;     // coords / 2**l (corr.py:44)
+    float xc = cx * inv, yc = cy * inv;
+    const bool sane = (fabsf(xc) < 1.0e6f) && (fabsf(yc) < 1.0e6f);   // also rejects NaN
+    // a unit that is not sane samples zeros (every brick of its window is outside the map): finite coordinates keep NaN / inf
+    // out of the weights, and its origin goes to -2^24
+    xc = sane ? xc : 0.f; yc = sane ? yc : 0.f;
+    // pos = c + d; g = 2 pos / (S - 1) - 1; u = (g + 1) * ((S - 1) / 2): the reference's round trip through normalised
+    // coordinates, for d = 0. The division is a multiplication by the correctly rounded reciprocal plus one FMA correction
+    // step. That is the correctly rounded quotient whenever the first product is within one ulp of it (Markstein) — not a
+    // theorem for every (t, b); for the divisors this network has (W_l - 1, H_l - 1 of the four levels at C1 and C2)
+    // tests/test_host_arith.py checks the chain against the IEEE division over every position on a 1/64-pixel lattice across
+    // the maps plus 16 pixels of margin.
+    auto chain = [](float c0, float sz) __attribute__((always_inline)) {
+      const float rs = 1.0f / sz, hs = sz / 2.f;                      // (IEEE divisions, once per wave)
+      const float t = 2.f * c0;
+      float q = t * rs;
+      q = __builtin_fmaf(__builtin_fmaf(-q, sz, t), rs, q);          // = t / sz (see above)
+      return ((q - 1.f) + 1.f) * hs;
+    };
+    const float ux = chain(xc, (float)(Wl - 1)), uy = chain(yc, (float)(Hl - 1));
+    const float flx = floorf(ux), fly = floorf(uy);
+    const float ww = ux - flx, nn = uy - fly, ee = 1.f - ww, ss = 1.f - nn;
+    P_w00 = ee * ss; P_w01 = ww * ss; P_w10 = ee * nn; P_w11 = ww * nn;
+    // window = the 10 x 10 cells floor - 4 .. floor + 5 (offsets -4 .. 4, taps at +0 and +1)
+    const int wx0 = sane ? (int)flx - 4 : -(1 << 24), wy0 = sane ? (int)fly - 4 : -(1 << 24);
+    const int bx0 = wx0 >> 3, by0 = wy0 >> 2;                       // arithmetic shifts: floor for negative origins
+    P_gb = sane ? ((wy0 - 4 * by0) * GW + (wx0 - 8 * bx0)) * 4 : 0;
+    const int BWl = lev == 0 ? pyr.BW[0] : lev == 1 ? pyr.BW[1] : lev == 2 ? pyr.BW[2] : pyr.BW[3];
+    const int BHl = lev == 0 ? pyr.BH[0] : lev == 1 ? pyr.BH[1] : lev == 2 ? pyr.BH[2] : pyr.BH[3];
+    // only the bricks the window really touches (2-3 columns, 3-4 rows) that lie inside the map: columns [clo, chi) and rows
+    // [rlo, rhi) of the 3 x 4 block -> a 12-bit mask, bit 3 r + c
+    const int nbx = (((wx0 & 7) + 9) >> 3) + 1, nby = (((wy0 & 3) + 9) >> 2) + 1;
+    const int clo = max(0, -bx0), chi = max(min(nbx, BWl - bx0), clo);
+    const int rlo = max(0, -by0), rhi = max(min(nby, BHl - by0), rlo);
+    const unsigned cm = (1u << (chi & 31)) - (1u << (clo & 31));                                   // 0 when the range is empty
+    const unsigned rm = 0x249u & ((1u << ((3 * rhi) & 31)) - (1u << ((3 * rlo) & 31)));            // bit 3 r for r in [rlo, rhi)
+    P_m12 = (int)((clo < 3 && rlo < 4) ? rm * cm : 0u);                                            // (shift counts are in range then)
+    P_sb = (by0 * BWl + bx0) * (TP * 128);     // (wraps for origins outside the map: those lanes are masked)
+  }
+
   v4f bv[DEPTH][2];
   // lane -> brick bi = 8k + (lane >> 3) of the 3 x 4 block of bricks (bi < 12), 16-byte part lane & 7 of its line
   int bxi[2], byi[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) { const int bi = 8 * k + (lane >> 3); byi[k] = bi / 3; bxi[k] = bi - 3 * byi[k]; }
+  // byte offset of this lane's part of brick (byi, bxi) from the window's first brick, per level
+  int loff[4][2];
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) loff[l][k] = (byi[k] * pyr.BW[l] + bxi[k]) * (TP * 128) + (lane & 7) * 16;
+  const int big = 0x7FFFFFF0;   // an offset past the end of every level: the load returns zeros
+  auto rep8 = [](unsigned m8) __attribute__((always_inline)) {   // bit b of m8 -> bits 8 b .. 8 b + 7 (scalar unit)
+    unsigned long long r;
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(r) : "s"(m8));
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(r) : "s"((unsigned)r));
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(r) : "s"((unsigned)r));
+    return r;
+  };
   auto issue = [&](int pi, int l) __attribute__((always_inline)) {   // l = pi & 3: level of the unit AND its ring slot
     const int pp = min(pbase + (pi >> 2), np - 1);
-    // (pp is wave-uniform: v_readlane, not a ds_bpermute whose wait would also sit behind the sampling phase's LDS traffic)
-    const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cmine.x), pp));
-    const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cmine.y), pp));
-    un[l] = unit_origin(cx, cy, 1.0f / (float)(1 << l));
-    const Unit& u = un[l];
-    const int BWl = pyr.BW[l], BHl = pyr.BH[l];
-    const long NBl = pyr.NB[l];
-    // only the bricks the 12 x 12 window really touches: 2-3 columns, 3-4 rows of bricks (scalar arithmetic)
-    const int nbx = (((u.wx0 & 7) + 11) >> 3) + 1, nby = (((u.wy0 & 3) + 11) >> 2) + 1;
+    // (units past the wave's 16th — the prefetches behind the last one — read the copies in lanes 16 .. 18: valid, unused)
+    const unsigned m12 = (unsigned)__builtin_amdgcn_readlane(P_m12, pi);
+    const int sbase = __builtin_amdgcn_readlane(P_sb, pi) + pp * 128;
+    const unsigned long long lm0 = rep8(m12 & 0xFFu), lm1 = rep8(m12 >> 8);
     // the pixel's map of this level as a buffer: a lane whose brick is outside the window or outside the map gets an offset
     // past the end, and the load returns zeros by itself (they ARE grid_sample's zero padding): no select on the data
     // (the pixel block's level as a buffer of NBK x 64 lines; the unit's pixel selects the line inside a brick's 8 KB run)
+    const long NBl = pyr.NB[l];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(pyr.base[l] + ((long)pair * pyr.NPB + pblk) * NBl * TP), 0, (int)(NBl * TP * 4), 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int bx = u.bx0 + bxi[k], by = u.by0 + byi[k];
-      const bool ok = (bxi[k] < nbx) & (byi[k] < nby) & ((unsigned)bx < (unsigned)BWl) & ((unsigned)by < (unsigned)BHl);
-      const int off = ok ? ((by * BWl + bx) * TP + pp) * 128 + (lane & 7) * 16 : 0x7FFFFFF0;
+      int off;
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "v"(big), "v"(loff[l][k] + sbase), "s"(k == 0 ? lm0 : lm1));
       bv[l][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
 #pragma unroll
   for (int d = 0; d < DEPTH - 1; ++d) issue(d, d);
   float* gw = grid[wave];
-  bool clamped = false;   // saturation of the sf format, reported once after the loop (sf.h)
-  // The unit body has no lane permutes (eight ds_bpermute per unit in round 2) and never drains the LDS queue (twice per unit
-  // in round 2): it relies on what the hardware guarantees — the LDS instructions of ONE wave execute in issue order, so a
-  // read issued after a write of the same wave sees it, and the next unit's grid writes cannot overtake this unit's reads.
-  // The 9 + 9 coordinate chains of a unit (x offsets -4..4, y offsets -4..4; the reference's arithmetic, corr.py:43-49 and
-  // utils.py:63-70) are evaluated ONCE, by lanes 0-17, one unit ahead, and left in a 64-entry table of the wave; a sample
-  // lane picks up the (weight, grid index) pairs of its two samples with four ds_read_b64 — LDS instructions, while the
-  // vector pipe does the arithmetic of the current unit.
-  // per-lane constants: grid slot of this lane's two brick parts; its two samples (i, j), their table entries and where they
-  // go in a pixel's row of the A tile (the 47 lanes past the 81st sample compute sample (8, 8) again into the dump rows)
-  int gofs[2], dofs[4][2], ex[2], ey[2];
+  // The unit body has no lane permutes (eight ds_bpermute per unit in round 2), no table round trip (rounds 3-4) and never
+  // drains the LDS queue: it relies on what the hardware guarantees — the LDS instructions of ONE wave execute in issue order,
+  // so a read issued after a write of the same wave sees it, and the next unit's grid writes cannot overtake this unit's reads.
+  // per-lane constants: grid slot of this lane's two brick parts; its two samples (i, j), their cell inside the window and where
+  // they go in a pixel's row of the A tile (the 47 lanes past the 81st sample compute sample (8, 8) again into the row's dump)
+  int gofs[2], dofs[4][2], sofs[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int part = lane & 7;   // bricks 12..15 do not exist: their lanes load zeros and write them to rows 16..23
@@ -164,100 +219,65 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
     // rows); pass 1 = column i = 8 (lanes 0-8) and row j = 8 (lanes 9-16)
     const int i9 = k == 0 ? (lane & 7) : (lane < 9 ? 8 : (lane < 17 ? lane - 9 : 8));
     const int j9 = k == 0 ? (lane >> 3) : (lane < 9 ? lane : 8);
-    ex[k] = i9; ey[k] = 9 + j9;
+    sofs[k] = (j9 * GW + i9) * 4;
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       const int c = l * 81 + i9 * 9 + j9;
-      dofs[l][k] = (c >> 5) * 128 + (c & 31) * 2;
+      dofs[l][k] = (k == 0 || lane < 17) ? (c >> 5) * 128 + (c & 31) * 2 : ADUMP + (lane & 15) * 2;
     }
   }
-  char* const dump = reinterpret_cast<char*>(gw + 22 * GW) + (lane & 15) * 2;
-  // chain constants of THIS lane's table entry: lanes 0-8 x offset lane - 4, lanes 9-17 y offset lane - 13 (the rest: unused entries)
-  const bool isx = lane < 9;
-  const float cfd = (float)((isx ? lane : min(lane - 9, 8)) - 4);
-  float csz[4], crs[4], chs[4];
-#pragma unroll
-  for (int l = 0; l < 4; ++l) { csz[l] = isx ? wm1[l] : hm1[l]; crs[l] = 1.0f / csz[l]; chs[l] = csz[l] / 2.f; }   // (IEEE divisions, once per wave)
-  float2* const tab = ctab[wave][0];
-  // pos = c + d; g = 2 pos / (S - 1) - 1; u = (g + 1) * ((S - 1) / 2); weight = u - floor(u);
-  // grid index = clamp(floor(u) - window origin, 0, 10) + origin in the grid. The division is a multiplication by the correctly
-  // rounded reciprocal plus one FMA correction step. That is the correctly rounded quotient whenever the first product is
-  // within one ulp of it (Markstein) — not a theorem for every (t, b); for the divisors this network has (W_l - 1, H_l - 1 of
-  // the four levels at C1 and C2) tests/test_host_arith.py checks the chain against the IEEE division over every position on
-  // a 1/64-pixel lattice across the maps plus 16 pixels of margin, so "the same bits as the division" holds where it is used.
-  auto chain_to_table = [&](const Unit& u, int l, int buf) __attribute__((always_inline)) {
-#pragma clang fp contract(off)   // the same roundings in every unrolled copy (results must not depend on a pixel's slot)
-    const float c0 = isx ? u.xc : u.yc;
-    const int org = isx ? u.wx0 : u.wy0, gorg = isx ? u.wx0 - 8 * u.bx0 : u.wy0 - 4 * u.by0;
-    const float t = 2.f * (c0 + cfd);
-    float q = t * crs[l];
-    q = __builtin_fmaf(__builtin_fmaf(-q, csz[l], t), crs[l], q);          // = t / csz (see above)
-    const float uu = ((q - 1.f) + 1.f) * chs[l];
-    const float fl = floorf(uu);
-    // (a unit that is not sane has its origin at -2^24: the clamp alone keeps the index inside the grid)
-    const int idx = min(max((int)fl - org, 0), 10) + gorg;
-    tab[buf * 64 + lane] = make_float2(uu - fl, __int_as_float(idx));
-  };
-  struct Taps { float ww[2], nn[2]; int off[2]; };   // per pass: x weight, y weight, grid offset (floats) of the top-left tap
-  auto read_table = [&](int buf, Taps& tp) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float2 x = tab[buf * 64 + ex[t]], y = tab[buf * 64 + ey[t]];
-      tp.ww[t] = x.x; tp.nn[t] = y.x;
-      tp.off[t] = __float_as_int(y.y) * GW + __float_as_int(x.y);
-    }
-  };
   auto fence = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // (compiler only: no instruction)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   static_assert(UPW % DEPTH == 0, "units per wave must be a multiple of the prefetch depth");
-  Taps tcur, tnext;
-  chain_to_table(un[0], 0, 0);
-  fence();
-  read_table(0, tcur);
+  float vmax = 0.f;   // largest sample magnitude of this lane: the saturation test of the sf format, once, after the loop
   // the unit loop is unrolled by DEPTH so that the register slots (= levels) are compile-time constants
   for (int pi0 = 0; pi0 < UPW; pi0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int pi = pi0 + d;
       issue(pi + DEPTH - 1, (d + DEPTH - 1) % DEPTH);
-      const Unit u = un[d];
       // window bricks -> grid. No wait: these writes come after the previous unit's sample reads and before this unit's
 #pragma unroll
       for (int k = 0; k < 2; ++k) *reinterpret_cast<v4f*>(gw + gofs[k]) = bv[d][k];
       fence();
+      // the unit's four bilinear products, scalars (nw, ne, sw, se of grid_sample)
+      const float w00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P_w00), pi));
+      const float w01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P_w01), pi));
+      const float w10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P_w10), pi));
+      const float w11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P_w11), pi));
+      const char* q0 = reinterpret_cast<const char*>(gw) + __builtin_amdgcn_readlane(P_gb, pi);
       float q00[2], q01[2], q10[2], q11[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const float* q = gw + tcur.off[t];
+        const float* q = reinterpret_cast<const float*>(q0 + sofs[t]);
         q00[t] = q[0]; q01[t] = q[1]; q10[t] = q[GW]; q11[t] = q[GW + 1];
       }
-      // the next unit's chains -> the other half of the table, and this lane's entries of it back (its coordinates arrived
-      // DEPTH - 2 units ago); both behind the sample reads in the LDS queue
-      chain_to_table(un[(d + 1) % DEPTH], (d + 1) % DEPTH, (d + 1) & 1);
-      fence();
-      read_table((d + 1) & 1, tnext);
       char* arow = atile + (pbase + (pi >> 2)) * APITCH;
+      float va[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        // explicit FMAs: left to itself the compiler fused these products differently in different copies of the unrolled
-        // loop, and a pixel's samples depended on its position in the block (the batch-invariance test caught it)
+        // explicit FMAs in grid_sample's order (nw, ne, sw, se): a pixel's samples must not depend on its position in the
+        // block or on the unrolled copy that computes them (the batch-invariance test)
 #pragma clang fp contract(off)
-        const float ww = tcur.ww[t], nn = tcur.nn[t];
-        const float ee = 1.f - ww, ss = 1.f - nn;
-        float v = __builtin_fmaf(q11[t], ww * nn, __builtin_fmaf(q10[t], ee * nn, __builtin_fmaf(q01[t], ww * ss, q00[t] * (ee * ss))));
-        v = u.sane ? v : 0.f;
-        const SfPair sp = sf_split_flag(v, clamped);
-        // (no branch around the store: lanes past the 81st sample write to the dump rows)
-        _Float16* dst = reinterpret_cast<_Float16*>((t == 0 || lane < 17) ? arow + dofs[d][t] : dump);
-        dst[0] = sp.hi;
-        dst[32] = sp.lo;
+        const float v = __builtin_fmaf(q11[t], w11, __builtin_fmaf(q10[t], w10, __builtin_fmaf(q01[t], w01, q00[t] * w00)));
+        va[t] = v;
+        // split: hi = f16(clamp(v)), lo = f16(v - hi) as one v_fma_mixlo_f16 (the same bits as convert-subtract-convert)
+        const float vc = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+        unsigned hi, lo;
+        asm("v_cvt_f16_f32_e32 %0, %1" : "=v"(hi) : "v"(vc));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(vc));
+        // (no branch around the store: lanes past the 81st sample write to the row's dump bytes)
+        unsigned short* dst = reinterpret_cast<unsigned short*>(arow + dofs[d][t]);
+        dst[0] = (unsigned short)hi;
+        dst[32] = (unsigned short)lo;
       }
-      tcur = tnext;
+      vmax = fmaxf(fmaxf(fabsf(va[0]), fabsf(va[1])), vmax);
     }
   }
+  const bool clamped = !(vmax <= 65504.f);
   sf_report(clamped);
 
   // ---- phase 2: [64 pixels x 352] x convc1^T -> 256 channels on v_mfma_f32_16x16x32_f16. Wave w owns the 16 channels

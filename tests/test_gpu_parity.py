@@ -275,7 +275,7 @@ def test_product_corr_kernels_match_oracle(shape):
     ref_cor1 = F.relu(F.conv2d(ref.double(), wc.double(), bc.double()))
     assert torch.isfinite(cor1).all()
     assert _maxerr(cor1, ref_cor1) < 5e-5 * max(1.0, scale)
-    assert torch.equal(cor1[0, :, 0, 1], F.relu(bc))         # all-zero samples: relu(bias) exactly
+    assert _maxerr(cor1[0, :, 0, 1], F.relu(bc)) < 1e-6      # all-zero samples: relu(bias), to the split-f16 store's 2^-22
 
 
 def test_product_lookup_matches_reference_golden(golden_dir, gsd):

@@ -337,6 +337,29 @@ def test_run_sequence_checks_every_lane_before_the_gather():
     assert tuple(poses.shape) == (9, 4, 4)
 
 
+def test_one_clamp_event_does_not_poison_later_sequences():
+    """finish() used to stop at the first lane whose check raised; the lanes behind it kept a stale ledger position
+    and raised for the SAME event at the end of the next, clean, sequence. Every lane is read before anything is raised."""
+    gsd = syn.to_torch(syn.make_gma_state(seed=1))
+    hsd = syn.to_torch(syn.make_clvo_state(seed=1))
+    main = OdometryPipeline(gsd, hsd, device=DEV, max_batch=2, iters=2)
+    lane = OdometryPipeline(gsd, hsd, device=DEV, max_batch=2, iters=2)
+    frames = _u8_frames(9, 376, 1241, seed=77).pin_memory()
+    main.run_sequence(frames, batch=2, lanes=[lane])          # both lanes have live handles and a clean record
+    bad = RAFTGMA(saturation_check_every=0)                   # a third module of the device clamps, unchecked
+    bad.load_state_dict(_scaled_state({"cnet.conv1": 3e5}))
+    bad = bad.to(DEV).eval()
+    bad._sat_pending = False
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=3)).to(DEV)
+    bad(fr[0:1], fr[1:2], iters=1, test_mode=True)
+    with pytest.raises(SplitF16RangeError):
+        main.run_sequence(frames, batch=2, lanes=[lane])      # the event is attributed to the lanes of the device (too wide, never lost)
+    poses = main.run_sequence(frames, batch=2, lanes=[lane])  # ... once: the next clean sequence runs
+    assert tuple(poses.shape) == (9, 4, 4)
+    with pytest.raises(SplitF16RangeError):
+        bad.check_saturation()                                # and the module that clamped still answers for it
+
+
 def test_clip_modes_are_bit_identical_to_pair_mode():
     """VERDICT r2 ("continued clips equal pair mode only up to kernel-selection rounding"): the statistics convolutions of
     the feature network now pick their tile height — which fixes the 32-pixel groups of the InstanceNorm partial sums — from
