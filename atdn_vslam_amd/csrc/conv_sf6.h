@@ -52,6 +52,8 @@ template <class E, class = void> struct EpiAux4 { struct type {}; };
 template <class E> struct EpiAux4<E, std::void_t<typename E::Aux4>> { using type = typename E::Aux4; };
 template <class E, class = void> struct epi_flowhead : std::false_type {};
 template <class E> struct epi_flowhead<E, std::void_t<decltype(E::kFlowHead)>> : std::bool_constant<E::kFlowHead> {};
+template <class E, class = void> struct epi_rawacc : std::false_type {};
+template <class E> struct epi_rawacc<E, std::void_t<decltype(E::kRawAcc)>> : std::bool_constant<E::kRawAcc> {};
 template <class E, class = void> struct epi_vec4 : std::false_type {};
 template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bool_constant<E::kVec4> {};
 
@@ -79,6 +81,16 @@ template <class E> struct epi_vec4<E, std::void_t<decltype(E::kVec4)>> : std::bo
 //     channels 16 cb + 4 g + 0..3 of pixel 16 half + n.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 struct SfAcc { f32x4v b[2][2]; };
+
+// Diagnostic builds only (python -m atdn_vslam_amd.build --variant stamp -DATDN_CONV_STAMP; tools/diag/conv_stamps.py): where
+// the life of a block of the ConvGRU kernels goes. Wave 0 of every block records s_memtime at its start, after the prologue
+// (first patch published), at the end of the main loop and at the end of the epilogue, the cycles it waited at the chunk
+// barriers, the 100 MHz real-time clock at both ends and the hardware id of its CU. The product build compiles none of it.
+#ifdef ATDN_CONV_STAMP
+#define ATDN_CONV_STAMP_SLOTS 4096
+extern __device__ unsigned long long atdn_conv_stamps_dev[4][ATDN_CONV_STAMP_SLOTS][8];
+template <class E> struct conv_stamp_kind : std::integral_constant<int, -1> {};
+#endif
 
 // ABL (tools/microbench only — diagnostic builds with WRONG results, timing only; the product instantiates ABL = 0): bit 0 no
 // weight loads in the loop, bit 1 no patch refresh (and no chunk-boundary barrier), bit 2 no LDS fragment reads in the loop,
@@ -118,6 +130,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
   const int ty0 = (tloc / g.tiles_x) * TH, tx0 = (tloc % g.tiles_x) * TW;
   const int n0 = tile_n * BN;
   const int lane = tid & 63, wave = tid >> 6;
+#ifdef ATDN_CONV_STAMP
+  constexpr int kStamp = conv_stamp_kind<Epi>::value;
+  unsigned long long st_r0 = 0, st_t0 = 0, st_t1 = 0, st_t2 = 0, st_bar = 0;
+  if constexpr (kStamp >= 0) { st_r0 = __builtin_amdgcn_s_memrealtime(); st_t0 = __builtin_amdgcn_s_memtime(); }
+#endif
 
   // ---- patch loader role (registers, true zero padding)
   // (NORM: its loader writes 8-byte halves, ds_write_b64 = groups of 16 lanes = two patch rows; with rows 4 apart —
@@ -233,6 +250,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
       store_patch(0);
     }
     __syncthreads();
+#ifdef ATDN_CONV_STAMP
+    if constexpr (kStamp >= 0) st_t1 = __builtin_amdgcn_s_memtime();
+#endif
     f16x8 ah[2][TM], al[2][TM];   // [pixel half][row tile]
     auto read_a = [&](int half, int tap) __attribute__((always_inline)) {
       const char* arow = Pb + (tap / KW + half) * RS + (tap % KW) * ROWB;
@@ -313,7 +333,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
         }
         // chunk boundary: publish the next patch image (one barrier)
         if (!(ABL & 2)) {
+#ifdef ATDN_CONV_STAMP
+          unsigned long long st_b0 = 0;
+          if constexpr (kStamp >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_b0 = __builtin_amdgcn_s_memtime(); }
+#endif
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef ATDN_CONV_STAMP
+          if constexpr (kStamp >= 0) st_bar += __builtin_amdgcn_s_memtime() - st_b0;
+#endif
           Pb = Pbytes + ((c + 1) & 1) * PSZ;
         }
         if (!(ABL & 4)) read_a(0, 0);
@@ -321,6 +348,21 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
     }
   }
 
+#ifdef ATDN_CONV_STAMP
+  if constexpr (kStamp >= 0) st_t2 = __builtin_amdgcn_s_memtime();
+  auto stamp_out = [&]() __attribute__((always_inline)) {
+    if constexpr (kStamp >= 0) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the epilogue's stores have left the wave
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      if (wave == 0 && lane == 0 && blockIdx.x < ATDN_CONV_STAMP_SLOTS) {
+        unsigned long long* o = atdn_conv_stamps_dev[kStamp * 2 + (KH == 5 ? 1 : 0)][blockIdx.x];
+        o[0] = st_r0; o[1] = r1; o[2] = st_t1 - st_t0; o[3] = st_t2 - st_t1; o[4] = st_bar; o[5] = t3 - st_t2;
+        o[6] = ((unsigned long long)xcc << 32) | hw; o[7] = t3 - st_t0;
+      }
+    }
+  };
+#endif
   if constexpr ((ABL & 8) != 0) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
     float tot = 0.f;
 #pragma unroll
@@ -355,13 +397,17 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
       return (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
     };
     // one 32-pixel x 32-channel accumulator tile -> the wave's slab [pixel][LDS_LD floats], scaled
+    // (RAW: epilogues that fold the weight scale — a power of two — into their first addition take the accumulators as they are)
+    constexpr bool RAW = epi_rawacc<Epi>::value && !epi_flowhead<Epi>::value;
     auto slab_write = [&](const SfAcc& a) __attribute__((always_inline)) {
+      const float sc = RAW ? 1.0f : g.wscale;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
           *reinterpret_cast<float4*>(tb + (16 * hh + (lane & 15)) * LDS_LD + 16 * cb + 4 * (lane >> 4)) =
-              make_float4(a.b[hh][cb][0] * g.wscale, a.b[hh][cb][1] * g.wscale, a.b[hh][cb][2] * g.wscale, a.b[hh][cb][3] * g.wscale);
+              RAW ? make_float4(a.b[hh][cb][0], a.b[hh][cb][1], a.b[hh][cb][2], a.b[hh][cb][3])
+                  : make_float4(a.b[hh][cb][0] * sc, a.b[hh][cb][1] * sc, a.b[hh][cb][2] * sc, a.b[hh][cb][3] * sc);
     };
     if constexpr (epi_flowhead<Epi>::value) {
       // ---- flow head: relu(conv1) x conv2's weights, reduced to 18 partial sums per pixel (epilogues_sf.h), then the block adds
@@ -498,15 +544,20 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (mq[q] >= 0 && nb < g.N) ep.apply4(img, mq[q], nb, v[q], aux[q], bj, clamped);
+            if (mq[q] >= 0 && nb < g.N) {
+              if constexpr (RAW) ep.apply4(img, mq[q], nb, v[q], aux[q], bj, clamped, g.wscale);
+              else ep.apply4(img, mq[q], nb, v[q], aux[q], bj, clamped);
+            }
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             if (mq[q] < 0) continue;
             if (nb + 4 <= g.N) {
-              ep.store4((ABL & 16) ? 0 : img, mq[q], nb, v[q], bj, clamped);
-            } else {  // N % 4 != 0: the last run is partial, element-wise
-              const float e4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+              if constexpr (RAW) ep.store4((ABL & 16) ? 0 : img, mq[q], nb, v[q], bj, clamped, g.wscale);
+              else ep.store4((ABL & 16) ? 0 : img, mq[q], nb, v[q], bj, clamped);
+            } else {  // N % 4 != 0: the last run is partial, element-wise (scaled accumulators)
+              const float sc = RAW ? g.wscale : 1.0f;
+              const float e4[4] = {v[q].x * sc, v[q].y * sc, v[q].z * sc, v[q].w * sc};
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (nb + e < g.N) ep(img, mq[q], nb + e, e4[e]);
@@ -516,6 +567,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
       }
     }
     sf_report(clamped);
+#ifdef ATDN_CONV_STAMP
+    stamp_out();
+#endif
     return;
   }
   // ---- pixel-major epilogue (TM x TN tiles per wave). A lane owns NSET = 2 channel columns of a 32 x 32 tile (channel

@@ -33,6 +33,10 @@ struct SfBias {
     return bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // (`clamped`: the kernel's saturation flag, reported once after its loops — sf.h, sf_store4_flag)
+  // (Round 5 measured this store with the RAW accumulator and the weight scale folded into the bias addition as an FMA, and
+  // with a scalar base + 32-bit offset address, as the ConvGRU gates now have it (SfGruZR): two fewer vector instructions per
+  // value, but the 128- and 64-wide 3x3 kernels came out at 276 / 188 registers instead of 244 / 168 — one wave per SIMD less —
+  // and cnet / the motion encoder lost 0.1 / 0.3 ms per forward. profiles/r05_ab_sf_ops.txt)
   __device__ __forceinline__ void store4(int img, int m, int n, float4 a, float4 b, bool& clamped) const {
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     if (ACT == ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
@@ -131,19 +135,24 @@ struct SfGruZR {
   static constexpr int kGen6 = 2;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
   struct Aux4 { float4 h, p; };
   __device__ __forceinline__ Aux4 load4(int img, int m, int n) const {
-    return {sf_load4(h, (long)img * ob + (long)m * 128, n & 127),
-            *reinterpret_cast<const float4*>(pre + (long)img * pb + (long)m * 256 + n)};
+    return {sf_load4u(h + (long)img * ob, (unsigned)m * 128u, n & 127),
+            *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pre + (long)img * pb) + 4u * ((unsigned)m * 256u + (unsigned)n))};
   }
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped) const {
+  // kRawAcc (round 5): `a` is the RAW accumulator and `ws` the layer's weight scale, a power of two (weights.h) — so a * ws is
+  // exact and fma(a, ws, p) has the bits of (a * ws) + p: the scaling multiply per value is gone from the epilogue. Addresses:
+  // the image's slice as a scalar base + an unsigned 32-bit offset (sf.h). Both gates together: -0.3 ms per forward
+  // (profiles/r05_ab_sf_ops.txt); the plain-store epilogues lost registers to the same change and keep the old form (SfBias).
+  static constexpr bool kRawAcc = true;
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped, float ws) const {
     float4 v;
-    v.x = sigmoid_fast_((a.x + x.p.x) + b.x);
-    v.y = sigmoid_fast_((a.y + x.p.y) + b.y);
-    v.z = sigmoid_fast_((a.z + x.p.z) + b.z);
-    v.w = sigmoid_fast_((a.w + x.p.w) + b.w);
-    const long o = (long)img * ob + (long)m * 128;
-    if (n < 128) *reinterpret_cast<float4*>(z + o + n) = v;
-    else sf_store4_flag(rh, o, n - 128, make_float4(v.x * x.h.x, v.y * x.h.y, v.z * x.h.z, v.w * x.h.w), clamped);
+    v.x = sigmoid_fast_(__builtin_fmaf(a.x, ws, x.p.x) + b.x);
+    v.y = sigmoid_fast_(__builtin_fmaf(a.y, ws, x.p.y) + b.y);
+    v.z = sigmoid_fast_(__builtin_fmaf(a.z, ws, x.p.z) + b.z);
+    v.w = sigmoid_fast_(__builtin_fmaf(a.w, ws, x.p.w) + b.w);
+    const unsigned o = (unsigned)m * 128u;
+    if (n < 128) *reinterpret_cast<float4*>(reinterpret_cast<char*>(z + (long)img * ob) + 4u * (o + (unsigned)n)) = v;
+    else sf_store4_flag_u(rh + (long)img * ob, o, n - 128, make_float4(v.x * x.h.x, v.y * x.h.y, v.z * x.h.z, v.w * x.h.w), clamped);
   }
 };
 
@@ -174,17 +183,20 @@ struct SfGruQ {
   static constexpr int kGen6 = 2;  // conv_sf6.h kernel shapes: 1 = 3x3, 2 = 1x5 / 5x1
   struct Aux4 { float4 h, z, p; };
   __device__ __forceinline__ Aux4 load4(int img, int m, int n) const {
-    const long o = (long)img * ob + (long)m * 128;
-    return {sf_load4(h, o, n), *reinterpret_cast<const float4*>(z + o + n), *reinterpret_cast<const float4*>(pre + o + n)};
+    const long ib = (long)img * ob;
+    const unsigned o = 4u * ((unsigned)m * 128u + (unsigned)n);
+    return {sf_load4u(h + ib, (unsigned)m * 128u, n), *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(z + ib) + o),
+            *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pre + ib) + o)};
   }
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped) const {
+  static constexpr bool kRawAcc = true;   // see SfGruZR
+  __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped, float ws) const {
     float4 o;
-    o.x = blend(x.z.x, x.h.x, tanh_fast_((a.x + x.p.x) + b.x));
-    o.y = blend(x.z.y, x.h.y, tanh_fast_((a.y + x.p.y) + b.y));
-    o.z = blend(x.z.z, x.h.z, tanh_fast_((a.z + x.p.z) + b.z));
-    o.w = blend(x.z.w, x.h.w, tanh_fast_((a.w + x.p.w) + b.w));
-    sf_store4_flag(hout, (long)img * ob + (long)m * 128, n, o, clamped);
+    o.x = blend(x.z.x, x.h.x, tanh_fast_(__builtin_fmaf(a.x, ws, x.p.x) + b.x));
+    o.y = blend(x.z.y, x.h.y, tanh_fast_(__builtin_fmaf(a.y, ws, x.p.y) + b.y));
+    o.z = blend(x.z.z, x.h.z, tanh_fast_(__builtin_fmaf(a.z, ws, x.p.z) + b.z));
+    o.w = blend(x.z.w, x.h.w, tanh_fast_(__builtin_fmaf(a.w, ws, x.p.w) + b.w));
+    sf_store4_flag_u(hout + (long)img * ob, (unsigned)m * 128u, n, o, clamped);
   }
 };
 

@@ -118,6 +118,24 @@ __device__ __forceinline__ void sf_store4(float* base, long off, int c, float4 v
 // the clamp goes into a register flag that the kernel reports once per wave after the loop (sf_report). sf_store4's counted
 // cold path — a pointer load and an atomic behind a branch — makes the wait-count pass drain every outstanding store and
 // prefetched operand at the join: the ConvGRU epilogues carried an s_waitcnt vmcnt(0) per pixel group (round 4).
+// Round 5: the split and its inverse in the instructions gfx950 has for them. Two conversions round a PAIR to f16
+// (v_cvt_pk_f16_f32), four v_fma_mix form the residuals lo = f16(v - hi) straight into the halves of two registers (fp32
+// arithmetic on an f16 operand, one rounding: the same bits as convert-back, subtract, convert — tools/diag/sf_mix_check.hip):
+// 10 vector instructions to store four values instead of 28 (conversions, subtractions, packing). The stamps of the ConvGRU
+// kernels (tools/diag/conv_stamps.py) put a block's epilogue at 13-21 % of its life, bound by vector-instruction issue beside
+// the partner wave's MFMAs.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sf_cvt_pk_(float a, float b) {
+  const f32x2 x = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));   // v_cvt_pk_f16_f32, round to nearest even
+}
+__device__ __forceinline__ unsigned sf_residual_pk_(unsigned hp, float a, float b) {
+  unsigned d;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hp), "v"(b));
+  return d;
+}
 __device__ __forceinline__ void sf_store4_flag(float* base, long off, int c, float4 v, bool& clamped) {
   // exact: the largest magnitude of the four against the limit (v_max3 + v_max with |.| source modifiers + one compare), and
   // two unordered compares for NaNs, which v_max drops. (Round 4 tested the SUM of the magnitudes here: four in-range values
@@ -125,18 +143,52 @@ __device__ __forceinline__ void sf_store4_flag(float* base, long off, int c, flo
   const float lim = 65504.f;
   const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
   clamped |= !(m <= lim) | __builtin_isunordered(v.x, v.y) | __builtin_isunordered(v.z, v.w);
-  v.x = fminf(fmaxf(v.x, -lim), lim); v.y = fminf(fmaxf(v.y, -lim), lim);
-  v.z = fminf(fmaxf(v.z, -lim), lim); v.w = fminf(fmaxf(v.w, -lim), lim);
-  const SfPair a = sf_split_nocheck_(v.x), b = sf_split_nocheck_(v.y), d = sf_split_nocheck_(v.z), e = sf_split_nocheck_(v.w);
+  v.x = __builtin_amdgcn_fmed3f(v.x, -lim, lim); v.y = __builtin_amdgcn_fmed3f(v.y, -lim, lim);
+  v.z = __builtin_amdgcn_fmed3f(v.z, -lim, lim); v.w = __builtin_amdgcn_fmed3f(v.w, -lim, lim);
+  const unsigned h0 = sf_cvt_pk_(v.x, v.y), h1 = sf_cvt_pk_(v.z, v.w);
+  const unsigned l0 = sf_residual_pk_(h0, v.x, v.y), l1 = sf_residual_pk_(h1, v.z, v.w);
   _Float16* q = sf_ptr(base, off, c);
-  *reinterpret_cast<f16x4*>(q) = f16x4{a.hi, b.hi, d.hi, e.hi};
-  *reinterpret_cast<f16x4*>(q + 32) = f16x4{a.lo, b.lo, d.lo, e.lo};
+  *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(q + 32) = make_uint2(l0, l1);
+}
+// hi + lo: convert, convert, add. (ONE v_fma_mix_f32 per value — hi * 1 + lo in fp32 — gives the same bits,
+// tools/diag/sf_mix_check.hip, and was measured SLOWER in every kernel whose epilogue decodes an operand: cnet +0.24 ms, the z|r
+// gates +0.06 ms per pass and forward, profiles/r05_ab_sf_ops.txt. The residual direction, v_fma_mixlo / mixhi, is neutral to
+// slightly faster and stays.)
+__device__ __forceinline__ float sf_join_lo_(unsigned hi, unsigned lo) {
+  return (float)__builtin_bit_cast(f16x2, hi)[0] + (float)__builtin_bit_cast(f16x2, lo)[0];
+}
+__device__ __forceinline__ float sf_join_hi_(unsigned hi, unsigned lo) {
+  return (float)__builtin_bit_cast(f16x2, hi)[1] + (float)__builtin_bit_cast(f16x2, lo)[1];
 }
 __device__ __forceinline__ float4 sf_load4(const float* base, long off, int c) {
   const _Float16* q = sf_ptr(base, off, c);
-  const f16x4 hi = *reinterpret_cast<const f16x4*>(q), lo = *reinterpret_cast<const f16x4*>(q + 32);
-  return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2],
-                     (float)hi[3] + (float)lo[3]);
+  const uint2 hi = *reinterpret_cast<const uint2*>(q), lo = *reinterpret_cast<const uint2*>(q + 32);
+  return make_float4(sf_join_lo_(hi.x, lo.x), sf_join_hi_(hi.x, lo.x), sf_join_lo_(hi.y, lo.y), sf_join_hi_(hi.y, lo.y));
+}
+// The same two with the address as a UNIFORM base (a scalar register pair: the image's slice of the tensor) plus an unsigned
+// 32-bit element offset: one vector add per access (global_load / global_store with a scalar base) instead of the 64-bit
+// vector arithmetic a `long` offset costs per access (2.4 vector instructions per stored value in the q gate's epilogue).
+// Every tensor of this library is < 4 GB per image slice.
+__device__ __forceinline__ unsigned sf_byte_offset_(unsigned off, int c) {
+  return 4u * (off + (unsigned)(c & ~31)) + 2u * (unsigned)(c & 31);
+}
+__device__ __forceinline__ void sf_store4_flag_u(float* base, unsigned off, int c, float4 v, bool& clamped) {
+  const float lim = 65504.f;
+  const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  clamped |= !(m <= lim) | __builtin_isunordered(v.x, v.y) | __builtin_isunordered(v.z, v.w);
+  v.x = __builtin_amdgcn_fmed3f(v.x, -lim, lim); v.y = __builtin_amdgcn_fmed3f(v.y, -lim, lim);
+  v.z = __builtin_amdgcn_fmed3f(v.z, -lim, lim); v.w = __builtin_amdgcn_fmed3f(v.w, -lim, lim);
+  const unsigned h0 = sf_cvt_pk_(v.x, v.y), h1 = sf_cvt_pk_(v.z, v.w);
+  const unsigned l0 = sf_residual_pk_(h0, v.x, v.y), l1 = sf_residual_pk_(h1, v.z, v.w);
+  char* q = reinterpret_cast<char*>(base) + sf_byte_offset_(off, c);
+  *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(q + 64) = make_uint2(l0, l1);
+}
+__device__ __forceinline__ float4 sf_load4u(const float* base, unsigned off, int c) {
+  const char* q = reinterpret_cast<const char*>(base) + sf_byte_offset_(off, c);
+  const uint2 hi = *reinterpret_cast<const uint2*>(q), lo = *reinterpret_cast<const uint2*>(q + 64);
+  return make_float4(sf_join_lo_(hi.x, lo.x), sf_join_hi_(hi.x, lo.x), sf_join_lo_(hi.y, lo.y), sf_join_hi_(hi.y, lo.y));
 }
 __device__ __forceinline__ float sf_load(const float* base, long off, int c) {
   const _Float16* q = sf_ptr(base, off, c);

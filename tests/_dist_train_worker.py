@@ -21,6 +21,22 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.set_num_threads(2)
+    if len(sys.argv) > 2 and sys.argv[2] == "synthetic":
+        # world-8 rehearsal of the exchange alone (VERDICT r4 #5c): a flat gradient of the trainer's size (5.06 M fp32 = 20 MB,
+        # what one RCCL all-reduce carries per iteration), seeded per rank, averaged, and the same AdamW update on every rank
+        n = 5_063_880
+        g = torch.Generator().manual_seed(1000 + rank)
+        local = torch.randn(n, generator=g)
+        flat = local.clone()
+        allreduce_mean_(flat)
+        w = torch.zeros(n)
+        lr = cosine_lr(0, 1e-3, 10, 1e-9)
+        with torch.no_grad():
+            tr.adamw_step(w, flat, torch.zeros_like(w), torch.zeros_like(w), 1, lr, 1e-3, 1e-8)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), local_head=local[:4096].numpy(), mean_head=flat[:4096].numpy(),
+                 mean_sum=float(flat.double().sum()), w_sum=float(w.double().sum()), w_head=w[:4096].numpy())
+        dist.destroy_process_group()
+        return
     B, T = 2, 2
     P, S = tr.split_state(syn.to_torch(syn.make_clvo_state(seed=1)))
     keys = [k for k in P if not k.startswith("polar_norm.")]

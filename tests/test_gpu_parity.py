@@ -115,6 +115,35 @@ HALO_CASES = [
 ]
 
 
+STRIDE2_CASES = [
+    # (Cin, Cout, H, W, nimg): the encoders' stride-2 3x3 convolutions (layer2.0 / layer3.0 conv1), split-f16 store.
+    # (Round 5 built a stride-2 form of the halo-patch kernel for them — tools/ab/r05_stride2.patch — which these cases
+    # verified; it lost to the GEMM-shaped kernel they run on and is not in the tree)
+    (64, 96, 188, 616, 2),     # fnet / cnet layer2.0.conv1 at KITTI size
+    (96, 128, 94, 308, 3),     # layer3.0.conv1
+    (64, 96, 21, 37, 5),       # odd sizes: ragged tiles on both axes, last input row / column is padding for some taps
+    (96, 128, 40, 52, 2),      # even sizes: the last tap column lies outside the image
+]
+
+
+@pytest.mark.parametrize("case", STRIDE2_CASES)
+def test_split_f16_stride2_halo_kernel_matches_fp64(case):
+    cin, cout, H, W, nimg = case
+    r = np.random.RandomState(hash(case) & 0xFFFF)
+    x = torch.from_numpy(r.normal(0, 1, (nimg, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((r.uniform(-1, 1, (cout, cin, 3, 3)) * np.sqrt(3.0 / (cin * 9))).astype(np.float32))
+    b = torch.from_numpy(r.uniform(-0.5, 0.5, (cout,)).astype(np.float32))
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    xd = _nhwc(x).to(DEV)
+    out = torch.full((nimg, ref.shape[2], ref.shape[3], cout), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.check(_lib.lib().atdn_conv2d_nhwc_sf_epi(_vp(xd), nimg, H, W, cin, _vp(w), _vp(b), cout, 3, 3, 2, 1, 1, 1,
+                                                  _vp(out), _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert _maxerr(got, ref) < 2e-5, _maxerr(got, ref)
+
+
 @pytest.mark.parametrize("sf_out", [0, 1])
 @pytest.mark.parametrize("case", HALO_CASES)
 def test_split_f16_halo_kernels_match_fp64(case, sf_out):

@@ -51,9 +51,22 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if rank == 0:
+        # roofline of the iteration: the head's convolutions are 0.635 GMAC per flow frame forward (SURVEY appendix
+        # A) on the exact-fp32 matrix core (v_mfma_f32_16x16x4_f32), the backward pass is two GEMMs of the same size per layer
+        # (data and weight gradients), the fully connected / LSTM tail 5.03 MMAC x 3; bytes: every flow frame is read once
+        # (2 x 376 x 1232 fp32) and the stem's 16-channel activation at 188 x 616 is written forward and read backward
+        frames = a.batch * a.seq
+        flop = frames * 3.0 * 2.0 * (0.635e9 + 5.03e6)
+        sec = dt / a.steps
+        by = frames * (2 * 376 * 1232 * 4.0 + 2 * 16 * 188 * 616 * 4.0)
         print(json.dumps({"metric": "CLVO training flow-frames/s (forward + backward + AdamW)", "value": world * a.batch * a.seq * a.steps / dt,
                           "unit": "flow frames/s", "n_gpus": world, "ms_per_iteration": dt * 1e3 / a.steps, "batch_per_gpu": a.batch,
-                          "sequence_length": a.seq, "loss_first": losses[0], "loss_last": losses[-1]}))
+                          "sequence_length": a.seq, "loss_first": losses[0], "loss_last": losses[-1],
+                          "roofline": {"bound": "mfma", "achieved": flop / sec / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                       "frac": flop / sec / 1e12 / 157.3, "algorithmic_flop_per_iteration": flop,
+                                       "note": "fp32 MFMA peak (the trainer computes in exact fp32); per GPU"},
+                          "hbm": {"algorithmic_bytes_per_iteration": by, "achieved_GBps": by / sec / 1e9, "peak_GBps": 8000.0,
+                                  "frac": by / sec / 1e9 / 8000.0}}))
     if world > 1:
         dist.destroy_process_group()
 

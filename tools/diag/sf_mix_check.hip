@@ -8,6 +8,28 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
+// Round 5 (adopted in sf.h): also the pair conversion v_cvt_pk_f16_f32 against two v_cvt_f16_f32, and the inverse
+// hi + lo as ONE v_fma_mix_f32 per value against convert, convert, add.
+__global__ void k2(const float* v, unsigned* bad, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * i + 1 >= n) return;
+  const float a = v[2 * i], b = v[2 * i + 1];
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const h2 hi = {(_Float16)a, (_Float16)b};
+  const h2 lo = {(_Float16)(a - (float)hi[0]), (_Float16)(b - (float)hi[1])};
+  const f2 x = {a, b};
+  const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x, h2));
+  unsigned nb = 0;
+  if (hp != __builtin_bit_cast(unsigned, hi)) nb |= 1;
+  const unsigned lp = __builtin_bit_cast(unsigned, lo);
+  float j0, j1;
+  asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(j0) : "v"(hp), "v"(lp));
+  asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(j1) : "v"(hp), "v"(lp));
+  const float r0 = (float)hi[0] + (float)lo[0], r1 = (float)hi[1] + (float)lo[1];
+  if (__float_as_uint(j0) != __float_as_uint(r0) || __float_as_uint(j1) != __float_as_uint(r1)) nb |= 2;
+  if (nb) atomicOr(bad, nb), atomicAdd(bad + 1, 1u);
+}
 __global__ void k(const float* v, unsigned* ref, unsigned* mix, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (2 * i + 1 >= n) return;
@@ -42,5 +64,9 @@ int main() {
   long bad = 0;
   for (int i = 0; i < n / 2; ++i) if (r[i] != m[i]) { if (bad < 5) printf("mismatch %d: %08x vs %08x (v %g %g)\n", i, r[i], m[i], v[2*i], v[2*i+1]); ++bad; }
   printf("v_fma_mix residual vs convert-subtract-convert: %ld mismatching pairs of %d\n", bad, n / 2);
+  unsigned* db; hipMalloc(&db, 8); hipMemset(db, 0, 8);
+  hipLaunchKernelGGL(k2, dim3(n / 2 / 256), dim3(256), 0, 0, dv, db, n);
+  unsigned hb[2]; hipMemcpy(hb, db, 8, hipMemcpyDeviceToHost);
+  printf("v_cvt_pk_f16_f32 vs two conversions, v_fma_mix_f32 join vs convert-convert-add: flags %u (1 = pair conversion, 2 = join), %u mismatching pairs of %d\n", hb[0], hb[1], n / 2);
   return 0;
 }
