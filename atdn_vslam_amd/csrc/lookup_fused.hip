@@ -31,8 +31,14 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int TP = 64;            // source pixels per block (round 3: 64 — the convc1 phase was bound by the L1 rate of its weight loads,
-                                  // a block multiplies twice the pixels with every weight fragment it fetches)
+constexpr int LP = kBrickPixelBlock;   // pixels per pixel block of the bricked pyramid (the layout's unit, kernels.h)
+constexpr int TP = 32;            // source pixels per block of THIS kernel: half a pixel block. Round 3 went from 32 to 64 (one block of 16
+                                  // waves per CU: the convc1 phase was bound by the L1 rate of its weight loads, and a block multiplies
+                                  // twice the pixels with every weight fragment it fetches). Round 5, with the sampling phase on its
+                                  // diet, that phase was 35 % of the kernel and strictly serial behind the sampling (ONE block per CU:
+                                  // nothing overlaps anything, not even the next block's start-up): back to 32 pixels and 8 waves so
+                                  // that TWO blocks share a CU and one's matrix phase runs under the other's sampling: 183 -> 171 us
+                                  // per launch (profiles/r05_ab_lookup_half_blocks.txt).
 constexpr int NCH = 352;          // 4 * 81 samples padded to a multiple of 32
 constexpr int APITCH = 1504;      // bytes per pixel row of the A tile: 11 x 128 + 96 = 94 slots of 16 B, 94 = 2 (mod 4): conflict-free
                                   // ds_read_b128 for the operand lane map of v_mfma_f32_16x16x32_f16 (16 pixels x 4 slots per instruction).
@@ -46,8 +52,8 @@ constexpr int GW = 24, GH = 24;   // per-wave window grid: 3 x 4 bricks (24 x 16
                                   // the kernel's LDS cycles.) Rows 16-23 are a dump for the lanes without a brick: the unit
                                   // body has NO branch (a branch around an LDS store made the compiler drain every prefetched load,
                                   // vmcnt(0), per unit)
-constexpr int DEPTH = 4;          // (pixel, level) units in flight per wave
-constexpr int NWAVE = 16;         // waves per block (one 1024-thread block per CU): wave w samples all four levels of pixels 4 w .. 4 w + 3
+constexpr int DEPTH = 4;          // (pixel, level) units in flight per wave (a multiple of the four levels; 8 in flight: 4 % SLOWER, round 5)
+constexpr int NWAVE = TP / 4;     // waves per block: wave w samples all four levels of pixels 4 w .. 4 w + 3
 constexpr int UPW = TP * 4 / NWAVE;   // units (pixels of its level) per wave
 
 // One (pixel, level) unit — round 5: the sampling unit on an instruction diet (rounds 3-4: ~101 vector ALU + 15 LDS instructions
@@ -73,7 +79,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // FUSED: multiply the sampled tile with convc1 and store relu(. + bias) as sf rows [pixel][256];
 // !FUSED: store the sampled tile itself as sf rows [pixel][352] (debug reads, the unfused comparison path)
 template <bool FUSED, bool FAST>
-__global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickPyramid pyr, const float* __restrict__ coords1,
+__global__ __launch_bounds__(NWAVE * 64, TP == 32 ? 4 : 1) void lookup_conv_kernel(const BrickPyramid pyr, const float* __restrict__ coords1,
                                                             const long npix, float* __restrict__ coords_used,
                                                             const float* __restrict__ wfrag, const float wscale,
                                                             const float* __restrict__ bias, float* __restrict__ out) {
@@ -82,12 +88,13 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (tells the compiler what the hardware guarantees: wave-uniform)
-  // block = one pixel block of one pair (the last block of a pair is partial when N % 64 != 0)
-  static_assert(TP == kBrickPixelBlock, "a block of this kernel is one pixel block of the bricked pyramid");
+  // block = TP consecutive pixels of one pair: a pixel block of the pyramid, or half of one (the last block of a pair is partial)
+  static_assert(LP % TP == 0 && TP % 16 == 0 && TP <= 64, "a block of this kernel is a whole fraction of a pixel block");
   const int bpp = (pyr.N + TP - 1) / TP;                        // blocks per pair
-  const int pair = (int)blockIdx.x / bpp, pblk = (int)blockIdx.x - pair * bpp;
-  const long p0 = (long)pair * pyr.N + (long)pblk * TP;         // first pixel of the block in coords1 / out
-  const int np = min(TP, pyr.N - pblk * TP);
+  const int pair = (int)blockIdx.x / bpp, kblk = (int)blockIdx.x - pair * bpp;
+  const int pblk = (kblk * TP) / LP, poff = (kblk * TP) % LP;   // the pyramid's pixel block, and this block's first line inside its brick runs
+  const long p0 = (long)pair * pyr.N + (long)kblk * TP;         // first pixel of the block in coords1 / out
+  const int np = min(TP, pyr.N - kblk * TP);
   (void)npix;
 
   // pad channels 324..351 of every row are zero
@@ -103,10 +110,9 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
   // hit L2 / the Infinity Cache — set the pace and the other twelve waited at the block barrier: `SQ_WAIT_ANY` 0.45.) Units run
   // in the order (pixel, level) with the level fastest, so unit pi has level pi & 3 = its slot in the DEPTH-4 ring: every
   // level-dependent quantity is indexed by a compile-time slot.
-  static_assert(DEPTH == 4, "unit pi has level pi & 3 = pi % DEPTH");
+  static_assert(DEPTH % 4 == 0, "unit pi has level pi & 3 = (pi % DEPTH) & 3");
   const int pbase = wave * (UPW / 4);
   // coordinates of the block's pixels: lane i holds pixel i (pixels past the end repeat the last one; never stored)
-  static_assert(TP == 64, "one lane per pixel of the block");
   const long pc = p0 + min(lane, np - 1);
   const float2 cmine = *reinterpret_cast<const float2*>(coords1 + pc * 2);
   if (wave == 0 && lane < np && coords_used) *reinterpret_cast<float2*>(coords_used + (p0 + lane) * 2) = cmine;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
     const unsigned cm = (1u << (chi & 31)) - (1u << (clo & 31));                                   // 0 when the range is empty
     const unsigned rm = 0x249u & ((1u << ((3 * rhi) & 31)) - (1u << ((3 * rlo) & 31)));            // bit 3 r for r in [rlo, rhi)
     P_m12 = (int)((clo < 3 && rlo < 4) ? rm * cm : 0u);                                            // (shift counts are in range then)
-    P_sb = (by0 * BWl + bx0) * (TP * 128);     // (wraps for origins outside the map: those lanes are masked)
+    P_sb = (by0 * BWl + bx0) * (LP * 128);     // (wraps for origins outside the map: those lanes are masked)
   }
 
   v4f bv[DEPTH][2];
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
 #pragma unroll
   for (int l = 0; l < 4; ++l)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) loff[l][k] = (byi[k] * pyr.BW[l] + bxi[k]) * (TP * 128) + (lane & 7) * 16;
+    for (int k = 0; k < 2; ++k) loff[l][k] = (byi[k] * pyr.BW[l] + bxi[k]) * (LP * 128) + (lane & 7) * 16;
   const int big = 0x7FFFFFF0;   // an offset past the end of every level: the load returns zeros
   auto rep8 = [](unsigned m8) __attribute__((always_inline)) {   // bit b of m8 -> bits 8 b .. 8 b + 7 (scalar unit)
     unsigned long long r;
@@ -183,23 +189,24 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
     asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(r) : "s"((unsigned)r));
     return r;
   };
-  auto issue = [&](int pi, int l) __attribute__((always_inline)) {   // l = pi & 3: level of the unit AND its ring slot
+  auto issue = [&](int pi, int sl) __attribute__((always_inline)) {   // sl = pi % DEPTH: ring slot of the unit; its level is sl & 3
+    const int l = sl & 3;
     const int pp = min(pbase + (pi >> 2), np - 1);
     // (units past the wave's 16th — the prefetches behind the last one — read the copies in lanes 16 .. 18: valid, unused)
     const unsigned m12 = (unsigned)__builtin_amdgcn_readlane(P_m12, pi);
-    const int sbase = __builtin_amdgcn_readlane(P_sb, pi) + pp * 128;
+    const int sbase = __builtin_amdgcn_readlane(P_sb, pi) + (poff + pp) * 128;
     const unsigned long long lm0 = rep8(m12 & 0xFFu), lm1 = rep8(m12 >> 8);
     // the pixel's map of this level as a buffer: a lane whose brick is outside the window or outside the map gets an offset
     // past the end, and the load returns zeros by itself (they ARE grid_sample's zero padding): no select on the data
     // (the pixel block's level as a buffer of NBK x 64 lines; the unit's pixel selects the line inside a brick's 8 KB run)
     const long NBl = pyr.NB[l];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(pyr.base[l] + ((long)pair * pyr.NPB + pblk) * NBl * TP), 0, (int)(NBl * TP * 4), 0x00020000);
+        const_cast<float*>(pyr.base[l] + ((long)pair * pyr.NPB + pblk) * NBl * LP), 0, (int)(NBl * LP * 4), 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       int off;
       asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "v"(big), "v"(loff[l][k] + sbase), "s"(k == 0 ? lm0 : lm1));
-      bv[l][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+      bv[sl][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
 #pragma unroll
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
         asm("v_cvt_f16_f32_e32 %0, %1" : "=v"(hi) : "v"(vc));
         asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(vc));
         // (no branch around the store: lanes past the 81st sample write to the row's dump bytes)
-        unsigned short* dst = reinterpret_cast<unsigned short*>(arow + dofs[d][t]);
+        unsigned short* dst = reinterpret_cast<unsigned short*>(arow + dofs[d & 3][t]);
         dst[0] = (unsigned short)hi;
         dst[32] = (unsigned short)lo;
       }
@@ -280,23 +287,28 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
   const bool clamped = !(vmax <= 65504.f);
   sf_report(clamped);
 
-  // ---- phase 2: [64 pixels x 352] x convc1^T -> 256 channels on v_mfma_f32_16x16x32_f16. Wave w owns the 16 channels
-  // 16 w .. 16 w + 15 for ALL 64 pixels (four 16-pixel column blocks), so the block fetches the 352 x 256 weight matrix
-  // exactly once (352 KiB per 64 pixels; the 8-wave / 32-pixel block of round 2 fetched it once per 32 pixels and was
-  // bound by the L1 rate of those loads: 5,600 cycles at 64 B/clk against 4,200 cycles of MFMA per block). Weights come
-  // straight from L2 in operand order (weights.h: pack_fragment_major16, one contiguous KiB per wave load) through a ring
-  // of WD chunks, the first WD requested BEFORE the barrier that ends the sampling phase; weights are the row operand, so
-  // lane (n, g) ends up with channels 16 w + 4 g + 0..3 of pixel 16 pb + n and stores 8 + 8 bytes.
+  // ---- phase 2: [TP pixels x 352] x convc1^T -> 256 channels on v_mfma_f32_16x16x32_f16. Wave w owns the CB 16-channel blocks
+  // 16 (CB w + cb) .. + 15 for ALL TP pixels (PB 16-pixel column blocks): the block fetches the 352 x 256 weight matrix exactly
+  // once (352 KiB per TP pixels), straight from L2 in operand order (weights.h: pack_fragment_major16, one contiguous KiB per wave
+  // load) through a ring of WD chunks, the first WD requested BEFORE the barrier that ends the sampling phase; weights are the
+  // row operand, so lane (n, g) ends up with channels 16 (CB w + cb) + 4 g + 0..3 of pixel 16 pb + n and stores 8 + 8 bytes.
+  // (At TP = 32 the matrix is fetched once per 32 pixels — 5,600 cycles of the L1's 64 B/clk per block, the rate that bound the
+  // 32-pixel block of round 2 — but now under the OTHER resident block's sampling phase, which needs the L1 for 100 KB of bricks.)
   constexpr int NQ = NCH / 32;
   constexpr int WD = 4;
+  constexpr int CB = 256 / 16 / NWAVE, PB = TP / 16;
+  static_assert(CB * NWAVE * 16 == 256, "the block's waves cover convc1's 256 output channels");
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   const int n16 = lane & 15, g16 = lane >> 4;
-  const char* wbase = reinterpret_cast<const char*>(wfrag) + (long)wave * NQ * 2048 + lane * 16;
-  f16x8 wh[WD], wl[WD];
+  const char* wbase = reinterpret_cast<const char*>(wfrag) + (long)(wave * CB) * NQ * 2048 + lane * 16;
+  f16x8 wh[WD][CB], wl[WD][CB];
   auto load_w = [&](int slot, int q) __attribute__((always_inline)) {
-    const char* p = wbase + (long)q * 2048;
-    wh[slot] = *reinterpret_cast<const f16x8*>(p);
-    if (!FAST) wl[slot] = *reinterpret_cast<const f16x8*>(p + 1024);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const char* p = wbase + ((long)cb * NQ + q) * 2048;
+      wh[slot][cb] = *reinterpret_cast<const f16x8*>(p);
+      if (!FAST) wl[slot][cb] = *reinterpret_cast<const f16x8*>(p + 1024);
+    }
   };
   if (FUSED) {
 #pragma unroll
@@ -313,37 +325,44 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void lookup_conv_kernel(const BrickP
     return;
   }
 
-  f32x4v acc[4];   // [pixel block]
+  f32x4v acc[CB][PB];
 #pragma unroll
-  for (int pb = 0; pb < 4; ++pb)
+  for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[pb][e] = 0.f;
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[cb][pb][e] = 0.f;
   const char* arow = atile + n16 * APITCH + 16 * g16;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
+    for (int pb = 0; pb < PB; ++pb) {
       const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + 16 * pb * APITCH + q * 128);
-      f32x4v c = acc[pb];
-      if (!FAST) {
-        const f16x8 al = *reinterpret_cast<const f16x8*>(arow + 16 * pb * APITCH + q * 128 + 64);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q % WD], al, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q % WD], ah, c, 0, 0, 0);
+      f16x8 al = ah;
+      if (!FAST) al = *reinterpret_cast<const f16x8*>(arow + 16 * pb * APITCH + q * 128 + 64);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        f32x4v c = acc[cb][pb];
+        if (!FAST) {
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q % WD][cb], al, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q % WD][cb], ah, c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q % WD][cb], ah, c, 0, 0, 0);
+        acc[cb][pb] = c;
       }
-      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q % WD], ah, c, 0, 0, 0);
-      acc[pb] = c;
     }
     if (q + WD < NQ) load_w(q % WD, q + WD);
   }
-  {
-    const int c = 16 * wave + 4 * g16;
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const int c = 16 * (wave * CB + cb) + 4 * g16;
     const float4 b = *reinterpret_cast<const float4*>(bias + c);
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
+    for (int pb = 0; pb < PB; ++pb) {
       const int px = 16 * pb + n16;
       if (px < np) {
-        const float4 o = make_float4(fmaxf(acc[pb][0] * wscale + b.x, 0.f), fmaxf(acc[pb][1] * wscale + b.y, 0.f),
-                                     fmaxf(acc[pb][2] * wscale + b.z, 0.f), fmaxf(acc[pb][3] * wscale + b.w, 0.f));
+        const float4 o = make_float4(fmaxf(acc[cb][pb][0] * wscale + b.x, 0.f), fmaxf(acc[cb][pb][1] * wscale + b.y, 0.f),
+                                     fmaxf(acc[cb][pb][2] * wscale + b.z, 0.f), fmaxf(acc[cb][pb][3] * wscale + b.w, 0.f));
         sf_store4(out + (p0 + px) * 256, 0, c, o);
       }
     }
