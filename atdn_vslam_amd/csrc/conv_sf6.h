@@ -184,17 +184,29 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
     nmu = *reinterpret_cast<const float4*>(g.in_mean + (long)img * g.C0 + (c << 5) + 4 * s);
     nrs = *reinterpret_cast<const float4*>(g.in_rstd + (long)img * g.C0 + (c << 5) + 4 * s);
   };
+  // (round 5: the split of the four normalised values as two pair conversions + four v_fma_mix residuals with the saturation
+  // flag in a register — sf.h — instead of four counted sf_split calls, each with a compare, a two-instruction clamp, three
+  // conversions, a subtraction and a cold branch to the device counter: the normalise-on-load loop carried 465 vector
+  // instructions per 324 MFMAs against 151 in the plain loader)
+  bool norm_sat = false;
   auto store_row_norm = [&](int buf, int k, float4 mu, float4 rs) {
-    const bool ok = (pmeta[k] >> 12) != 0;
+    // ReLU, the format's clamp and the zero padding in ONE v_med3 per value: the upper limit is 65504 for a pixel of the image
+    // and 0 for a padding pixel (whose registers hold some other pixel's data)
+    const float hi = (pmeta[k] >> 12) != 0 ? 65504.f : 0.f;
     float4 v = pr[k];
-    v.x = fmaxf((v.x - mu.x) * rs.x, 0.f); v.y = fmaxf((v.y - mu.y) * rs.y, 0.f);
-    v.z = fmaxf((v.z - mu.z) * rs.z, 0.f); v.w = fmaxf((v.w - mu.w) * rs.w, 0.f);
-    v = keep_if(ok, v);
-    const SfPair a = sf_split(v.x), b = sf_split(v.y), d = sf_split(v.z), e = sf_split(v.w);
+    v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y; v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
+    // (a NaN of the raw tensor is dropped by the maximum below and by v_med3, as fmaxf(., 0) dropped it before: it shows as 0
+    // here and as a NaN in the statistics of the producer, which has already flagged it)
+    const float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    norm_sat |= !(m <= 65504.f);
+    v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, hi); v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, hi);
+    v.z = __builtin_amdgcn_fmed3f(v.z, 0.f, hi); v.w = __builtin_amdgcn_fmed3f(v.w, 0.f, hi);
+    const unsigned h0 = sf_cvt_pk_(v.x, v.y), h1 = sf_cvt_pk_(v.z, v.w);
+    const unsigned l0 = sf_residual_pk_(h0, v.x, v.y), l1 = sf_residual_pk_(h1, v.z, v.w);
     // the 16-byte slot field addresses slot s of the pixel: its 128-byte chunk starts s slots earlier
     char* px = Pbytes + buf * PSZ + (((pmeta[k] & 0xFFFu) - (unsigned)s) << 4);
-    *reinterpret_cast<f16x4*>(px + 8 * s) = f16x4{a.hi, b.hi, d.hi, e.hi};
-    *reinterpret_cast<f16x4*>(px + 64 + 8 * s) = f16x4{a.lo, b.lo, d.lo, e.lo};
+    *reinterpret_cast<uint2*>(px + 8 * s) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(px + 64 + 8 * s) = make_uint2(l0, l1);
   };
 
   // ---- MFMA roles
@@ -363,6 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
     }
   };
 #endif
+  if constexpr (NORM) sf_report(norm_sat);
   if constexpr ((ABL & 8) != 0) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
     float tot = 0.f;
 #pragma unroll
@@ -600,6 +613,25 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
       const int oy = ty0 + p / TW, ox = tx0 + p % TW;
       mm[e] = (oy < g.Ho && ox < g.Wo) ? oy * g.Wo + ox : -1;
     }
+    // statistics epilogues (round 5: instruction count — the kernels with this epilogue ran 3.7-5.2 vector instructions per
+    // MFMA): what depends on the pixels alone is formed once per row tile, not once per channel column — the valid-pixel count of
+    // the 32-pixel group (the same in every lane: lanes differ in their channel), its reciprocal, the element offsets of the
+    // eight pixels; a group without padding pixels (all but the tiles on the right and bottom edge) takes a path without masks;
+    // and the stored value is the one the statistics were formed from, not a second bias addition.
+    int cnt = 0;
+    unsigned mo[NPX];
+    if constexpr (Epi::kStats) {
+#pragma unroll
+      for (int e = 0; e < NPX; ++e) {
+        cnt += mm[e] >= 0 ? 1 : 0;
+        mo[e] = (unsigned)max(mm[e], 0) * (unsigned)ep.ld;
+      }
+      cnt += __shfl_xor(cnt, 16);
+      cnt += __shfl_xor(cnt, 32);
+      cnt = __builtin_amdgcn_readfirstlane(cnt);
+    }
+    const bool full = cnt == 32;
+    const float inv_cnt = 1.0f / (float)(cnt > 0 ? cnt : 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -611,22 +643,31 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
           // lanes that hold the same channel (lane ^ 16, lane ^ 32)
           const float bias = nok ? biasj[j][cs] : 0.f;
           float v[NPX];
-          float sum = 0.f;
-          int cnt = 0;
 #pragma unroll
-          for (int e = 0; e < NPX; ++e) {
-            v[e] = val_of(acc[i][j], cs, e) * g.wscale + bias;
-            if (mm[e] >= 0) { sum += v[e]; ++cnt; }
+          for (int e = 0; e < NPX; ++e) v[e] = __builtin_fmaf(val_of(acc[i][j], cs, e), g.wscale, bias);
+          float sum, m2;
+          if (full) {
+            sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          } else {
+            sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < NPX; ++e) sum += mm[e] >= 0 ? v[e] : 0.f;
           }
           sum += __shfl_xor(sum, 16);
-          cnt += __shfl_xor(cnt, 16);
           sum += __shfl_xor(sum, 32);
-          cnt += __shfl_xor(cnt, 32);
-          const float mean = sum / (float)(cnt > 0 ? cnt : 1);
-          float m2 = 0.f;
+          const float mean = sum * inv_cnt;
+          if (full) {
+            float d[NPX];
 #pragma unroll
-          for (int e = 0; e < NPX; ++e)
-            if (mm[e] >= 0) { const float d = v[e] - mean; m2 += d * d; }
+            for (int e = 0; e < NPX; ++e) d[e] = v[e] - mean;
+            m2 = __builtin_fmaf(d[1], d[1], d[0] * d[0]);
+#pragma unroll
+            for (int e = 2; e < NPX; ++e) m2 = __builtin_fmaf(d[e], d[e], m2);
+          } else {
+            m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < NPX; ++e) { const float dd = mm[e] >= 0 ? v[e] - mean : 0.f; m2 = __builtin_fmaf(dd, dd, m2); }
+          }
           m2 += __shfl_xor(m2, 16);
           m2 += __shfl_xor(m2, 32);
           const int grp = tloc * (TH * TW / 32) + wm * TM + i;
@@ -636,6 +677,13 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
             ep.part_m2[o] = m2;
           }
           if (lane == 0 && n == 0) ep.part_cnt[(long)img * ep.groups_per_img + grp] = (float)cnt;
+          if (nok) {   // the raw value: scalar base of the image's slice + 32-bit element offset
+            char* ob = reinterpret_cast<char*>(ep.dst + (long)img * ep.ob);
+#pragma unroll
+            for (int e = 0; e < NPX; ++e)
+              if (full || mm[e] >= 0) *reinterpret_cast<float*>(ob + 4u * (mo[e] + (unsigned)n)) = v[e];
+          }
+          continue;
         }
         if (nok) {
           if constexpr (Epi::kPrefetch) {
