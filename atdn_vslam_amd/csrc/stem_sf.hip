@@ -81,11 +81,16 @@ __global__ __launch_bounds__(256, MODE == 1 ? 4 : 3) void stem_sf_kernel(const S
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int p = tid + 256 * k;
-      if (p < PR * PC) {
-        const SfPair x = sf_split_flag(v[k].x, clamped), y = sf_split_flag(v[k].y, clamped),
-                     z = sf_split_flag(v[k].z, clamped), w = sf_split_flag(v[k].w, clamped);
-        *reinterpret_cast<f16x4*>(lds + p * 8) = f16x4{x.hi, y.hi, z.hi, w.hi};
-        *reinterpret_cast<f16x4*>(lds + PLANE + p * 8) = f16x4{x.lo, y.lo, z.lo, w.lo};
+      if (p < PR * PC) {   // (round 5: the packed split of sf.h — two pair conversions, four v_fma_mix residuals, one range test)
+        float4 x = v[k];
+        const float m = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+        clamped |= !(m <= 65504.f) | __builtin_isunordered(x.x, x.y) | __builtin_isunordered(x.z, x.w);
+        x.x = __builtin_amdgcn_fmed3f(x.x, -65504.f, 65504.f); x.y = __builtin_amdgcn_fmed3f(x.y, -65504.f, 65504.f);
+        x.z = __builtin_amdgcn_fmed3f(x.z, -65504.f, 65504.f); x.w = __builtin_amdgcn_fmed3f(x.w, -65504.f, 65504.f);
+        const unsigned h0 = sf_cvt_pk_(x.x, x.y), h1 = sf_cvt_pk_(x.z, x.w);
+        const unsigned l0 = sf_residual_pk_(h0, x.x, x.y), l1 = sf_residual_pk_(h1, x.z, x.w);
+        *reinterpret_cast<uint2*>(lds + p * 8) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(lds + PLANE + p * 8) = make_uint2(l0, l1);
       }
     }
     sf_report(clamped);
@@ -191,12 +196,17 @@ __global__ __launch_bounds__(256, MODE == 1 ? 4 : 3) void stem_sf_kernel(const S
             const float4 rs = *reinterpret_cast<const float4*>(&cst[2][c]);
             x[0] = (x[0] - mu.x) * rs.x; x[1] = (x[1] - mu.y) * rs.y; x[2] = (x[2] - mu.z) * rs.z; x[3] = (x[3] - mu.w) * rs.w;
           }
-          SfPair s[4];
+          // ReLU and the format's clamp in one v_med3 per value; the range test on the largest of the four (a NaN: the
+          // unordered compares — v_max and v_med3 drop it)
+          const float m = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+          clamped |= !(m <= 65504.f) | __builtin_isunordered(x[0], x[1]) | __builtin_isunordered(x[2], x[3]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s[e] = sf_split_flag(fmaxf(x[e], 0.f), clamped);
+          for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(x[e], 0.f, 65504.f);
+          const unsigned h0 = sf_cvt_pk_(x[0], x[1]), h1 = sf_cvt_pk_(x[2], x[3]);
+          const unsigned l0 = sf_residual_pk_(h0, x[0], x[1]), l1 = sf_residual_pk_(h1, x[2], x[3]);
           char* d = slab + r * SLAB_PITCH + j * 128 + (8 * k + 4 * h) * 2;
-          *reinterpret_cast<f16x4*>(d) = f16x4{s[0].hi, s[1].hi, s[2].hi, s[3].hi};
-          *reinterpret_cast<f16x4*>(d + 64) = f16x4{s[0].lo, s[1].lo, s[2].lo, s[3].lo};
+          *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(d + 64) = make_uint2(l0, l1);
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
