@@ -26,7 +26,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # epilogues that run beside other waves' MFMAs those are no faster than the scalar forms (MI355X_MICROARCH.md, constants table),
 # and the register-pair shuffles they need are extra instructions in loops bound by instruction issue. Whole forward, same job:
 # 41.67 -> 41.35 ms per 16 pairs (cnet -3 %, motion encoder -2 %, lookup -3 %, flow head -1.5 %; q gate +0.7 %, softmax +1 %).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# -mllvm -amdgpu-mfma-vgpr-form=1 (round 5): MFMA results in ordinary vector registers. Left to itself the register allocator keeps
+# accumulators in the accumulation half of the file and pays for it in copies — the chunk loop of the 64-wide 3x3 kernel carried 24
+# v_accvgpr_write + 24 v_accvgpr_read + 24 v_accvgpr_mov per 324 MFMAs (tools/diag/isa_loop_census.py) — and in registers: with the
+# flag 198 of the library's 406 kernels use fewer (the 128-wide normalise-on-load kernel 276 -> 248: two waves per SIMD instead of
+# one; the GEMM-shaped 128 x 128 kernel 176-184 -> 156: three instead of two; no kernel spills). fnet 4.53 -> 4.45 ms, the rest
+# within noise (profiles/r05_ab_vgpr_form.txt); results are bit-identical (the flag moves registers, not arithmetic).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+         "-Wall", "-Wno-unused-function"]
 
 
 def _sources():
