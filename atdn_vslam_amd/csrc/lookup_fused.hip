@@ -167,7 +167,8 @@ __global__ __launch_bounds__(NWAVE * 64, TP == 32 ? 4 : 1) void lookup_conv_kern
     const unsigned cm = (1u << (chi & 31)) - (1u << (clo & 31));                                   // 0 when the range is empty
     const unsigned rm = 0x249u & ((1u << ((3 * rhi) & 31)) - (1u << ((3 * rlo) & 31)));            // bit 3 r for r in [rlo, rhi)
     P_m12 = (int)((clo < 3 && rlo < 4) ? rm * cm : 0u);                                            // (shift counts are in range then)
-    P_sb = (by0 * BWl + bx0) * (LP * 128);     // (wraps for origins outside the map: those lanes are masked)
+    // (unsigned: the product wraps for origins far outside the map — every brick of such a unit is masked)
+    P_sb = (int)((unsigned)(by0 * BWl + bx0) * (unsigned)(LP * 128));
   }
 
   v4f bv[DEPTH][2];
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(NWAVE * 64, TP == 32 ? 4 : 1) void lookup_conv_kern
     const int pp = min(pbase + (pi >> 2), np - 1);
     // (units past the wave's 16th — the prefetches behind the last one — read the copies in lanes 16 .. 18: valid, unused)
     const unsigned m12 = (unsigned)__builtin_amdgcn_readlane(P_m12, pi);
-    const int sbase = __builtin_amdgcn_readlane(P_sb, pi) + (poff + pp) * 128;
+    const int sbase = (int)((unsigned)__builtin_amdgcn_readlane(P_sb, pi) + (unsigned)((poff + pp) * 128));
     const unsigned long long lm0 = rep8(m12 & 0xFFu), lm1 = rep8(m12 >> 8);
     // the pixel's map of this level as a buffer: a lane whose brick is outside the window or outside the map gets an offset
     // past the end, and the load returns zeros by itself (they ARE grid_sample's zero padding): no select on the data
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(NWAVE * 64, TP == 32 ? 4 : 1) void lookup_conv_kern
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       int off;
-      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "v"(big), "v"(loff[l][k] + sbase), "s"(k == 0 ? lm0 : lm1));
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "v"(big), "v"((int)((unsigned)loff[l][k] + (unsigned)sbase)), "s"(k == 0 ? lm0 : lm1));
       bv[sl][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
