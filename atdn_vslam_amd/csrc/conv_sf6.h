@@ -52,6 +52,8 @@ template <class E, class = void> struct EpiAux4 { struct type {}; };
 template <class E> struct EpiAux4<E, std::void_t<typename E::Aux4>> { using type = typename E::Aux4; };
 template <class E, class = void> struct epi_flowhead : std::false_type {};
 template <class E> struct epi_flowhead<E, std::void_t<decltype(E::kFlowHead)>> : std::bool_constant<E::kFlowHead> {};
+template <class E, class = void> struct epi_ring3 : std::false_type {};
+template <class E> struct epi_ring3<E, std::void_t<decltype(E::kRing3)>> : std::bool_constant<E::kRing3> {};
 template <class E, class = void> struct epi_rawacc : std::false_type {};
 template <class E> struct epi_rawacc<E, std::void_t<decltype(E::kRawAcc)>> : std::bool_constant<E::kRawAcc> {};
 template <class E, class = void> struct epi_vec4 : std::false_type {};
@@ -88,7 +90,7 @@ struct SfAcc { f32x4v b[2][2]; };
 // barriers, the 100 MHz real-time clock at both ends and the hardware id of its CU. The product build compiles none of it.
 #ifdef ATDN_CONV_STAMP
 #define ATDN_CONV_STAMP_SLOTS 4096
-extern __device__ unsigned long long atdn_conv_stamps_dev[4][ATDN_CONV_STAMP_SLOTS][8];
+extern __device__ unsigned long long atdn_conv_stamps_dev[4][ATDN_CONV_STAMP_SLOTS][12];
 template <class E> struct conv_stamp_kind : std::integral_constant<int, -1> {};
 #endif
 
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
 #ifdef ATDN_CONV_STAMP
   constexpr int kStamp = conv_stamp_kind<Epi>::value;
   unsigned long long st_r0 = 0, st_t0 = 0, st_t1 = 0, st_t2 = 0, st_bar = 0;
+  unsigned long long st_e_slab = 0, st_e_wait = 0, st_e_apply = 0;   // epilogue: transpose through the slab / operand wait / arithmetic + stores
   if constexpr (kStamp >= 0) { st_r0 = __builtin_amdgcn_s_memrealtime(); st_t0 = __builtin_amdgcn_s_memtime(); }
 #endif
 
@@ -234,7 +237,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
       for (int cb = 0; cb < 2; ++cb)
         wrow[j][cb] = g.w + (long)min(((n0 >> 4) + (wn * TN + j) * 2 + cb), nblk16 - 1) * (NTAP * nck) * 512 + lane * 4;
     // ring of RT K-step slots; the chunk loop is unrolled over CU chunks so that every slot index is a compile-time constant
-    constexpr int RT = (NTAP % 3 == 0) ? 3 : 2;
+    // (three slots for the 5-tap ConvGRU gates too — their 12 chunks are whole iterations of the 3-chunk unroll that a 3-slot ring
+    // over 5 taps needs: q gates -2.4 %, z|r -0.3 %; the context convolutions, 4 chunks, would multiply two surplus chunks and stay
+    // on two slots. profiles/r05_ab_gru_ring3.txt)
+    constexpr int RT = (NTAP % 3 == 0 || epi_ring3<Epi>::value) ? 3 : 2;
     constexpr int CU = (NTAP % RT == 0) ? 1 : RT;
     constexpr int NS = CU * NTAP;            // K steps per iteration of the (unrolled) chunk loop
     static_assert(NS % RT == 0, "ring size must divide the K steps of an unrolled iteration");
@@ -371,6 +377,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
         unsigned long long* o = atdn_conv_stamps_dev[kStamp * 2 + (KH == 5 ? 1 : 0)][blockIdx.x];
         o[0] = st_r0; o[1] = r1; o[2] = st_t1 - st_t0; o[3] = st_t2 - st_t1; o[4] = st_bar; o[5] = t3 - st_t2;
         o[6] = ((unsigned long long)xcc << 32) | hw; o[7] = t3 - st_t0;
+        o[8] = st_e_slab; o[9] = st_e_wait; o[10] = st_e_apply; o[11] = 0;
       }
     }
   };
@@ -527,6 +534,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
       for (int j = 0; j < TN; ++j) {
         const int nb = n0 + (wn * TN + j) * 32 + tcol;
         const float4 bj = ep.bias4(max(min(nb, g.N - 4), 0));   // this lane's 4 channels: one load per channel run
+#ifdef ATDN_CONV_STAMP
+        unsigned long long st_a = 0;
+        if constexpr (kStamp >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_a = __builtin_amdgcn_s_memtime(); }
+#endif
         slab_write(acc[i][j]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -539,6 +550,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next tile
+#ifdef ATDN_CONV_STAMP
+        unsigned long long st_b = 0;
+        if constexpr (kStamp >= 0) { st_b = __builtin_amdgcn_s_memtime(); st_e_slab += st_b - st_a; }
+#endif
         if constexpr (Epi::kPrefetch) {
           AuxT aux[4];
           if constexpr (PIPE) {
@@ -555,12 +570,26 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
 #pragma unroll
             for (int q = 0; q < 4; ++q) aux[q] = ep.load4(img, max(mq[q], 0), min(nb, g.N - 4));
           }
+#ifdef ATDN_CONV_STAMP
+#if ATDN_CONV_STAMP == 2   // variant 2: drain the memory queue before the arithmetic: what the operands (and older stores) still cost here
+          unsigned long long st_c = 0;
+          if constexpr (kStamp >= 0) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            st_c = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st_e_wait += st_c - st_b; st_b = st_c;
+          }
+#endif
+#endif
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (mq[q] >= 0 && nb < g.N) {
               if constexpr (RAW) ep.apply4(img, mq[q], nb, v[q], aux[q], bj, clamped, g.wscale);
               else ep.apply4(img, mq[q], nb, v[q], aux[q], bj, clamped);
             }
+#ifdef ATDN_CONV_STAMP
+          if constexpr (kStamp >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_e_apply += __builtin_amdgcn_s_memtime() - st_b; }
+#endif
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {

@@ -144,6 +144,7 @@ struct SfGruZR {
   // the image's slice as a scalar base + an unsigned 32-bit offset (sf.h). Both gates together: -0.3 ms per forward
   // (profiles/r05_ab_sf_ops.txt); the plain-store epilogues lost registers to the same change and keep the old form (SfBias).
   static constexpr bool kRawAcc = true;
+  static constexpr bool kRing3 = true;   // conv_sf6.h: three weight slots (K = 12 chunks x 5 taps)
   __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped, float ws) const {
     float4 v;
     v.x = sigmoid_fast_(__builtin_fmaf(a.x, ws, x.p.x) + b.x);
@@ -190,6 +191,7 @@ struct SfGruQ {
   }
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
   static constexpr bool kRawAcc = true;   // see SfGruZR
+  static constexpr bool kRing3 = true;
   __device__ __forceinline__ void apply4(int img, int m, int n, float4 a, Aux4 x, float4 b, bool& clamped, float ws) const {
     float4 o;
     o.x = blend(x.z.x, x.h.x, tanh_fast_(__builtin_fmaf(a.x, ws, x.p.x) + b.x));

@@ -22,10 +22,10 @@ for _ in range(3):
     net.forward_sequence(fr, iters=12)
 torch.cuda.synchronize()
 SLOTS = 4096
-buf = (C.c_ulonglong * (4 * SLOTS * 8))()
+buf = (C.c_ulonglong * (4 * SLOTS * 12))()
 L = C.CDLL(_lib.LIB_PATH)
 assert L.atdn_conv_stamps(buf) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(4, SLOTS, 8)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(4, SLOTS, 12)
 names = ["z|r 1x5", "z|r 5x1", "q 1x5", "q 5x1"]
 nblk = [B * 10 * 6 * 2, B * 10 * 6 * 2, B * 10 * 6, B * 10 * 6]
 for k in range(4):
@@ -45,6 +45,9 @@ for k in range(4):
     print("   shares of a block's life: prologue %.1f %%, main loop %.1f %%, epilogue %.1f %%; clock %.2f GHz"
           % (100 * pro.mean() / tot.mean(), 100 * main.mean() / tot.mean(), 100 * epi.mean() / tot.mean(),
              tot.mean() / (life_us.mean() * 1e3)))
+    es, ew, ea = (x[:, j].astype(np.float64).mean() for j in (8, 9, 10))
+    print("   inside the epilogue (wave 0, 4 tiles): transpose through the slab %.0f | waiting for operands / older stores %.0f (stamp "
+          "variant 2 only: a drain before the arithmetic) | arithmetic + store issue %.0f cycles" % (es, ew, ea))
     # occupancy over time: blocks alive at 20 sample points
     ts = np.linspace(0, span_us, 21)[:-1] + span_us / 40
     alive = [int(((r0 - t_start) / 100.0 <= t).sum() - ((r1 - t_start) / 100.0 <= t).sum()) for t in ts]
