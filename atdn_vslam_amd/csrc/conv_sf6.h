@@ -520,6 +520,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
     using AuxT = typename std::conditional<Epi::kPrefetch, typename EpiAux4<Epi>::type, NoAux>::type;
     // (only while the operands of a tile fit 32 registers per lane: the q gate's three operand vectors would take the
     // 128-wide block from three to two resident blocks per CU)
+    // (round 5 measured the q gate WITH the look-ahead again — its stamps show 11.4 k cycles of operand wait per block: no change,
+    // 1.97 / 2.02 ms either way, profiles/r05_ab_q_gate_prefetch.txt: the partner wave's main loop covers the wait)
     constexpr bool PIPE = Epi::kPrefetch && sizeof(AuxT) <= 2 * sizeof(float4);
     AuxT aux_next[PIPE ? 4 : 1];
     bool clamped = false;   // saturation of the sf stores: flagged in a register, reported once (sf.h: sf_store4_flag)
