@@ -55,6 +55,20 @@ for k in range(4):
     ncu = len(np.unique(cu))
     starts = np.sort((r0 - t_start) / 100.0)
     print("   distinct CUs seen %d; blocks started in the first 5 us: %d; last block started at %.1f us" % (ncu, int((starts < 5).sum()), starts[-1]))
+    # are the co-resident blocks of a CU in phase? For every block: the distance from its start to the nearest OTHER block start on
+    # its CU (two blocks per CU: ~0 = they run in lock step, their epilogues never meet the partner's main loop; ~half a block
+    # life = staggered)
+    st_us = (r0 - t_start) / 100.0
+    dists = []
+    for cid in np.unique(cu):
+        t = np.sort(st_us[cu == cid])
+        if len(t) < 2:
+            continue
+        d = np.minimum(np.diff(t, prepend=t[0] - 1e9), np.diff(t, append=t[-1] + 1e9))
+        dists.append(d)
+    dists = np.concatenate(dists)
+    print("   start-to-nearest-start on the same CU: median %.1f us, p25 %.1f, p75 %.1f (block life %.1f us; blocks per CU %.1f)"
+          % (np.median(dists), np.percentile(dists, 25), np.percentile(dists, 75), life_us.mean(), n / float(ncu)))
     # early vs late blocks
     order = np.argsort(r0)
     q = n // 4
