@@ -308,10 +308,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
     constexpr int NH = 2 * NTAP;                        // half-steps per chunk
     static_assert(!NORM || NH - 1 - NP >= 1, "normalise-on-load spreads its NP patch rows over the half-steps of a chunk");
     read_a(0, 0);
-    // (round 5: the ConvGRU kernels raise their waves' priority for the main loop and drop it for the epilogue — a wave that is
-    // multiplying wins the issue slot over its SIMD partner's epilogue instructions: z|r -0.9 %, q -1.8 %; on the thin 3x3 kernels
-    // of the encoders the same cost 1 %, so they stay at the default. profiles/r05_ab_setprio.txt)
-    if constexpr (KH != 3) __builtin_amdgcn_s_setprio(2);
+    // (round 5: every kernel but the instance-norm ones raises its waves' priority for the main loop and drops it for the
+    // epilogue — a wave that is multiplying wins the issue slot over its SIMD partner's epilogue instructions: z|r -0.9 %,
+    // q -1.8 %, motion encoder -1.2 %; on the statistics kernels of fnet the same cost 1 %, so they stay at the default; level 3
+    // measures the same as level 2. profiles/r05_ab_setprio.txt)
+    if constexpr (KH != 3 || !Epi::kStats) __builtin_amdgcn_s_setprio(2);
     for (int c0 = 0; c0 < nck; c0 += CU) {
 #pragma unroll
       for (int cu = 0; cu < CU; ++cu) {
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
     }
   };
 #endif
-  if constexpr (KH != 3) __builtin_amdgcn_s_setprio(0);
+  if constexpr (KH != 3 || !Epi::kStats) __builtin_amdgcn_s_setprio(0);
   if constexpr (NORM) sf_report(norm_sat);
   if constexpr ((ABL & 8) != 0) {  // diagnostic: no epilogue (one conditional store keeps the accumulators alive)
     float tot = 0.f;

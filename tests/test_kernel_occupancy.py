@@ -42,3 +42,12 @@ def test_hot_kernels_keep_their_occupancy_and_do_not_spill():
             worse.append("%s: %d registers / %d spilled / %d waves per SIMD, table has %d / %d / %d"
                          % (k[:110], g["vgpr"], g["spilled_dwords"], g["waves_per_simd"], w["vgpr"], w["spilled_dwords"], w["waves_per_simd"]))
     assert not worse, "occupancy lost:\n" + "\n".join(worse)
+
+
+if __name__ == "__main__":   # python tests/test_kernel_occupancy.py --regen : rewrite the table from the built library, on purpose
+    if "--regen" in sys.argv:
+        sys.path.insert(0, ROOT)
+        old = json.load(open(os.path.join(ROOT, "tests", "golden", "kernel_occupancy.json")))
+        cur = _current()
+        json.dump({k: cur[k] for k in sorted(old) if k in cur}, open(os.path.join(ROOT, "tests", "golden", "kernel_occupancy.json"), "w"), indent=0, sort_keys=True)
+        print("rewrote %d of %d entries" % (sum(k in cur for k in old), len(old)))

@@ -1,7 +1,7 @@
 """Registers, LDS and occupancy of every kernel of a built library, from the code objects' metadata:
     python tools/diag/kernel_regs.py [path/to/lib.so] [name fragment]
 For each kernel: vgpr_count (VGPR + AGPR on gfx950: what sets the waves per SIMD, 512 / count rounded down to the allocation
-granule of 8), sgpr_count, spills, LDS bytes, and the waves per SIMD that follow. A change that "only" touches an epilogue can
+granule of 8), sgpr_count, spills, LDS bytes, and the waves per SIMD that follow (the smaller of the register and the LDS bound). A change that "only" touches an epilogue can
 move a kernel across an occupancy step (round 5: 244 -> 276 registers = two waves per SIMD -> one, +5 % on every launch)."""
 import os
 import re
@@ -62,10 +62,15 @@ def main():
             continue
         v = int(k["vgpr_count"])
         waves = min(8, 512 // max(8, -(-v // 8) * 8))
+        # the LDS bound: blocks per CU by the 160 KB of LDS x waves per block / 4 SIMDs (a kernel whose register count allows three
+        # waves but whose LDS allows two blocks of four waves runs at two)
+        lds, wg = int(k.get("group_segment_fixed_size", 0)), int(k.get("max_flat_workgroup_size", 256))
+        if lds > 0:
+            waves = min(waves, max(1, (163840 // lds) * max(1, wg // 64) // 4))
         rows.append((n.replace("atdn::", "").replace("(anonymous namespace)::", ""), v, int(k.get("sgpr_count", 0)),
                      int(k.get("vgpr_spill_count", 0)), int(k.get("group_segment_fixed_size", 0)), waves))
     rows.sort()
-    print("%-140s %5s %5s %6s %7s %s" % ("kernel", "vgpr", "sgpr", "spill", "lds", "waves/SIMD by registers"))
+    print("%-140s %5s %5s %6s %7s %s" % ("kernel", "vgpr", "sgpr", "spill", "lds", "waves/SIMD (registers, LDS)"))
     for r in rows:
         print("%-140s %5d %5d %6d %7d %d" % (r[0][:140], r[1], r[2], r[3], r[4], r[5]))
 
