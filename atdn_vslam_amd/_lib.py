@@ -19,6 +19,7 @@ SIGNATURES = {
     "atdn_gma_load": (C.c_int, [_vp, C.c_char_p, _vp, _i64p, C.c_int]),
     "atdn_gma_finalize": (C.c_int, [_vp]),
     "atdn_gma_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "atdn_gma_forward_predictions": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "atdn_gma_forward_sequence": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "atdn_gma_forward_sequence_continued": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "atdn_gma_debug_read": (C.c_long, [_vp, C.c_char_p, _vp, C.c_long, _vp]),

@@ -100,6 +100,13 @@ int atdn_gma_forward(atdn_gma* h, const float* im1, const float* im2, int B, int
   h->net.forward(im1, im2, B, iters, flow_init, flow_low, flow_up, (hipStream_t)stream);
   ATDN_API_END
 }
+int atdn_gma_forward_predictions(atdn_gma* h, const float* im1, const float* im2, int B, int iters, const float* flow_init,
+                                 float* flow_predictions, void* stream) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.forward_predictions(im1, im2, B, iters, flow_init, flow_predictions, (hipStream_t)stream);
+  ATDN_API_END
+}
 int atdn_gma_forward_sequence(atdn_gma* h, const float* frames, int B, int iters, const float* flow_init,
                               float* flow_low, float* flow_up, void* stream) {
   ATDN_API_BEGIN

@@ -817,6 +817,9 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   // ConvGRU convolutions (1x5 / 5x1): 128-wide blocks even for N = 256. Their epilogue is heavy (gate operands, sigmoids,
   // two stores per value: ~20 % of a block's time) and no MFMA overlaps it inside a block; three 4-wave blocks fit a CU
   // where one 8-wave block does, so one block's epilogue runs under the others' main loops (z|r, 16 pairs: 295 -> 286 us).
+  // (Round 5 also measured 64-wide blocks for the gates, 8 x 16 and 12 x 16 pixels, 2 x 2 waves — the shape the 3x3 convolutions
+  // of the motion encoder run best with: z|r 3.40 -> 3.52 / 3.63 ms per forward, q 1.94 -> 2.06 / 2.08; the vertical pass worse
+  // still, 174 registers = two waves per SIMD without the wider block's patch reuse. profiles/r05_ab_gru_block_width.txt)
   if constexpr (KH != 3) bn = std::min(bn, 128);
   *th_out = 8;
   if (s.in_mean) {   // normalise-on-load: statistics convs of the feature network (3x3, 64 / 96 / 128 channels)

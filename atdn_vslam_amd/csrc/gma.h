@@ -39,6 +39,11 @@ class GmaNet {
                float* flow_up, hipStream_t st);
   // B consecutive pairs of one clip: frames NCHW [B+1,3,H,W]; pair b = (frame b, frame b+1). The feature network
   // runs once per FRAME (B+1 passes instead of 2B).
+  // flow_predictions of network.py:106-129 (test_mode=False): the convex upsampling of EVERY iteration's flow with that
+  // iteration's mask, preds [iters][B][2][H][W]. The mask head runs per iteration here (in test mode only the last one's
+  // reaches the output); launched eagerly, not as a graph: the destination moves with the iteration.
+  void forward_predictions(const float* im1, const float* im2, int B, int iters, const float* flow_init, float* preds,
+                           hipStream_t st);
   void forward_sequence(const float* frames, int B, int iters, const float* flow_init, float* flow_low, float* flow_up,
                         hipStream_t st, bool continued = false);
   // copy an internal tensor to host (parity tests); returns element count, or -1 for an unknown name
@@ -79,6 +84,10 @@ class GmaNet {
   int seq_ = 0;        // 0: pair mode; 1: sequence (B+1 frames, every frame through fnet once); 2: sequence continued
                        //    (frame 0 is the previous call's last frame: its features are reused, fnet sees B frames)
   int last_frame_ = -1;  // fmap_ slot of the last frame of the previous sequence call
+  float* preds_out_ = nullptr;   // forward_predictions only: where iteration `it` writes its upsampled flow (+ it * preds_stride_)
+  long preds_stride_ = 0;
+  void mask_head_sf(int B, hipStream_t st);
+  void mask_head(int B, hipStream_t st);
   int last_B_ = 0;       // pairs of the last forward (debug reads that recompute something do so for these pairs only)
 
   StateDict sd_;

@@ -452,14 +452,23 @@ void GmaNet::run_body(int B, int iters, hipStream_t st) {
   launch_softmax_rows(attn_.p, (long)B * N, N, ldN, st);
   mark(ST_ATTN, st);
 
-  for (int it = 0; it < iters; ++it) iteration(B, st);
-
+  for (int it = 0; it < iters; ++it) {
+    iteration(B, st);
+    if (preds_out_) {   // forward_predictions: every iteration's flow through its own mask (network.py:118-124)
+      mask_head(B, st);
+      launch_upsample(mask_.p, flow4_.p, B, H8, W8, nullptr, preds_out_ + it * preds_stride_, st);
+    }
+  }
   // ---- mask head, once (update.py:120-123,138): only the last iteration's mask reaches the output
-  s = conv_shape(mask0_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  if (!preds_out_) mask_head(B, st);
+  mark(ST_MASK, st);
+}
+
+void GmaNet::mask_head(int B, hipStream_t st) {
+  ConvShape s = conv_shape(mask0_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   conv_dispatch<MODE_TAP>(s, EpiBias<ACT_RELU>{mask0_.b, fh_.p, (long)N * 256, 256, 1.f}, st);
   s = conv_shape(mask2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 0, 0);
   conv_dispatch<MODE_TAP>(s, EpiBias<ACT_NONE>{mask2_.b, mask_.p, (long)N * 576, 576, 0.25f}, st);
-  mark(ST_MASK, st);
 }
 
 // =============================================================== split-f16 pipeline (precision == 1)
@@ -668,13 +677,22 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   }
   mark(ST_GRU_CTX, st);
 
-  for (int it = 0; it < iters; ++it) iteration_sf(B, st);
+  for (int it = 0; it < iters; ++it) {
+    iteration_sf(B, st);
+    if (preds_out_) {   // forward_predictions: every iteration's flow through its own mask (network.py:118-124)
+      mask_head_sf(B, st);
+      launch_upsample(mask_.p, flow4_.p, B, H8, W8, nullptr, preds_out_ + it * preds_stride_, st);
+    }
+  }
+  if (!preds_out_) mask_head_sf(B, st);   // test mode: only the last iteration's mask reaches the output (update.py:120-123,138)
+  mark(ST_MASK, st);
+}
 
-  s = conv_shape(mask0_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+void GmaNet::mask_head_sf(int B, hipStream_t st) {
+  ConvShape s = conv_shape(mask0_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   conv_sf_dispatch(s, mask0_.wscale, SfBias<ACT_RELU>{mask0_.b, fh_.p, (long)N * 256, 256}, st);
   s = conv_shape(mask2_, fh_.p, 256, (long)N * 256, B, H8, W8, 1, 0, 0);
   conv_sf_dispatch(s, mask2_.wscale, EpiBias<ACT_NONE>{mask2_.b, mask_.p, (long)N * 576, 576, 0.25f}, st);
-  mark(ST_MASK, st);
 }
 
 void GmaNet::capture(int B, int iters) {
@@ -745,6 +763,26 @@ void GmaNet::forward(const float* im1, const float* im2, int B, int iters, const
   else launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
   launch_body(B, iters, st);
   launch_upsample(mask_.p, flow4_.p, B, H8, W8, flow_low, flow_up, st);
+}
+
+void GmaNet::forward_predictions(const float* im1, const float* im2, int B, int iters, const float* flow_init, float* preds,
+                                 hipStream_t st) {
+  ATDN_CHECK(ready_, "weights not finalized");
+  ATDN_CHECK(B >= 1 && B <= maxB, "batch exceeds max_batch of this handle");
+  ATDN_CHECK(iters >= 1 && iters <= 64, "iters out of range");
+  ATDN_CHECK(im1 && im2 && preds, "null tensor");
+  seq_ = 0;
+  last_frame_ = 0;
+  last_B_ = B;
+  launch_prep_images(im1, im2, B, H, W, img4_.p, st, B);
+  if (precision >= 1) launch_init_coords_sf(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p, XLD, 254, st);
+  else launch_init_coords(flow_init, B, H8, W8, coords1_.p, flow4_.p, x_.p + 254, XLD, st);
+  struct Guard {   // the body reads the destination from the handle: never leave it set behind an exception
+    GmaNet* n; ~Guard() { n->preds_out_ = nullptr; n->preds_stride_ = 0; }
+  } guard{this};
+  preds_out_ = preds;
+  preds_stride_ = (long)B * 2 * H * W;
+  if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, st); } else run_body(B, iters, st);
 }
 
 BrickPyramid GmaNet::brick_pyramid() const {

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   const long o = (img * 2) * Hf * Wf + (long)(8 * h + i) * Wf + 8 * w + j;
   flow_up[o] = ux;
   flow_up[o + Hf * Wf] = uy;
-  if (lane == 0) {
+  if (lane == 0 && flow_low) {   // (flow_low == nullptr: the per-iteration predictions of GmaNet::forward_predictions)
     const float4 f = reinterpret_cast<const float4*>(flow4)[p];
     flow_low[(img * 2 + 0) * N + m] = f.x;
     flow_low[(img * 2 + 1) * N + m] = f.y;

@@ -254,9 +254,9 @@ class RAFTGMA(_NativeModule):
 
     @torch.no_grad()
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
-        if not test_mode:
-            raise NotImplementedError("only the inference contract (test_mode=True) is built; the per-iteration "
-                                      "training outputs of network.py:129 are out of scope")
+        """`test_mode=True`: (flow_low, flow_up) of the last iteration (network.py:126-127). `test_mode=False`: the reference's
+        `flow_predictions` (network.py:106-129) — a list of `iters` tensors [B,2,H,W], the upsampled flow after every iteration;
+        values only (this module is inference-only: the list carries no autograd graph)."""
         self._require_input(image1, "RAFTGMA.forward")
         if image1.shape != image2.shape or image1.dim() != 4 or image1.shape[1] != 3:
             raise RuntimeError("expected two [B,3,H,W] frames, got %s and %s" % (tuple(image1.shape), tuple(image2.shape)))
@@ -269,14 +269,21 @@ class RAFTGMA(_NativeModule):
                 fi = flow_init.to(image1.device).float().contiguous()
                 if tuple(fi.shape) != (B, 2, H // 8, W // 8):
                     raise RuntimeError("flow_init must be [B,2,H/8,W/8]")
-            flow_low = torch.empty((B, 2, H // 8, W // 8), dtype=torch.float32, device=image1.device)
-            flow_up = torch.empty((B, 2, H, W), dtype=torch.float32, device=image1.device)
             h = self._handle(H, W, B)
-            _lib.check(_lib.lib().atdn_gma_forward(h, _ptr(im1), _ptr(im2), B, int(iters), _ptr(fi), _ptr(flow_low),
-                                                   _ptr(flow_up), _stream()))
+            if not test_mode:
+                preds = torch.empty((int(iters), B, 2, H, W), dtype=torch.float32, device=image1.device)
+                _lib.check(_lib.lib().atdn_gma_forward_predictions(h, _ptr(im1), _ptr(im2), B, int(iters), _ptr(fi), _ptr(preds),
+                                                                   _stream()))
+            else:
+                flow_low = torch.empty((B, 2, H // 8, W // 8), dtype=torch.float32, device=image1.device)
+                flow_up = torch.empty((B, 2, H, W), dtype=torch.float32, device=image1.device)
+                _lib.check(_lib.lib().atdn_gma_forward(h, _ptr(im1), _ptr(im2), B, int(iters), _ptr(fi), _ptr(flow_low),
+                                                       _ptr(flow_up), _stream()))
             retry = self._after_forward()
         if retry:
             return self.forward(image1, image2, iters=iters, flow_init=flow_init, upsample=upsample, test_mode=test_mode)
+        if not test_mode:
+            return list(preds.unbind(0))
         return flow_low, flow_up
 
     @torch.no_grad()

@@ -60,6 +60,14 @@ int atdn_gma_finalize(atdn_gma* h);
 int atdn_gma_forward(atdn_gma* h, const float* im1, const float* im2, int B, int iters, const float* flow_init,
                      float* flow_low, float* flow_up, void* stream);
 
+/* flow_predictions = flow_net(image1, image2, iters=iters, flow_init=flow_init, test_mode=False)   (network.py:106-129:
+ * the training-time return of RAFTGMA.forward — the convex upsampling of EVERY iteration's flow with that iteration's mask)
+ *   flow_predictions  [iters,B,2,H,W]; slice iters-1 equals atdn_gma_forward's flow_up
+ * The mask head runs once per iteration in this call (atdn_gma_forward needs only the last one's); launched kernel by kernel,
+ * not as a graph. Inference only: no gradients are produced. */
+int atdn_gma_forward_predictions(atdn_gma* h, const float* im1, const float* im2, int B, int iters, const float* flow_init,
+                                 float* flow_predictions, void* stream);
+
 /* The same for B consecutive pairs of one clip, as NeuralSLAM walks a sequence (neural_slam.py:196-217: frame t is
  * image2 of pair t-1 and image1 of pair t): frames [B+1,3,H,W]; pair b = (frames[b], frames[b+1]). The feature
  * network runs once per frame instead of twice. Split-f16 handles only. */

@@ -156,9 +156,11 @@ def strip_prefix(sd):
 
 
 @torch.no_grad()
-def gma_forward(sd, image1, image2, iters=12, flow_init=None, taps=None):
+def gma_forward(sd, image1, image2, iters=12, flow_init=None, taps=None, predictions=None):
     """RAFTGMA.forward(test_mode=True) → (flow_low [B,2,H/8,W/8], flow_up [B,2,H,W]).
-    `taps`, if a dict, receives intermediate tensors for per-stage parity tests."""
+    `taps`, if a dict, receives intermediate tensors for per-stage parity tests.
+    `predictions`, if a list, receives what test_mode=False returns (network.py:106-129): every iteration's flow, upsampled
+    with that iteration's mask."""
     sd = strip_prefix(sd)
     im1 = (2 * (image1 / 255.0) - 1.0).contiguous()
     im2 = (2 * (image2 / 255.0) - 1.0).contiguous()
@@ -186,6 +188,8 @@ def gma_forward(sd, image1, image2, iters=12, flow_init=None, taps=None):
         net = sep_conv_gru(net, torch.cat([inp, mf, mfg], 1), sd)
         delta = flow_head(net, sd)
         coords1 = coords1 + delta
+        if predictions is not None:   # network.py:118-124
+            predictions.append(convex_upsample(coords1 - coords0, up_mask(net, sd)))
         if taps is not None and it == 0:
             taps.update(lookup0=corr, mf0=mf, mfg0=mfg, net1=net, delta0=delta)
     mask = up_mask(net, sd)

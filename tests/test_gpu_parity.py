@@ -406,6 +406,38 @@ def test_gma_c1_full_flow_matches_golden(golden_dir, gsd, flow_net):
     assert _maxerr(low, ref_low) < 2e-4 and _maxerr(up, ref_up) < 1e-3
 
 
+def test_gma_flow_predictions_match_reference_golden(golden_dir, gsd, flow_net):
+    """RAFTGMA.forward(test_mode=False) — the reference's per-iteration `flow_predictions` (network.py:106-129;
+    tests/golden/make_golden_preds.py ran the reference itself) through atdn_gma_forward_predictions, in both arithmetic modes."""
+    from oracle import gma_ref
+    g = np.load(os.path.join(golden_dir, "gma_preds.npz"))
+    iters = int(g["iters"])
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=int(g["seed_frames"])))
+    preds = flow_net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=iters)            # test_mode defaults to False, as in the reference
+    assert isinstance(preds, list) and len(preds) == iters and all(tuple(p.shape) == (1, 2, 160, 512) for p in preds)
+    p = torch.stack(preds, 0)[:, 0].cpu()
+    assert _maxerr(p[:, :, ::4, ::4], torch.from_numpy(g["preds_s4"])) < 1e-3
+    np.testing.assert_allclose(p.double().abs().sum(dim=(2, 3)).numpy(), g["preds_abs"], rtol=1e-5)
+    ref = []
+    gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=iters, predictions=ref)
+    for it in range(iters):   # the early iterations carry less accumulated rounding than the last
+        assert _maxerr(p[it], ref[it][0]) < 1e-3, it
+    assert _maxerr(p[0], ref[0][0]) < 2e-4
+    # the last prediction IS the test-mode output (same kernels, same order: bit for bit)
+    _, up = flow_net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=iters, test_mode=True)
+    assert torch.equal(preds[-1], up)
+    # B = 2 with a flow_init, 3 iterations
+    fi = torch.from_numpy(g["flow_init"]).to(DEV)
+    preds2 = flow_net(torch.cat([fr[0:1], fr[1:2]]).to(DEV), torch.cat([fr[1:2], fr[0:1]]).to(DEV), iters=3, flow_init=fi)
+    p2 = torch.stack(preds2, 0).cpu()
+    assert tuple(p2.shape) == (3, 2, 2, 160, 512)
+    assert _maxerr(p2[:, :, :, ::4, ::4], torch.from_numpy(g["preds2_s4"])) < 1e-3
+    np.testing.assert_allclose(p2.double().abs().sum(dim=(3, 4)).numpy(), g["preds2_abs"], rtol=1e-5)
+    # and a test-mode call afterwards is unaffected by the predictions call before it
+    _, up_b = flow_net(fr[0:1].to(DEV), fr[1:2].to(DEV), iters=iters, test_mode=True)
+    assert torch.equal(up_b, up)
+
+
 def test_gma_c2_kitti_size_matches_golden_and_is_batch_invariant(golden_dir, gsd, flow_net):
     g = np.load(os.path.join(golden_dir, "gma_c2.npz"))
     fr = torch.from_numpy(syn.make_frames(2, 376, 1232, seed=int(g["seed_frames"]))).to(DEV)
@@ -454,8 +486,6 @@ def test_gma_flow_init_matches_oracle(gsd, flow_net):
 
 
 def test_gma_module_contract(flow_net):
-    with pytest.raises(NotImplementedError):
-        flow_net(torch.zeros(1, 3, 160, 512, device=DEV), torch.zeros(1, 3, 160, 512, device=DEV))
     with pytest.raises(RuntimeError):
         flow_net(torch.zeros(1, 3, 160, 512), torch.zeros(1, 3, 160, 512), test_mode=True)  # CPU tensors: no fallback
     with pytest.raises(RuntimeError):

@@ -61,6 +61,26 @@ def test_gma_c1_stages_and_flow(golden_dir, gsd):
     assert float(np.abs(g["flow_up"]).max()) > 1.0  # non-trivial flow
 
 
+def test_gma_flow_predictions_of_every_iteration(golden_dir, gsd):
+    """RAFTGMA.forward(test_mode=False) (network.py:106-129): the oracle's per-iteration upsampled flows against the reference's
+    own list (tests/golden/make_golden_preds.py), with and without a flow_init."""
+    g = _load(golden_dir, "gma_preds.npz")
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=int(g["seed_frames"])))
+    preds = []
+    _, up = gma_ref.gma_forward(gsd, fr[0:1], fr[1:2], iters=int(g["iters"]), predictions=preds)
+    assert len(preds) == int(g["iters"]) and torch.equal(preds[-1], up)
+    p = torch.stack(preds, 0)[:, 0]
+    np.testing.assert_allclose(p[:, :, ::4, ::4].numpy(), g["preds_s4"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(p.double().abs().sum(dim=(2, 3)).numpy(), g["preds_abs"], rtol=1e-5)
+    # the iterations differ from one another (a test that compared eight copies of the last flow would pass nothing)
+    assert float(np.abs(g["preds_s4"][0] - g["preds_s4"][-1]).max()) > 0.5
+    preds2 = []
+    gma_ref.gma_forward(gsd, torch.cat([fr[0:1], fr[1:2]]), torch.cat([fr[1:2], fr[0:1]]), iters=3,
+                        flow_init=torch.from_numpy(g["flow_init"]), predictions=preds2)
+    p2 = torch.stack(preds2, 0)
+    np.testing.assert_allclose(p2[:, :, :, ::4, ::4].numpy(), g["preds2_s4"], rtol=0, atol=1e-3)
+
+
 @pytest.mark.timeout(600)
 def test_gma_c2_flow_and_head(golden_dir, gsd, hsd):
     g = _load(golden_dir, "gma_c2.npz")
