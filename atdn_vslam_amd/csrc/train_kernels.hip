@@ -1094,8 +1094,13 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
       const int c = 4 * g + j;
       breg[tap][j] = transposed ? w[((long)c * 16 + n) * K * K + (K * K - 1 - tap)] : w[((long)n * 16 + c) * K * K + tap];
     }
-  const float bv = bias ? bias[n] : 0.f;
-  const C16Consts cc = c16_consts<TAIL>(tail, n);
+  // Round 5: the weights are the ROW operand and the patch the COLUMN operand, so D comes out as (row = output channel 4g + e,
+  // column = pixel lane & 15): a lane holds four consecutive channels of ONE pixel and stores 16 bytes, a wave one contiguous KiB
+  // (the other way round every store instruction wrote four 64-byte pieces, 4 bytes per lane). Same products, same sums.
+  float bv[4];
+  C16Consts cc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { bv[e] = bias ? bias[4 * g + e] : 0.f; cc[e] = c16_consts<TAIL>(tail, 4 * g + e); }
   constexpr int TILES = TH * TW / 16, TPR = TW / 16;   // 16-pixel MFMA tiles of the block tile; per row
   static_assert(TILES % 2 == 0, "two tiles per wave and trip");
   // the patch of the next block tile is fetched into registers while this one is computed
@@ -1129,7 +1134,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
     for (int t = 2 * wave; t < TILES; t += 8) {   // two independent accumulation chains per wave
       const int ty0 = t / TPR, tx0 = (t % TPR) * 16, ty1 = (t + 1) / TPR, tx1 = ((t + 1) % TPR) * 16;
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      // in the A operand lane & 15 is the pixel of the row
+      // in the patch operand lane & 15 is the pixel of the row
       const float* b0 = patch + ((ty0 * S) * PW + (tx0 + n) * S) * PP + 4 * g;
       const float* b1 = patch + ((ty1 * S) * PW + (tx1 + n) * S) * PP + 4 * g;
 #pragma unroll
@@ -1137,30 +1142,35 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
         const int off = ((tap / K) * PW + (tap % K)) * PP;
         const float4 a0 = *reinterpret_cast<const float4*>(b0 + off);
         const float4 a1 = *reinterpret_cast<const float4*>(b1 + off);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[tap][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[tap][0], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[tap][1], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[tap][1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[tap][2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, breg[tap][2], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[tap][3], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, breg[tap][3], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][0], a0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][0], a1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][1], a0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][1], a1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][2], a0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][2], a1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][3], a0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][3], a1.w, acc1, 0, 0, 0);
       }
-      // D: row (pixel) = 4*g + e, column (output channel) = lane & 15
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int oya = oy0 + ty0, oxa = ox0 + tx0 + 4 * g + e, oyb = oy0 + ty1, oxb = ox0 + tx1 + 4 * g + e;
-        const long oa = (((long)img * Ho + oya) * Wo + oxa) * 16 + n, ob = (((long)img * Ho + oyb) * Wo + oxb) * 16 + n;
-        float* pa = z + oa;
-        float* pb = z + ob;
+      // D: row (output channel) = 4*g + e, column (pixel) = lane & 15
+      auto put = [&](const f32x4_t& acc, int oy, int ox) __attribute__((always_inline)) {
+        if (oy >= Ho || ox >= Wo) return;
+        const long o = (((long)img * Ho + oy) * Wo + ox) * 16 + 4 * g;
+        float4* pz = reinterpret_cast<float4*>(z + o);
+        float v[4];
         if constexpr (TAIL == 0) {
-          if (oya < Ho && oxa < Wo) *pa = acc0[e] + bv + (accumulate ? *pa : 0.f);
-          if (oyb < Ho && oxb < Wo) *pb = acc1[e] + bv + (accumulate ? *pb : 0.f);
+          float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (accumulate) old = *pz;
+          const float od[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[e] + bv[e] + od[e];
         } else {
-          if (oya < Ho && oxa < Wo) *pa = c16_tail<TAIL>(acc0[e] + bv, cc, tail.skip, oa);
-          if (oyb < Ho && oxb < Wo) *pb = c16_tail<TAIL>(acc1[e] + bv, cc, tail.skip, ob);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = c16_tail<TAIL>(acc[e] + bv[e], cc[e], tail.skip, o + e);
         }
-      }
+        *pz = make_float4(v[0], v[1], v[2], v[3]);
+      };
+      put(acc0, oy0 + ty0, ox0 + tx0 + n);
+      put(acc1, oy0 + ty1, ox0 + tx1 + n);
     }
   }
 }
@@ -1199,8 +1209,10 @@ __global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x
       const int f = 4 * g + j, kx = f >> 1, c = f & 1;
       breg[ky][j] = kx < 7 ? w[(((long)n * 2 + c) * 7 + ky) * 7 + kx] : 0.f;
     }
-  const float bv = bias ? bias[n] : 0.f;
-  const C16Consts cc = c16_consts<TAIL>(tail, n);
+  float bv[4];   // (weights as the row operand: a lane ends up with channels 4g..4g+3 of one pixel, see conv16_kernel)
+  C16Consts cc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { bv[e] = bias ? bias[4 * g + e] : 0.f; cc[e] = c16_consts<TAIL>(tail, 4 * g + e); }
   constexpr int NV = ST_PH * ST_PWC, NF = (NV + 255) / 256;
   float2 pre[NF];
   auto fetch = [&](int bt) {
@@ -1231,27 +1243,30 @@ __global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x
     for (int t = 2 * wave; t < TILES; t += 8) {
       const int ty0 = t / TPR, tx0 = (t % TPR) * 16, ty1 = (t + 1) / TPR, tx1 = ((t + 1) % TPR) * 16;
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const float* b0 = patch + (ty0 * 2) * ST_ROWP + 4 * (tx0 + n) + 4 * g;   // lane & 15 = pixel of the A row
+      const float* b0 = patch + (ty0 * 2) * ST_ROWP + 4 * (tx0 + n) + 4 * g;   // lane & 15 = pixel of the patch operand
       const float* b1 = patch + (ty1 * 2) * ST_ROWP + 4 * (tx1 + n) + 4 * g;
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) {
         const float4 a0 = *reinterpret_cast<const float4*>(b0 + ky * ST_ROWP);
         const float4 a1 = *reinterpret_cast<const float4*>(b1 + ky * ST_ROWP);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[ky][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[ky][0], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[ky][1], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[ky][1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[ky][2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, breg[ky][2], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[ky][3], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, breg[ky][3], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[ky][0], a0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[ky][0], a1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[ky][1], a0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[ky][1], a1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[ky][2], a0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[ky][2], a1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[ky][3], a0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[ky][3], a1.w, acc1, 0, 0, 0);
       }
+      auto put = [&](const f32x4_t& acc, int oy, int ox) __attribute__((always_inline)) {
+        if (oy >= Ho || ox >= Wo) return;
+        float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int oya = oy0 + ty0, oxa = ox0 + tx0 + 4 * g + e, oyb = oy0 + ty1, oxb = ox0 + tx1 + 4 * g + e;
-        if (oya < Ho && oxa < Wo) z[(((long)img * Ho + oya) * Wo + oxa) * 16 + n] = c16_tail<TAIL>(acc0[e] + bv, cc, nullptr, 0);
-        if (oyb < Ho && oxb < Wo) z[(((long)img * Ho + oyb) * Wo + oxb) * 16 + n] = c16_tail<TAIL>(acc1[e] + bv, cc, nullptr, 0);
-      }
+        for (int e = 0; e < 4; ++e) v[e] = c16_tail<TAIL>(acc[e] + bv[e], cc[e], nullptr, 0);
+        *reinterpret_cast<float4*>(z + (((long)img * Ho + oy) * Wo + ox) * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+      };
+      put(acc0, oy0 + ty0, ox0 + tx0 + n);
+      put(acc1, oy0 + ty1, ox0 + tx1 + n);
     }
   }
 }
@@ -1284,7 +1299,7 @@ __global__ __launch_bounds__(256) void tconv16_s2_kernel(const float* __restrict
   constexpr int TH = 8, TW = 64, PH = TH / 2 + 2, PW = TW / 2 + 2;
   __shared__ __attribute__((aligned(16))) float patch[PH * PW * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, idx = lane & 15, g = lane >> 4;
-  float breg[K * K][4];   // contraction over n: slot g of MFMA j = output channel 4g + j; column = input channel idx
+  float breg[K * K][4];   // contraction over n: slot g of MFMA j = output channel 4g + j; row = input channel idx
 #pragma unroll
   for (int tap = 0; tap < K * K; ++tap)
 #pragma unroll
@@ -1332,24 +1347,26 @@ __global__ __launch_bounds__(256) void tconv16_s2_kernel(const float* __restrict
             const float4 a0 = *reinterpret_cast<const float4*>(b);
             const float4 a1 = *reinterpret_cast<const float4*>(b + 16 * 16);
             const int tap = ky * K + kx;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[tap][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[tap][0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[tap][1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[tap][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[tap][2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, breg[tap][2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[tap][3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, breg[tap][3], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][0], a0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][0], a1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][1], a0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][1], a1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][2], a0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][2], a1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][3], a0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tap][3], a1.w, acc1, 0, 0, 0);
           }
         }
-        if (y < H) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int xa = x0 + 2 * (4 * g + e) + px, xb = xa + 32;
-            float* pa = dx + (((long)img * H + y) * W + xa) * 16 + idx;
-            if (xa < W) *pa = acc0[e] + (accumulate ? *pa : 0.f);
-            if (xb < W) pa[32 * 16] = acc1[e] + (accumulate ? pa[32 * 16] : 0.f);
-          }
+        if (y < H) {   // (weights as the row operand: the lane holds channels 4g..4g+3 of pixel idx, see conv16_kernel)
+          const int xa = x0 + 2 * idx + px, xb = xa + 32;
+          float4* pa = reinterpret_cast<float4*>(dx + (((long)img * H + y) * W + xa) * 16 + 4 * g);
+          auto put = [&](float4* q, const f32x4_t& acc) __attribute__((always_inline)) {
+            float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (accumulate) old = *q;
+            *q = make_float4(acc[0] + old.x, acc[1] + old.y, acc[2] + old.z, acc[3] + old.w);
+          };
+          if (xa < W) put(pa, acc0);
+          if (xb < W) put(pa + 32 * 4, acc1);
         }
       }
     }
