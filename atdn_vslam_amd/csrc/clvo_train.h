@@ -56,10 +56,11 @@ class ClvoTrainer {
   Lin make_lin(const std::string& p, bool bias = true);
 
   void pack_weights(hipStream_t st);
-  void conv_fwd(const ConvL& c, const float* x, int h, int w, float* z, hipStream_t st);
+  int conv_fwd(const ConvL& c, const float* x, int h, int w, float* z, hipStream_t st, bool with_stats = false);
   void conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w_in, int ho, int wo, float* dx, int ldd, hipStream_t st,
                      bool accumulate = false);
-  void bn_fwd(const BnL& bn, const float* z, long P, bool mish, const float* add, float* y, hipStream_t st);
+  int bn_fwd(const BnL& bn, const float* z, long P, bool mish, const float* add, float* y, hipStream_t st, int rows_done = 0,
+             bool stats_next = false);
   // dy -> dz (through BN and the activation); adds dgamma/dbeta; bias gradient of the producing conv into db (optional)
   void bn_bwd(const BnL& bn, const float* dy, const float* z, long P, bool mish, float* dz, float* db, hipStream_t st);
 
@@ -69,6 +70,8 @@ class ClvoTrainer {
   StateDict sd_;
   bool ready_ = false;
   bool conv16_ = !(getenv("ATDN_TRAIN_CONV16") && getenv("ATDN_TRAIN_CONV16")[0] == '0');  // 16-channel convs on the 16x16x4 MFMA kernel
+  // BatchNorm statistics taken in the kernel that writes the layer's input (0: a reduction pass of their own, the A/B partner)
+  bool fused_stats_ = !(getenv("ATDN_TRAIN_FUSED_STATS") && getenv("ATDN_TRAIN_FUSED_STATS")[0] == '0');
   std::map<std::string, Slot> pindex_;
   std::map<std::string, long> sindex_;
   long n_params_ = 0, n_stats_ = 0;

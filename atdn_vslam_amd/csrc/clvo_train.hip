@@ -158,7 +158,9 @@ void ClvoTrainer::finalize() {
   packed_.alloc(packed_n_);
   bnstat_.alloc(bnstat_n_);
   const long Pmax = (long)B * px(1);
-  part_.alloc((long)T * bn_partial_blocks(Pmax) * 2 * 16 + 64);
+  // partial rows of the BatchNorm reductions: per group, one per reduction block, per persistent block of a producing convolution
+  // (<= 1024: train_kernels.hip) or per block of bn_apply
+  part_.alloc((long)T * std::max<long>(std::max<long>(bn_partial_blocks(Pmax), bn_apply_partial_rows(Pmax)), 1024) * 2 * 16 + 64);
   sums_.alloc((long)T * 2 * 16);
   wscratch_.alloc(std::max(wgrad_scratch_floats(0, 0, 16, 3, 3), wgrad_scratch_floats(0, 0, 3, 7, 7)));
   loss_.alloc(4);
@@ -217,14 +219,18 @@ void ClvoTrainer::pack_weights(hipStream_t st) {
   for (auto& r : res_) { pack(r.a.conv); pack(r.b.conv); pack(r.skip); }
 }
 
-void ClvoTrainer::conv_fwd(const ConvL& c, const float* x, int h, int w, float* z, hipStream_t st) {
+// Returns the partial rows per group of the BatchNorm statistics of Mish(z) the kernel left in part_ (with_stats, 16-channel
+// kernels only), or 0: the caller's bn_fwd then reduces z itself.
+int ClvoTrainer::conv_fwd(const ConvL& c, const float* x, int h, int w, float* z, hipStream_t st, bool with_stats) {
+  Conv16Stats cs;
+  cs.part = with_stats && fused_stats_ ? part_.p : nullptr; cs.group_imgs = B; cs.capacity = part_.n;
   if (c.cin == 16 && conv16_) {   // 16 -> 16 channels: the 16x16x4 fp32 MFMA kernel, weights straight from the parameters
-    launch_conv16(x, T * B, h, w, P(c.w), false, P(c.b), c.kh, c.stride, c.pad, z, st);
-    return;
+    launch_conv16(x, T * B, h, w, P(c.w), false, P(c.b), c.kh, c.stride, c.pad, z, st, false, &cs);
+    return cs.rows;
   }
   if (c.cin == 2 && c.cpix == 4 && c.kh == 7 && c.kw == 7 && c.stride == 2 && c.pad == 3 && conv16_) {
-    launch_stem16(x, T * B, h, w, P(c.w), P(c.b), z, st);
-    return;
+    launch_stem16(x, T * B, h, w, P(c.w), P(c.b), z, st, nullptr, &cs);
+    return cs.rows;
   }
   ConvShape s;
   s.src0 = x; s.ld0 = c.cpix; s.sb0 = (long)h * w * c.cpix; s.C0 = c.cpix; s.H = h; s.W = w;
@@ -232,6 +238,7 @@ void ClvoTrainer::conv_fwd(const ConvL& c, const float* x, int h, int w, float* 
   s.w = packed_.p + c.fwd_off; s.ldw = c.kh * round_up(c.kw * c.cpix, 32); s.N = 16; s.nimg = T * B;
   const int oh = conv_out(h, c.kh, c.stride, c.pad), ow = conv_out(w, c.kw, c.stride, c.pad);
   conv_dispatch<MODE_ROW>(s, EpiBias<ACT_NONE>{P(c.b), z, (long)oh * ow * 16, 16, 1.f}, st);
+  return 0;
 }
 
 void ClvoTrainer::conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w_in, int ho, int wo, float* dx, int ldd,
@@ -263,12 +270,23 @@ void ClvoTrainer::conv_bwd_data(const ConvL& c, const float* dz, int h_in, int w
   conv_dispatch<MODE_ROW>(s, EpiBias<ACT_NONE>{nullptr, dx, (long)h_in * w_in * ldd, ldd, 1.f}, st);
 }
 
-void ClvoTrainer::bn_fwd(const BnL& bn, const float* z, long Pg, bool mish, const float* add, float* y, hipStream_t st) {
+// rows_done > 0: part_ already holds that many partial rows per group of this layer's statistics (left there by the kernel that
+// produced z). stats_next: this pass also leaves the statistics of Mish(y) in part_ for the BatchNorm that follows y directly;
+// returns their rows per group (part_ is free again by then: the finalize that read it is earlier in the stream).
+int ClvoTrainer::bn_fwd(const BnL& bn, const float* z, long Pg, bool mish, const float* add, float* y, hipStream_t st, int rows_done,
+                        bool stats_next) {
   float* mean = bnstat_.p + bn.stat_off;
   float* rstd = mean + (long)T * 16;
-  launch_bn_stats(z, T, Pg, mish, part_.p, st);
-  launch_bn_finalize(part_.p, T, Pg, stats_.p + bn.rm, stats_.p + bn.rv, mean, rstd, st);
-  launch_bn_apply(z, T, Pg, mish, mean, rstd, P(bn.gamma), P(bn.beta), add, y, st);
+  if (rows_done > 0) {
+    ATDN_CHECK(mish, "fused statistics are those of Mish(z)");
+    launch_bn_finalize_rows(part_.p, T, rows_done, Pg, stats_.p + bn.rm, stats_.p + bn.rv, mean, rstd, sums_.p, st);
+  } else {
+    launch_bn_stats(z, T, Pg, mish, part_.p, st);
+    launch_bn_finalize(part_.p, T, Pg, stats_.p + bn.rm, stats_.p + bn.rv, mean, rstd, sums_.p, st);   // (sums_: idle in the forward)
+  }
+  const bool next = stats_next && fused_stats_;
+  launch_bn_apply(z, T, Pg, mish, mean, rstd, P(bn.gamma), P(bn.beta), add, y, st, next ? part_.p : nullptr);
+  return next ? bn_apply_partial_rows(Pg) : 0;
 }
 
 void ClvoTrainer::bn_bwd(const BnL& bn, const float* dy, const float* z, long Pg, bool mish, float* dz, float* db, hipStream_t st) {
@@ -293,22 +311,24 @@ float ClvoTrainer::forward_backward(const float* flows, const float* true_rot, c
   // ================= forward (train mode)
   launch_swap_bt(flows, B, T, 2 * px(0), true, flow_.p, st);   // [B][T] clip layout -> step-major [T][B]
   launch_prep_flow(flow_.p, nimg, H, W, P(dw_w_), P(dw_b_), x0_.p, st);
-  conv_fwd(stem_.conv, x0_.p, H, W, z1_.p, st);
-  bn_fwd(stem_.bn, z1_.p, Pg(1), true, nullptr, y1_.p, st);
+  // (round 5: every BatchNorm's statistics come out of the kernel that writes its input — the convolution, or for out_block the
+  // pass that forms zo — instead of a reduction pass of their own; part_ carries them to the finalize right behind)
+  int rows = conv_fwd(stem_.conv, x0_.p, H, W, z1_.p, st, true);
+  bn_fwd(stem_.bn, z1_.p, Pg(1), true, nullptr, y1_.p, st, rows);
   const float* x = y1_.p;
   for (int k = 0; k < 4; ++k) {
     ResBlock& r = res_[k]; ResAct& A = ract_[k];
     const int h = hs_[k + 1], w = ws_[k + 1];
-    conv_fwd(r.a.conv, x, h, w, A.za.p, st);
-    bn_fwd(r.a.bn, A.za.p, Pg(k + 1), true, nullptr, A.ua.p, st);
-    conv_fwd(r.b.conv, A.ua.p, h, w, A.zb.p, st);
-    conv_fwd(r.skip, x, h, w, A.s.p, st);
-    bn_fwd(r.b.bn, A.zb.p, Pg(k + 2), true, A.s.p, A.zo.p, st);    // zo = BN_b(mish(zb)) + skip
-    bn_fwd(r.out, A.zo.p, Pg(k + 2), true, nullptr, A.o.p, st);
+    rows = conv_fwd(r.a.conv, x, h, w, A.za.p, st, true);
+    bn_fwd(r.a.bn, A.za.p, Pg(k + 1), true, nullptr, A.ua.p, st, rows);
+    rows = conv_fwd(r.b.conv, A.ua.p, h, w, A.zb.p, st, true);
+    conv_fwd(r.skip, x, h, w, A.s.p, st, false);
+    rows = bn_fwd(r.b.bn, A.zb.p, Pg(k + 2), true, A.s.p, A.zo.p, st, rows, true);    // zo = BN_b(mish(zb)) + skip
+    bn_fwd(r.out, A.zo.p, Pg(k + 2), true, nullptr, A.o.p, st, rows);
     x = A.o.p;
   }
-  conv_fwd(last_.conv, x, hs_[5], ws_[5], z6_.p, st);
-  bn_fwd(last_.bn, z6_.p, Pg(6), true, nullptr, y6_.p, st);
+  rows = conv_fwd(last_.conv, x, hs_[5], ws_[5], z6_.p, st, true);
+  bn_fwd(last_.bn, z6_.p, Pg(6), true, nullptr, y6_.p, st, rows);
   launch_nhwc_to_chw(y6_.p, nimg, (int)px(6), flat_.p, st);         // nn.Flatten order (C, H, W)
   launch_gemm(false, true, TB, 512, 832, flat_.p, 832, P(fc_.w), 832, zf_.p, 512, 0.f, P(fc_.b), st);
   launch_mish_fwd(zf_.p, feat_.p, (long)TB * 512, st);

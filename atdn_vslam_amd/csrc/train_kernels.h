@@ -19,11 +19,19 @@ int bn_partial_blocks(long P);  // blocks per group the reduction kernels use
 // part[G][nblk][2][16]: sum and sum of squares of a = mish(z) (mish=true) or of z itself
 void launch_bn_stats(const float* z, int G, long P, bool mish, float* part, hipStream_t st);
 // mean/rstd [G][16]; running stats updated sequentially over the G calls (momentum 0.1, unbiased variance)
+// (var_scratch: [G][16] floats, the groups' unbiased variances between the two launches)
 void launch_bn_finalize(const float* part, int G, long P, float* running_mean, float* running_var, float* mean,
-                        float* rstd, hipStream_t st);
-// y = (act(z) - mean) * rstd * gamma + beta (+ add), act = mish or identity
+                        float* rstd, float* var_scratch, hipStream_t st);
+// the same with the partial rows counted by the caller (statistics taken in a producing kernel: Conv16Stats::rows, or
+// bn_apply_partial_rows(P) after launch_bn_apply(..., next_part))
+void launch_bn_finalize_rows(const float* part, int G, int rows, long P, float* running_mean, float* running_var, float* mean,
+                             float* rstd, float* var_scratch, hipStream_t st);
+// y = (act(z) - mean) * rstd * gamma + beta (+ add), act = mish or identity.
+// next_part (optional, [G][bn_apply_partial_rows(P)][2][16]): sums of Mish(y), Mish(y)^2 — the statistics of a BatchNorm that
+// follows y directly (ResidualConv.out_block: bn(mish(x + skip)), layers/conv.py:78-80,88)
+int bn_apply_partial_rows(long P);
 void launch_bn_apply(const float* z, int G, long P, bool mish, const float* mean, const float* rstd, const float* gamma,
-                     const float* beta, const float* add, float* y, hipStream_t st);
+                     const float* beta, const float* add, float* y, hipStream_t st, float* next_part = nullptr);
 // backward: part[G][nblk][2][16] = sum dy, sum dy*xhat
 void launch_bn_bwd_stats(const float* dy, const float* z, int G, long P, bool mish, const float* mean, const float* rstd,
                          float* part, hipStream_t st);
@@ -95,14 +103,21 @@ struct Conv16Tail {
   const float* sc = nullptr; const float* sh = nullptr;
   const float* skip = nullptr; const float* sc2 = nullptr; const float* sh2 = nullptr;
 };
+// Training forward only: BatchNorm statistics of Mish(z) taken in the producing kernel (see c16_stat_flush in train_kernels.hip).
+// `part` [groups][rows][2][16] with `capacity` floats; the launcher zeroes what it uses and sets `rows` (partial rows per group) for
+// launch_bn_finalize_rows. group_imgs = images per statistics group (the images of one time step).
+struct Conv16Stats {
+  float* part = nullptr; int group_imgs = 1; long capacity = 0; int rows = 0;
+};
 void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, const float* bias, float* z, hipStream_t st,
-                   const Conv16Tail* tail = nullptr);
+                   const Conv16Tail* tail = nullptr, Conv16Stats* stat = nullptr);
 // data gradient of a stride-2 16 -> 16 convolution (w OIHW, K = 3 pad 1 or K = 1 pad 0): dx [nimg][H][W][16] from
 // dz [nimg][Ho][Wo][16]; accumulate: dx += instead of dx =
 void launch_tconv16_s2(const float* dz, int nimg, int Ho, int Wo, const float* w, int K, int pad, int H, int W, bool accumulate,
                        float* dx, hipStream_t st);
 void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int K, int S,
-                   int pad, float* z, hipStream_t st, bool accumulate = false);   // accumulate: z += instead of z =
+                   int pad, float* z, hipStream_t st, bool accumulate = false,   // accumulate: z += instead of z =
+                   Conv16Stats* stat = nullptr);
 // the same convolution with an eval-mode tail: K = 3 with S = 1 or 3 (Conv blocks), K = 3, S = 2 with tail.skip (ResidualConv)
 void launch_conv16_eval(const float* x, int nimg, int H, int W, const float* w, const float* bias, int K, int S, int pad,
                         const Conv16Tail& tail, float* z, hipStream_t st);

@@ -18,10 +18,12 @@ namespace {
 struct MishVal { float y, dy; };
 __device__ __forceinline__ MishVal mish_both(float x) {
   if (x > 20.0f) return {x, 1.0f};
+  // (round 5: v_rcp_f32 — 1 ulp — instead of the two IEEE divisions, ~10 instructions each: the statistics taken inside the
+  // convolution kernels pay for every vector instruction of their epilogue)
   const float n = __expf(x);
   const float t = n * (n + 2.0f);
-  const float th = t / (t + 2.0f);
-  const float sg = n / (1.0f + n);
+  const float th = t * __builtin_amdgcn_rcpf(t + 2.0f);
+  const float sg = n * __builtin_amdgcn_rcpf(1.0f + n);
   return {x * th, th + x * (1.0f - th * th) * sg};
 }
 __device__ __forceinline__ float mish_fast(float x) { return mish_both(x).y; }
@@ -124,33 +126,47 @@ __device__ __forceinline__ void sum_partials2(const float* __restrict__ part_g, 
     for (int k = 0; k < 16; ++k) { s1 += r[0][k][ch]; s2 += r[1][k][ch]; }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int G, int nblk, double invP,
-                                                          double unbias, float* __restrict__ rm, float* __restrict__ rv,
-                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+// One block per group sums its partial rows (round 5: up to 1,024 of them when a convolution kernel took the statistics — the
+// groups one after the other in ONE block cost 70 us per layer); a second, 16-thread launch walks the running statistics through
+// the groups IN ORDER, as G successive forward() calls would. (Not a last-block-finishes counter: a device-scope release on this
+// chip writes back an XCD's whole L2, kernels.hip.)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, double invP, double unbias,
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* __restrict__ var_g) {
   __shared__ double r[2][16][16];
-  const int ch = threadIdx.x & 15;
-  const bool lead = threadIdx.x < 16;
+  const int ch = threadIdx.x & 15, g = blockIdx.x;
+  double s1, s2;
+  sum_partials2(part + (long)g * nblk * 32, nblk, r, s1, s2);
+  if (threadIdx.x < 16) {
+    const double mu = s1 * invP;
+    double var = s2 * invP - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[g * 16 + ch] = (float)mu;
+    rstd[g * 16 + ch] = (float)(1.0 / sqrt(var + 1e-5));
+    var_g[g * 16 + ch] = (float)(var * unbias);
+  }
+}
+__global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var_g, int G, float* __restrict__ rm,
+                                  float* __restrict__ rv) {
+  const int ch = threadIdx.x;
   float m_run = rm[ch], v_run = rv[ch];
   for (int g = 0; g < G; ++g) {
-    double s1, s2;
-    sum_partials2(part + (long)g * nblk * 32, nblk, r, s1, s2);
-    if (lead) {
-      const double mu = s1 * invP;
-      double var = s2 * invP - mu * mu;
-      if (var < 0.0) var = 0.0;
-      mean[g * 16 + ch] = (float)mu;
-      rstd[g * 16 + ch] = (float)(1.0 / sqrt(var + 1e-5));
-      m_run = 0.9f * m_run + 0.1f * (float)mu;                 // torch: running = (1-momentum)*running + momentum*batch
-      v_run = 0.9f * v_run + 0.1f * (float)(var * unbias);
-    }
+    m_run = 0.9f * m_run + 0.1f * mean[g * 16 + ch];                 // torch: running = (1-momentum)*running + momentum*batch
+    v_run = 0.9f * v_run + 0.1f * var_g[g * 16 + ch];
   }
-  if (lead) { rm[ch] = m_run; rv[ch] = v_run; }
+  rm[ch] = m_run; rv[ch] = v_run;
+}
+void launch_bn_finalize_rows(const float* part, int G, int rows, long P, float* running_mean, float* running_var, float* mean,
+                             float* rstd, float* var_scratch, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(G), dim3(256), 0, st, part, rows, 1.0 / (double)P,
+                     P > 1 ? (double)P / (double)(P - 1) : 1.0, mean, rstd, var_scratch);
+  ATDN_HIP(hipGetLastError());
+  hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(16), 0, st, mean, var_scratch, G, running_mean, running_var);
+  ATDN_HIP(hipGetLastError());
 }
 void launch_bn_finalize(const float* part, int G, long P, float* running_mean, float* running_var, float* mean, float* rstd,
-                        hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, part, G, bn_partial_blocks(P), 1.0 / (double)P,
-                     P > 1 ? (double)P / (double)(P - 1) : 1.0, running_mean, running_var, mean, rstd);
-  ATDN_HIP(hipGetLastError());
+                        float* var_scratch, hipStream_t st) {
+  launch_bn_finalize_rows(part, G, bn_partial_blocks(P), P, running_mean, running_var, mean, rstd, var_scratch, st);
 }
 
 // (round 5: one group per blockIdx.y and a strip of pixels per block, four float4 — eight with the residual — in flight per thread and
@@ -160,7 +176,7 @@ constexpr long kApplyPix = 4096;   // pixels per block
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ z, long P, int mish, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float4* __restrict__ add,
-                                                       float4* __restrict__ y) {
+                                                       float4* __restrict__ y, float* __restrict__ next_part) {
   const int g = blockIdx.y;
   const int quad = threadIdx.x & 3, lane_pix = threadIdx.x >> 2;
   const long p0 = (long)blockIdx.x * kApplyPix, p1 = min(p0 + kApplyPix, P);
@@ -170,6 +186,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
     const int ch = quad * 4 + e;
     mu[e] = mean[g * 16 + ch]; rs[e] = rstd[g * 16 + ch]; ga[e] = gamma[ch]; be[e] = beta[ch];
   }
+  float n1[4] = {0.f, 0.f, 0.f, 0.f}, n2[4] = {0.f, 0.f, 0.f, 0.f};   // next_part: sums of Mish(y), Mish(y)^2
   auto one = [&](const float4 v, const float4 r) {
     const float a[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r.x, r.y, r.z, r.w};
     float o[4];
@@ -178,6 +195,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
       const float x = mish ? mish_fast(a[e]) : a[e];
       o[e] = (x - mu[e]) * rs[e] * ga[e] + be[e];
       o[e] += rr[e];   // (zeros without a residual: x + 0 = x)
+      if (next_part) { const float m = mish_fast(o[e]); n1[e] += m; n2[e] += m * m; }
     }
     return make_float4(o[0], o[1], o[2], o[3]);
   };
@@ -195,12 +213,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
     const long i = ((long)g * P + p) * 4 + quad;
     y[i] = one(z[i], add ? add[i] : zero);
   }
+  if (next_part) {   // the block's partial row, reduced like reduce2_kernel's
+    __shared__ float red[2][256][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = n1[e]; red[1][threadIdx.x][e] = n2[e]; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int which = threadIdx.x >> 4, ch = threadIdx.x & 15;
+      float acc = 0.f;
+      for (int t = (ch >> 2); t < 256; t += 4) acc += red[which][t][ch & 3];
+      next_part[(((long)g * gridDim.x + blockIdx.x) * 2 + which) * 16 + ch] = acc;
+    }
+  }
 }
+int bn_apply_partial_rows(long P) { return (int)cdivl(P, kApplyPix); }
 void launch_bn_apply(const float* z, int G, long P, bool mish, const float* mean, const float* rstd, const float* gamma,
-                     const float* beta, const float* add, float* y, hipStream_t st) {
+                     const float* beta, const float* add, float* y, hipStream_t st, float* next_part) {
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)cdivl(P, kApplyPix), G), dim3(256), 0, st,
                      reinterpret_cast<const float4*>(z), P, mish ? 1 : 0, mean, rstd, gamma, beta,
-                     reinterpret_cast<const float4*>(add), reinterpret_cast<float4*>(y));
+                     reinterpret_cast<const float4*>(add), reinterpret_cast<float4*>(y), next_part);
   ATDN_HIP(hipGetLastError());
 }
 
@@ -1073,6 +1104,34 @@ __device__ __forceinline__ float c16_tail(float v, const C16Consts& c, const flo
   return mish_tail_(y + skip[o]) * c.sc2 + c.sh2;
 }
 
+// Training forward (TAIL 0) with `st.part` set: the sums of Mish(z) and Mish(z)^2 per (statistics group, channel) that the
+// BatchNorm behind the convolution needs (layers/conv.py:38: bn(activation(conv(x)))) are taken from the values on their way
+// to memory — the separate pass that re-read z for them was 9 % of a training iteration. A lane keeps the sums of its four
+// channels while the block's tiles stay in one group (group = image / st.group_imgs: the images of one time step) and the
+// block writes ONE partial row per group it met: part[group][block][2][16] (zeroed by the launcher; bn_finalize adds the rows
+// in double, in a fixed order: no atomics).
+struct C16StatAcc {
+  float s1[4], s2[4];
+  int grp;
+};
+__device__ __forceinline__ void c16_stat_flush(C16StatAcc& a, const Conv16Stats& st, float (*sred)[2][16]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { a.s1[e] += __shfl_xor(a.s1[e], m); a.s2[e] += __shfl_xor(a.s2[e], m); }
+    if (n == 0) { sred[wave][0][4 * g + e] = a.s1[e]; sred[wave][1][4 * g + e] = a.s2[e]; }
+    a.s1[e] = 0.f; a.s2[e] = 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int which = threadIdx.x >> 4, ch = threadIdx.x & 15;
+    const float t = (sred[0][which][ch] + sred[1][which][ch]) + (sred[2][which][ch] + sred[3][which][ch]);
+    st.part[(((long)a.grp * gridDim.x + blockIdx.x) * 2 + which) * 16 + ch] = t;
+  }
+  __syncthreads();
+}
+
 // K operand order: MFMA (tap, j) holds channel 4g + j in k-slot g = lane >> 4, so a lane's float4 (channels 4g..4g+3 of
 // its pixel) feeds the four MFMAs of a tap component by component.
 template <int K, int S, int TH, int TW, int TAIL = 0>
@@ -1080,7 +1139,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
                                                      const float* __restrict__ w, int transposed,
                                                      const float* __restrict__ bias, int pad, int Ho, int Wo,
                                                      float* __restrict__ z, int tiles_x, int tiles_img, int ntiles,
-                                                     int accumulate, const Conv16Tail tail) {
+                                                     int accumulate, const Conv16Tail tail, const Conv16Stats stat) {
   constexpr int PH = (TH - 1) * S + K, PW = (TW - 1) * S + K, PP = c16_pitch(S);
   __shared__ __attribute__((aligned(16))) float patch[PH * PW * PP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1120,9 +1179,19 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
     }
   };
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  __shared__ float sred[4][2][16];
+  C16StatAcc sa{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, -1};
+  const bool stats = TAIL == 0 && stat.part != nullptr;
   for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
     const int img = bt / tiles_img, tloc = bt - img * tiles_img;
     const int oy0 = (tloc / tiles_x) * TH, ox0 = (tloc % tiles_x) * TW;
+    if (stats) {   // (uniform over the block: every thread walks the same tiles)
+      const int grp = img / stat.group_imgs;
+      if (grp != sa.grp) {
+        if (sa.grp >= 0) c16_stat_flush(sa, stat, sred);
+        sa.grp = grp;
+      }
+    }
     __syncthreads();   // everyone is done with the previous patch
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -1163,6 +1232,10 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
           const float od[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[e] + bv[e] + od[e];
+          if (stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float m = mish_fast(v[e]); sa.s1[e] += m; sa.s2[e] += m * m; }
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = c16_tail<TAIL>(acc[e] + bv[e], cc[e], tail.skip, o + e);
@@ -1173,17 +1246,27 @@ __global__ __launch_bounds__(256) void conv16_kernel(const float* __restrict__ x
       put(acc1, oy0 + ty1, ox0 + tx1 + n);
     }
   }
+  if (stats && sa.grp >= 0) c16_stat_flush(sa, stat, sred);
 }
 
 template <int K, int S, int TH, int TW, int TAIL = 0>
 void conv16_launch(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int pad,
-                   float* z, bool accumulate, hipStream_t st, const Conv16Tail& tail = Conv16Tail{}) {
+                   float* z, bool accumulate, hipStream_t st, const Conv16Tail& tail = Conv16Tail{}, Conv16Stats* stat = nullptr) {
   const int Ho = (H + 2 * pad - K) / S + 1, Wo = (W + 2 * pad - K) / S + 1;
   const int tx = cdiv(Wo, TW), ty = cdiv(Ho, TH);
   const int ntiles = nimg * tx * ty;
   const int grid = ntiles < 256 * 3 ? ntiles : 256 * 3;   // persistent blocks: the weights are loaded into registers once
+  Conv16Stats sv;
+  if (stat && stat->part) {
+    ATDN_CHECK(TAIL == 0 && !accumulate && stat->group_imgs >= 1 && nimg % stat->group_imgs == 0, "conv16 statistics: plain training forward only");
+    const int groups = nimg / stat->group_imgs;
+    ATDN_CHECK((long)groups * grid * 32 <= stat->capacity, "conv16 statistics: partial buffer too small");
+    ATDN_HIP(hipMemsetAsync(stat->part, 0, (size_t)groups * grid * 32 * sizeof(float), st));   // blocks write the groups they meet
+    stat->rows = grid;
+    sv = *stat;
+  }
   hipLaunchKernelGGL((conv16_kernel<K, S, TH, TW, TAIL>), dim3(grid), dim3(256), 0, st, x, nimg, H, W, w, transposed ? 1 : 0, bias,
-                     pad, Ho, Wo, z, tx, tx * ty, ntiles, accumulate ? 1 : 0, tail);
+                     pad, Ho, Wo, z, tx, tx * ty, ntiles, accumulate ? 1 : 0, tail, sv);
   ATDN_HIP(hipGetLastError());
 }
 }  // namespace
@@ -1198,7 +1281,8 @@ template <int TAIL>
 __global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x, int nimg, int H, int W,
                                                      const float* __restrict__ w /*[16][2][7][7]*/,
                                                      const float* __restrict__ bias, int Ho, int Wo, float* __restrict__ z,
-                                                     int tiles_x, int tiles_img, int ntiles, const Conv16Tail tail) {
+                                                     int tiles_x, int tiles_img, int ntiles, const Conv16Tail tail,
+                                                     const Conv16Stats stat) {
   __shared__ __attribute__((aligned(16))) float patch[ST_PH * ST_ROWP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
   float breg[7][4];
@@ -1229,9 +1313,19 @@ __global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x
   };
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
   constexpr int TILES = ST_TH * ST_TW / 16, TPR = ST_TW / 16;
+  __shared__ float sred[4][2][16];
+  C16StatAcc sa{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, -1};
+  const bool stats = TAIL == 0 && stat.part != nullptr;
   for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
     const int img = bt / tiles_img, tloc = bt - img * tiles_img;
     const int oy0 = (tloc / tiles_x) * ST_TH, ox0 = (tloc % tiles_x) * ST_TW;
+    if (stats) {
+      const int grp = img / stat.group_imgs;
+      if (grp != sa.grp) {
+        if (sa.grp >= 0) c16_stat_flush(sa, stat, sred);
+        sa.grp = grp;
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -1264,25 +1358,41 @@ __global__ __launch_bounds__(256) void stem16_kernel(const float* __restrict__ x
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = c16_tail<TAIL>(acc[e] + bv[e], cc[e], nullptr, 0);
         *reinterpret_cast<float4*>(z + (((long)img * Ho + oy) * Wo + ox) * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        if (stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float m = mish_fast(v[e]); sa.s1[e] += m; sa.s2[e] += m * m; }
+        }
       };
       put(acc0, oy0 + ty0, ox0 + tx0 + n);
       put(acc1, oy0 + ty1, ox0 + tx1 + n);
     }
   }
+  if (stats && sa.grp >= 0) c16_stat_flush(sa, stat, sred);
 }
 }  // namespace
 
 void launch_stem16(const float* x4, int nimg, int H, int W, const float* w, const float* bias, float* z, hipStream_t st,
-                   const Conv16Tail* tail) {
+                   const Conv16Tail* tail, Conv16Stats* stat) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int tx = cdiv(Wo, ST_TW), ty = cdiv(Ho, ST_TH), ntiles = nimg * tx * ty;
   const int grid = ntiles < 256 * 4 ? ntiles : 256 * 4;
   if (tail) {
     ATDN_CHECK(tail->sc && tail->sh && !tail->skip, "stem tail is BN(Mish(.))");
-    hipLaunchKernelGGL(stem16_kernel<1>, dim3(grid), dim3(256), 0, st, x4, nimg, H, W, w, bias, Ho, Wo, z, tx, tx * ty, ntiles, *tail);
+    ATDN_CHECK(!stat || !stat->part, "stem statistics: training forward only");
+    hipLaunchKernelGGL(stem16_kernel<1>, dim3(grid), dim3(256), 0, st, x4, nimg, H, W, w, bias, Ho, Wo, z, tx, tx * ty, ntiles, *tail,
+                       Conv16Stats{});
   } else {
+    Conv16Stats sv;
+    if (stat && stat->part) {
+      ATDN_CHECK(stat->group_imgs >= 1 && nimg % stat->group_imgs == 0, "stem statistics: whole groups of images");
+      const int groups = nimg / stat->group_imgs;
+      ATDN_CHECK((long)groups * grid * 32 <= stat->capacity, "stem statistics: partial buffer too small");
+      ATDN_HIP(hipMemsetAsync(stat->part, 0, (size_t)groups * grid * 32 * sizeof(float), st));
+      stat->rows = grid;
+      sv = *stat;
+    }
     hipLaunchKernelGGL(stem16_kernel<0>, dim3(grid), dim3(256), 0, st, x4, nimg, H, W, w, bias, Ho, Wo, z, tx, tx * ty, ntiles,
-                       Conv16Tail{});
+                       Conv16Tail{}, sv);
   }
   ATDN_HIP(hipGetLastError());
 }
@@ -1389,12 +1499,13 @@ void launch_tconv16_s2(const float* dz, int nimg, int Ho, int Wo, const float* w
 }
 
 void launch_conv16(const float* x, int nimg, int H, int W, const float* w, bool transposed, const float* bias, int K, int S,
-                   int pad, float* z, hipStream_t st, bool accumulate) {
-  if (K == 3 && S == 1) conv16_launch<3, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
-  else if (K == 3 && S == 2) conv16_launch<3, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
-  else if (K == 3 && S == 3) conv16_launch<3, 3, 2, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
-  else if (K == 1 && S == 2) conv16_launch<1, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
-  else if (K == 1 && S == 1) conv16_launch<1, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st);
+                   int pad, float* z, hipStream_t st, bool accumulate, Conv16Stats* stat) {
+  const Conv16Tail nt{};
+  if (K == 3 && S == 1) conv16_launch<3, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st, nt, stat);
+  else if (K == 3 && S == 2) conv16_launch<3, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st, nt, stat);
+  else if (K == 3 && S == 3) conv16_launch<3, 3, 2, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st, nt, stat);
+  else if (K == 1 && S == 2) conv16_launch<1, 2, 4, 32>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st, nt, stat);
+  else if (K == 1 && S == 1) conv16_launch<1, 1, 8, 64>(x, nimg, H, W, w, transposed, bias, pad, z, accumulate, st, nt, stat);
   else throw Error("conv16: no kernel for this shape");
 }
 

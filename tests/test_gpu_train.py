@@ -142,3 +142,34 @@ def test_training_iteration_at_the_baseline_shape_matches_the_oracle():
         assert float((got - p)[ok].abs().max()) <= 2e-5 * float(p.abs().max()) + 2e-6, k
         assert abs(float(got.double().norm()) - float(p.double().norm())) <= 2e-5 * float(p.double().norm()), k
     print("24x6 iteration: loss %.6f (oracle %.6f), worst gradient-norm deviation %.2e" % (loss, float(ref_loss), worst))
+
+
+def test_fused_batchnorm_statistics_match_the_separate_reduction(monkeypatch):
+    """Round 5: the BatchNorm statistics of the training forward come out of the kernel that writes the layer's input (the
+    16-channel convolutions' epilogue, or bn_apply for out_block). ATDN_TRAIN_FUSED_STATS=0 is the reduction pass of their own they
+    replaced: same values, another summation order — loss, predictions, running statistics and gradients agree to fp32 rounding."""
+    B, T = 3, 4
+    sd = syn.to_torch(syn.make_clvo_state(seed=3))
+    flows = torch.from_numpy(syn.make_flow(B * T, 376, 1232, seed=78)).view(B, T, 2, 376, 1232).to(DEV)
+    r = np.random.RandomState(6)
+    true_rot = torch.from_numpy(r.normal(0, 0.01, (B, T, 3)).astype(np.float32))
+    true_tr = torch.from_numpy(r.normal(0, 0.5, (B, T, 3)).astype(np.float32))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ATDN_TRAIN_FUSED_STATS", mode)   # read when the trainer is constructed
+        tr = CLVOTrainer(sd, B, T, device=DEV, lr=1e-3, weight_decay=1e-3, eps=1e-8, total_steps=10, eta_min=1e-9)
+        loss, pr, pt = tr.forward_backward(flows, true_rot, true_tr)
+        out[mode] = (loss, pr.cpu(), pt.cpu(),
+                     {k: tr.gradient(k).cpu() for k in ("encoder_CNN.1.conv.weight", "encoder_CNN.2.conv.0.bn.weight",
+                                                        "encoder_CNN.5.out_block.1.bias", "lstm1.weight_ih")},
+                     {k: v.cpu() for k, v in tr.state_dict().items()
+                      if k in ("encoder_CNN.1.bn.running_mean", "encoder_CNN.3.out_block.1.running_var", "encoder_CNN.6.bn.running_var")})
+    a, b = out["1"], out["0"]
+    assert abs(a[0] - b[0]) < 1e-5 * max(1.0, abs(b[0]))
+    assert float((a[1] - b[1]).abs().max()) < 1e-5 and float((a[2] - b[2]).abs().max()) < 1e-5
+    for k in a[3]:
+        na, d = float(b[3][k].double().norm()), float((a[3][k] - b[3][k]).double().norm())
+        assert d <= 1e-3 * na + 1e-9, (k, d, na)
+    assert len(a[4]) == 3
+    for k in a[4]:
+        assert float((a[4][k] - b[4][k]).abs().max()) <= 1e-5 * float(b[4][k].abs().max()) + 1e-7, k
