@@ -49,5 +49,11 @@ if __name__ == "__main__":   # python tests/test_kernel_occupancy.py --regen : r
         sys.path.insert(0, ROOT)
         old = json.load(open(os.path.join(ROOT, "tests", "golden", "kernel_occupancy.json")))
         cur = _current()
-        json.dump({k: cur[k] for k in sorted(old) if k in cur}, open(os.path.join(ROOT, "tests", "golden", "kernel_occupancy.json"), "w"), indent=0, sort_keys=True)
-        print("rewrote %d of %d entries" % (sum(k in cur for k in old), len(old)))
+        # a kernel whose argument list changed keeps its place in the table under its new name (same name up to the "(")
+        bases = {k.split("(")[0] for k in old}
+        new = {k: v for k, v in cur.items() if k in old or k.split("(")[0] in bases}
+        for k in sorted(set(new) - set(old)):
+            was = [old[o] for o in old if o.split("(")[0] == k.split("(")[0]]
+            print("renamed: %s  now %s, was %s" % (k[:100], new[k], was[:1]))
+        json.dump(new, open(os.path.join(ROOT, "tests", "golden", "kernel_occupancy.json"), "w"), indent=0, sort_keys=True)
+        print("table: %d entries (%d before)" % (len(new), len(old)))
