@@ -107,7 +107,7 @@ class GmaNet {
   long gamma_off_ = -1;
 
   // workspace
-  DeviceBuf img4_, enc_[4], scratch_, pcnt_, fin_, fmap_, psum_, pm2_, mean_[2], rstd_[2];
+  DeviceBuf img4_, enc_[4], scratch_, pcnt_, fin_, fmap_, psum_, pm2_, mean_[3], rstd_[3];   // [2]: the feature network's stem statistics, alive until its first block's residual pass
   DeviceBuf pyr_[4], h_[2], x_, qk_, attn_, vT_, corrfeat_, cor1_, corflo_, flo1_, z_, rh_, fh_, mask_;
   DeviceBuf coords1_, flow4_, pre_zr_[2], pre_q_[2];
   int pyrH_[4], pyrW_[4];

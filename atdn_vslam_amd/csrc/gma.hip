@@ -151,8 +151,8 @@ GmaNet::~GmaNet() {
   (void)hipDeviceSynchronize();
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &rstd_[0],
-                      &rstd_[1], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
+  DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &mean_[2], &rstd_[0],
+                      &rstd_[1], &rstd_[2], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
                       &pre_zr_[1], &pre_q_[0], &pre_q_[1], &rowmax_, &rinv_,
                       &fbrick_[0], &fbrick_[1], &fbrick_[2], &fbrick_[3], &fplain_[0], &fplain_[1], &fplain_[2], &coords_used_, &fhG_};
@@ -256,7 +256,7 @@ void GmaNet::finalize() {
   fmap_.alloc(2L * B * N * 256);
   const long groups = (long)cdiv(H2 * W2, 64) * 4 + 8;
   psum_.alloc(2L * B * groups * 128); pm2_.alloc(2L * B * groups * 128); pcnt_.alloc(2L * B * groups); fin_.alloc(2L * B * 32 * 128 * 4 * 2);
-  for (int i = 0; i < 2; ++i) { mean_[i].alloc(2L * B * 128); rstd_[i].alloc(2L * B * 128); }
+  for (int i = 0; i < 3; ++i) { mean_[i].alloc(2L * B * 128); rstd_[i].alloc(2L * B * 128); }
   pyrH_[0] = H8; pyrW_[0] = W8;
   for (int l = 1; l < 4; ++l) { pyrH_[l] = pyrH_[l - 1] / 2; pyrW_[l] = pyrW_[l - 1] / 2; }
   ATDN_CHECK(pyrH_[3] >= 2 && pyrW_[3] >= 2, "frame too small for a 4-level pyramid");
@@ -498,7 +498,15 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
   };
   // 7x7 stem on the split-f16 engine (stem_sf.hip); with InstanceNorm the conv runs twice (statistics, then
   // normalise + ReLU -> sf) instead of materialising the raw tensor
-  if (instance) {
+  // (round 5, split-f16 mode: ONE pass — raw fp32 output + statistics; the first block normalises it on load, below)
+  const bool stem_raw = instance && norm_on_load_;
+  if (stem_raw) {
+    const int groups = stem_sf_groups(h, w);
+    ATDN_CHECK((long)nimg * groups * 64 <= psum_.n && (long)nimg * groups <= pcnt_.n, "statistics scratch too small");
+    launch_stem_sf(3, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, X, psum_.p, pm2_.p, pcnt_.p, nullptr, nullptr, st);
+    launch_in_finalize_cnt(psum_.p, pm2_.p, pcnt_.p, nimg, groups, h * w, 64, 1e-5f, mean_[2].p, rstd_[2].p,
+                           reinterpret_cast<double*>(fin_.p), st);
+  } else if (instance) {
     const int groups = stem_sf_groups(h, w);
     ATDN_CHECK((long)nimg * groups * 64 <= psum_.n && (long)nimg * groups <= pcnt_.n, "statistics scratch too small");
     launch_stem_sf(1, images, nimg, H, W, E.stem.wf, E.stem.wscale, E.stem.b, nullptr, psum_.p, pm2_.p, pcnt_.p, nullptr,
@@ -522,11 +530,15 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
       // conv1 -> (InstanceNorm + ReLU inside conv2's patch loader) -> conv2: the pass that used to materialise
       // relu(IN(conv1)) between them (4 B read + 4 B written per element) is gone. conv2's statistics land in slot 1
       // because slot 0 (conv1's) is read by conv2 itself.
-      stats_sf(Bk.c1, X, c, h, w, stride, 1, R, 0);
+      const bool raw_in = stem_raw && bi == 0;   // X is the stem's RAW output: conv1 normalises on load, the shortcut on the fly
+      ATDN_CHECK(!raw_in || !Bk.has_ds, "the block behind the stem has no downsample branch");
+      stats_sf(Bk.c1, X, c, h, w, stride, 1, R, 0, raw_in ? 2 : -1);
       stats_sf(Bk.c2, R, co, oh, ow, 1, 1, Y, 1, 0);
       if (Bk.has_ds) {
         stats_sf(Bk.ds, X, c, h, w, 2, 0, R, 0);  // R is dead once conv2 has consumed it: holds the raw shortcut
         launch_in_apply_sf(Y, O, mean_[1].p, rstd_[1].p, nullptr, R, mean_[0].p, rstd_[0].p, nimg, ohw, co, st);
+      } else if (raw_in) {
+        launch_in_apply_sf(Y, O, mean_[1].p, rstd_[1].p, nullptr, X, mean_[2].p, rstd_[2].p, nimg, ohw, co, st, true);
       } else {
         launch_in_apply_sf(Y, O, mean_[1].p, rstd_[1].p, X, nullptr, nullptr, nullptr, nimg, ohw, co, st);
       }

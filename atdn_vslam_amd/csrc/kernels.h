@@ -86,7 +86,7 @@ void launch_from_sf(const float* src, float* dst, long rows, int C, hipStream_t 
 // `res_raw` normalised with rmean/rrstd): y = relu(r + y)
 void launch_in_apply_sf(const float* x, float* y, const float* mean, const float* rstd, const float* res,
                         const float* res_raw, const float* rmean, const float* rrstd, int nimg, long HW, int C,
-                        hipStream_t st);
+                        hipStream_t st, bool res_relu = false);
 // 2x2 average (floor sizes) of an sf feature map [img][H*W][C] (per-image strides sb / db in floats)
 void launch_pool_features_sf(const float* src, int nimg, int H, int W, int C, long sb, float* dst, long db, hipStream_t st);
 // as launch_init_coords, x flow channels written in sf at channels cflow, cflow+1 of the sf GRU input

@@ -663,7 +663,7 @@ void launch_from_sf(const float* src, float* dst, long rows, int C, hipStream_t 
 __global__ void in_apply_sf_kernel(const float4* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, const float* __restrict__ res,
                                    const float4* __restrict__ res_raw, const float* __restrict__ rmean,
-                                   const float* __restrict__ rrstd, long per_img4, int C, long total4) {
+                                   const float* __restrict__ rrstd, int res_relu, long per_img4, int C, long total4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long img = i / per_img4;
     const int c = (int)((i * 4) % C);
@@ -684,6 +684,9 @@ __global__ void in_apply_sf_kernel(const float4* __restrict__ x, float* __restri
         const float* r2 = rrstd + img * C + c;
         r.x = (r.x - m2[0]) * r2[0]; r.y = (r.y - m2[1]) * r2[1];
         r.z = (r.z - m2[2]) * r2[2]; r.w = (r.w - m2[3]) * r2[3];
+        if (res_relu) {   // the shortcut is relu(IN(raw stem output)) (extractor.py:161-163), never materialised
+          r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+        }
       }
       v.x = fmaxf(r.x + v.x, 0.f); v.y = fmaxf(r.y + v.y, 0.f);
       v.z = fmaxf(r.z + v.z, 0.f); v.w = fmaxf(r.w + v.w, 0.f);
@@ -693,12 +696,12 @@ __global__ void in_apply_sf_kernel(const float4* __restrict__ x, float* __restri
 }
 void launch_in_apply_sf(const float* x, float* y, const float* mean, const float* rstd, const float* res,
                         const float* res_raw, const float* rmean, const float* rrstd, int nimg, long HW, int C,
-                        hipStream_t st) {
+                        hipStream_t st, bool res_relu) {
   ATDN_CHECK(C % 32 == 0, "sf tensors need C % 32 == 0");
   const long per_img4 = HW * C / 4, total4 = per_img4 * nimg;
   const int grid = (int)std::min<long>(cdivl(total4, 256), 256 * 16);
   hipLaunchKernelGGL(in_apply_sf_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(x), y, mean,
-                     rstd, res, reinterpret_cast<const float4*>(res_raw), rmean, rrstd, per_img4, C, total4);
+                     rstd, res, reinterpret_cast<const float4*>(res_raw), rmean, rrstd, res_relu ? 1 : 0, per_img4, C, total4);
   ATDN_HIP(hipGetLastError());
 }
 

@@ -15,6 +15,11 @@
 //     The conv is so cheap that it is simply run TWICE: MODE_STATS computes it for the per-(32-pixel group, channel)
 //     partial sums only (nothing else is written), MODE_NORM recomputes it and writes relu((conv + bias - mean) * rstd)
 //     as sf. The raw fp32 tensor (237 MB per 8 frames), its re-read and the separate normalisation pass are gone.
+//     Round 5, MODE_RAW_STATS (3): ONE pass that stores the raw conv + bias as fp32 (the same 4 bytes per value as the sf
+//     tensor MODE_NORM wrote) and the same partial sums; nobody materialises relu(IN(.)) any more — layer1.0's first
+//     conv normalises in its patch loader (conv_sf6.h, as every second conv of a block already does) and the block's
+//     residual pass normalises the shortcut on the fly (in_apply_sf_kernel). The split-f16 feature network runs this;
+//     the f16 fast mode keeps the two-pass form.
 //   * the sf output of a row tile (32 pixels x 256 B, contiguous in memory) is assembled in a wave-private LDS slab and
 //     stored as whole lines, 1 KiB per wave instruction.
 #include "conv_mfma.h"
@@ -191,6 +196,10 @@ __global__ __launch_bounds__(256, MODE == 1 ? 4 : 3) void stem_sf_kernel(const S
           const float4 b = *reinterpret_cast<const float4*>(&cst[0][c]);
           float x[4] = {acc[i][j][4 * k] * a.wscale + b.x, acc[i][j][4 * k + 1] * a.wscale + b.y,
                         acc[i][j][4 * k + 2] * a.wscale + b.z, acc[i][j][4 * k + 3] * a.wscale + b.w};
+          if constexpr (MODE == 3) {   // raw fp32 into the slab: 64 channels x 4 B = the 256 B of an sf pixel
+            *reinterpret_cast<float4*>(slab + r * SLAB_PITCH + c * 4) = make_float4(x[0], x[1], x[2], x[3]);
+            continue;
+          }
           if constexpr (MODE == 2) {
             const float4 mu = *reinterpret_cast<const float4*>(&cst[1][c]);
             const float4 rs = *reinterpret_cast<const float4*>(&cst[2][c]);
@@ -217,6 +226,27 @@ __global__ __launch_bounds__(256, MODE == 1 ? 4 : 3) void stem_sf_kernel(const S
         const int px = 4 * p + (lane >> 4);
         const v4f v = *reinterpret_cast<const v4f*>(slab + px * SLAB_PITCH + (lane & 15) * 16);
         if (oy < a.Ho && tx0 + px < a.Wo) *reinterpret_cast<v4f*>(orow + px * 64 + (lane & 15) * 4) = v;
+      }
+      if constexpr (MODE == 3) {
+        // statistics of the row tile's 32 pixels from the slab: lane = channel, the pixels in order (the grouping and the order
+        // follow from the layer's geometry alone: a clip, a continued clip and single pairs produce the same bits)
+        float v[32];
+        float sum = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int px = 0; px < 32; ++px) {
+          v[px] = *reinterpret_cast<const float*>(slab + px * SLAB_PITCH + lane * 4);
+          if (oy < a.Ho && tx0 + px < a.Wo) { sum += v[px]; ++cnt; }
+        }
+        const float mean = sum / (float)(cnt > 0 ? cnt : 1);
+        float m2 = 0.f;
+#pragma unroll
+        for (int px = 0; px < 32; ++px)
+          if (oy < a.Ho && tx0 + px < a.Wo) { const float d = v[px] - mean; m2 += d * d; }
+        const long gi = (long)img * (a.tiles_img * TH) + tloc * TH + 2 * wave + i;
+        a.part_sum[gi * 64 + lane] = sum;
+        a.part_m2[gi * 64 + lane] = m2;
+        if (lane == 0) a.part_cnt[gi] = (float)cnt;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next row tile
@@ -246,6 +276,9 @@ void launch_stem_sf(int mode, const float* img4, int nimg, int H, int W, const f
   } else if (mode == 1) {
     ATDN_CHECK(part_sum && part_m2 && part_cnt, "stem statistics buffers missing");
     hipLaunchKernelGGL(stem_sf_kernel<1>, grid, block, 0, st, a);
+  } else if (mode == 3) {
+    ATDN_CHECK(out_sf && part_sum && part_m2 && part_cnt, "stem raw output / statistics buffers missing");
+    hipLaunchKernelGGL(stem_sf_kernel<3>, grid, block, 0, st, a);
   } else {
     ATDN_CHECK(out_sf && mean && rstd, "stem normalisation operands missing");
     hipLaunchKernelGGL(stem_sf_kernel<2>, grid, block, 0, st, a);
