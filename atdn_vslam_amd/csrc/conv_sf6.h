@@ -510,7 +510,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
             for (int w = 0; w < NW; ++w) sum += rq[w * (32 * LDS_LD)];   // fixed order: deterministic
             const int p = i * 32 + px;
             const int oy = ty0 + p / TW, ox = tx0 + p % TW;
-            if (oy < g.Ho && ox < g.Wo) ep.G[((long)img * ep.npix + (long)oy * g.Wo + ox) * 18 + u] = sum;
+            if (oy < g.Ho && ox < g.Wo)
+              ep.G[(long)(n0 / (NW * 32)) * ep.gstride + ((long)img * ep.npix + (long)oy * g.Wo + ox) * 18 + u] = sum;
           }
           __syncthreads();   // the slabs are rewritten by the next row tile
         }

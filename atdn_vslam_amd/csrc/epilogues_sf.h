@@ -236,8 +236,9 @@ struct SfFlowHeadPartial {
   static constexpr int kGen6 = 1;
   const float* bias;   // conv1 bias [256]
   const float* w2;     // conv2 weights, fp32 [18][256]: row tap * 2 + output
-  float* G; long npix; // [img][pix][18]
+  float* G; long npix; // [channel block of the launch][img][pix][18]: a block of BN < 256 channels writes its own copy, the gather adds them
   float w2mul, w2inv;  // power-of-two scale of conv2's weights for the split-f16 product (max |w| in [1, 2)) and its inverse
+  long gstride = 0;    // floats between the copies of G (0: one 256-wide block per pixel tile)
   __device__ __forceinline__ float4 bias4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
   __device__ __forceinline__ void store4(int, int, int, float4, float4, bool&) const {}
   __device__ __forceinline__ void operator()(int, int, int, float) const {}

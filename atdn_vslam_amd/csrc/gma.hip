@@ -276,7 +276,7 @@ void GmaNet::finalize() {
   if (sf) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
   z_.alloc(n8 * 128); rh_.alloc(n8 * 128); fh_.alloc(n8 * 256); mask_.alloc(n8 * 576);
-  if (sf) fhG_.alloc(n8 * 18);
+  if (sf) fhG_.alloc(2 * n8 * 18);   // (two copies: one per 128-channel block of the fused flow head)
   coords1_.alloc(n8 * 2); flow4_.alloc(n8 * 4);
   if (sf) for (int p = 0; p < 2; ++p) { pre_zr_[p].alloc(n8 * 256); pre_q_[p].alloc(n8 * 128); }
   // pad lanes that kernels read but never write must be finite zeros
@@ -619,8 +619,9 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   s = conv_shape(fh1_, h_[0].p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
   const SfFlowDelta fd{fh2_.b, coords1_.p, flow4_.p, x_.p, XLD, (long)N * XLD, 254, W8, (long)N};
   // conv1 with conv2's partial sums in its epilogue, then the 3 x 3 gather (small_convs.h)
-  launch_flow_head_fused(s, fh1_.wscale, SfFlowHeadPartial{fh1_.b, arena_.dev(fh2_w32_off_), fhG_.p, (long)N, fh2_mul_, 1.0f / fh2_mul_}, st);
-  launch_flow_gather(fhG_.p, B, H8, W8, fd, st);
+  const long fh_gs = (long)maxB * N * 18;   // second copy of the partial sums: channels 128..255 (conv_sf_inst_e.hip)
+  launch_flow_head_fused(s, fh1_.wscale, SfFlowHeadPartial{fh1_.b, arena_.dev(fh2_w32_off_), fhG_.p, (long)N, fh2_mul_, 1.0f / fh2_mul_, fh_gs}, st);
+  launch_flow_gather(fhG_.p, fh_gs, B, H8, W8, fd, st);
   mark(ST_FLOWHEAD, st);
 }
 

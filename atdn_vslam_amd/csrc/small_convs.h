@@ -15,6 +15,6 @@ void launch_flow_conv7_sf(const float* flow4, int nimg, int H, int W, const floa
 // pixel's 3 x 3 neighbourhood (zero padding outside the map) and applies SfFlowDelta (conv2's bias, coordinate update).
 struct ConvShape;
 void launch_flow_head_fused(const ConvShape& s, float wscale, const SfFlowHeadPartial& ep, hipStream_t st);
-void launch_flow_gather(const float* G, int nimg, int H, int W, const SfFlowDelta& ep, hipStream_t st);
+void launch_flow_gather(const float* G, long gstride, int nimg, int H, int W, const SfFlowDelta& ep, hipStream_t st);
 
 }  // namespace atdn

@@ -154,7 +154,7 @@ void launch_flow_conv7_sf(const float* flow4, int nimg, int H, int W, const floa
 // ---------------------------------------------------------------------------------------------- conv2 gather
 // out[p][o] = sum over taps t = (ty, tx) of G[p + (ty - 1, tx - 1)][t * 2 + o]   (conv2 3x3, pad 1: pixels outside
 // the map contribute nothing), then the flow update. One thread per pixel; G (4 MB at 8 pairs) is L2-resident.
-__global__ __launch_bounds__(256) void flow_gather_kernel(const float* __restrict__ G, int H, int W, long total,
+__global__ __launch_bounds__(256) void flow_gather_kernel(const float* __restrict__ G, long gstride, int H, int W, long total,
                                                           const SfFlowDelta ep) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256) void flow_gather_kernel(const float* __restric
   for (int t = 0; t < 9; ++t) {
     const int sy = y + t / 3 - 1, sx = x + t % 3 - 1;
     if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
-      const float2 g = *reinterpret_cast<const float2*>(G + ((long)img * HW + (long)sy * W + sx) * 18 + 2 * t);
+      const float* gp = G + ((long)img * HW + (long)sy * W + sx) * 18 + 2 * t;
+      float2 g = *reinterpret_cast<const float2*>(gp);
+      if (gstride) {   // two channel blocks per pixel tile: their partial sums, in channel order
+        const float2 g1 = *reinterpret_cast<const float2*>(gp + gstride);
+        g.x += g1.x; g.y += g1.y;
+      }
       s0 += g.x; s1 += g.y;
     }
   }
@@ -175,9 +180,9 @@ __global__ __launch_bounds__(256) void flow_gather_kernel(const float* __restric
   ep.apply(img, m, 1, s1, a1);
 }
 
-void launch_flow_gather(const float* G, int nimg, int H, int W, const SfFlowDelta& ep, hipStream_t st) {
+void launch_flow_gather(const float* G, long gstride, int nimg, int H, int W, const SfFlowDelta& ep, hipStream_t st) {
   const long total = (long)nimg * H * W;
-  hipLaunchKernelGGL(flow_gather_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, G, H, W, total, ep);
+  hipLaunchKernelGGL(flow_gather_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, G, gstride, H, W, total, ep);
   ATDN_HIP(hipGetLastError());
 }
 
