@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 // gaps of the wave that owns it (one or two per gap: 'vector-instruction ISSUE cost' of the guide says that is nearly free),
 // and the memory phases carry loads, LDS traffic and barriers only: 632 -> 526 us per launch at 16 pairs (same job).
 // History: the 4-wave kernel this replaced (every wave interleaving its own memory work with its own MFMAs) ran 372 us at 8
-// pairs against 315 for the first ping-pong. Measured in round 4 and not kept (profiles/r04_ab_attention.txt): s_setprio(1)
+// pairs against 315 for the first ping-pong. Measured in round 4 and not kept (profiles/r04_ab_attention.txt; priority 1 and 2 again in round 5 with the
+// decode in the MFMA gaps, after it had paid in the conv kernels: 6.85 / 6.49 ms per forward for the product against 6.83 / 6.50
+// and 6.57 / 6.65 — inside the run-to-run spread of this stage, profiles/r05_ab_attn_prio.txt): s_setprio(1)
 // around the multiplying set's MFMAs; the V^T staging split over both sets (it only moves work between two memory phases).
 #ifdef ATDN_ATTN_STAMP   // diagnostic: s_memtime stamps around the segments of a phase, summed per wave (waves 0 and 4 of every block)
 __device__ unsigned atdn_attn_stamps_dev[1024][2][8];
