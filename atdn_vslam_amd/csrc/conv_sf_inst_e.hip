@@ -9,6 +9,7 @@ void launch_flow_head_fused(const ConvShape& s, float wscale, const SfFlowHeadPa
   // was alone on its CU (230 registers) with sixteen block barriers in its epilogue; two four-wave blocks share a CU like the
   // ConvGRU kernels' and each writes its own copy of the 18 partial sums, which flow_gather_kernel adds in channel order:
   // 2.35 / 2.37 -> 2.24 / 2.23 ms per forward (profiles/r05_ab_flow_head_128.txt).
+  // (the f16 fast mode measures 4 % better on the old 256-wide block — 1.155 against 1.20 ms per forward; one shape for both modes)
   ATDN_CHECK(ep.gstride > 0, "two channel blocks per pixel tile write two copies of G");
   if (sf_fast_mode()) launch_conv_sf6_m<8, 128, 1, 4, 3, 3, SfFlowHeadPartial, true, false>(s, wscale, ep, st);
   else launch_conv_sf6_m<8, 128, 1, 4, 3, 3, SfFlowHeadPartial, false, false>(s, wscale, ep, st);
