@@ -128,24 +128,30 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   constexpr int CH = KT * KROW;        // one 32-channel chunk of the tile
   constexpr int IMG = 4 * CH;          // [4 channel chunks][64 keys][160 B]
   constexpr bool FULL = !STATS && !FAST;   // all three products of the split
+  // Row blocks of 16 queries per wave. The statistics sweep (one f16 product per logit, nothing stored) takes FOUR: its loop is
+  // bound by the LDS reads of the key fragments — every wave reads the whole key tile — and 64 queries per wave halve them per
+  // MFMA (round 5: 0.333 -> 0.262 ms per forward, same row maxima bit for bit: profiles/r05_ab_rowmax_64.txt). The full sweep stores its 32-query strips in the consumer's block order: two.
+  constexpr int RB = STATS ? 4 : 2;
+  constexpr int SR = 16 * RB;              // queries per wave (strip)
   constexpr int BLK = AT_BLK_BYTES;
   __shared__ __attribute__((aligned(16))) char lds[2 * IMG];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles = (g.RT + 3) >> 2;
+  const int nstrip = STATS ? (g.Npad + SR - 1) / SR : g.RT;
+  const int tiles = (nstrip + 3) >> 2;
   const int id = xcd_remap(blockIdx.x, g.B * tiles);
   const int b = id / tiles, tile = id - b * tiles;
   const int strip = tile * 4 + wave;
-  const bool strip_ok = strip < g.RT;
+  const bool strip_ok = strip < nstrip;
   const int n16 = lane & 15, g16 = lane >> 4;
   const char* qkb = reinterpret_cast<const char*>(qk + (long)b * g.N * 256);
 
   // query fragments (the column operand), resident for the whole sweep: [row block][channel chunk]
-  f16x8 qh[2][4], ql[2][4];
-  int mrow[2];
+  f16x8 qh[RB][4], ql[RB][4];
+  int mrow[RB];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
-    mrow[rb] = strip * 32 + 16 * rb + n16;
+  for (int rb = 0; rb < RB; ++rb) {
+    mrow[rb] = strip * SR + 16 * rb + n16;
     const char* qrow = qkb + (long)min(mrow[rb], g.N - 1) * 1024 + 16 * g16;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -175,10 +181,11 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   };
 
   const int NHT = (g.Q + 1) >> 1;
-  float run[2];          // running row maximum / running row sum of this lane's keys, per row block
-  float c0[2] = {0.f, 0.f};
+  float run[RB];         // running row maximum / running row sum of this lane's keys, per row block
+  float c0[RB];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
+  for (int rb = 0; rb < RB; ++rb) {
+    c0[rb] = 0.f;
     run[rb] = STATS ? -INFINITY : 0.f;
     if (!STATS) c0[rb] = (float)AT_SHIFT - rowmax_in[(long)b * g.Npad + min(mrow[rb], g.Npad - 1)] * LOG2E;
   }
@@ -191,11 +198,11 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   fetch(min(1, NHT - 1));
   for (int j = 0; j < NHT; ++j) {
     const char* img = lds + (j & 1) * IMG + n16 * KROW + 16 * g16;
-    f32x4v acc[4][2];   // [key block][row block]
+    f32x4v acc[4][RB];  // [key block][row block]
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[kb][rb][e] = 0.f;
     // key fragments of channel chunk c + 1 are requested before the MFMAs of chunk c are issued (two register sets);
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
           f32x4v a = acc[kb][rb];
           if (FULL) {
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[c & 1][kb], qh[rb][c], a, 0, 0, 0);
@@ -242,8 +249,8 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
         const int key0 = j * KT + 32 * cq + 4 * g16;
         u32x2 bytes2[2] = {{0u, 0u}, {0u, 0u}};   // residual bytes of both row blocks: one 16-byte store (and one load in the consumer)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          if (STATS) {
+        for (int rb = 0; rb < RB; ++rb) {
+          if constexpr (STATS) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
               if (!TAIL || key0 + (i & 3) + 16 * (i >> 2) < g.N) run[rb] = fmaxf(run[rb], acc[2 * cq + (i >> 2)][rb][i & 3]);
@@ -285,12 +292,12 @@ __global__ __launch_bounds__(256, 2) void qk_softmax_kernel(const float* __restr
   }
   sf_report(clamped);
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
+  for (int rb = 0; rb < RB; ++rb) {
     float r_ = run[rb];
     if (STATS) {
       r_ = fmaxf(r_, __shfl_xor(r_, 16));
       r_ = fmaxf(r_, __shfl_xor(r_, 32));
-      if (g16 == 0 && strip_ok) rowmax_out[(long)b * g.Npad + mrow[rb]] = r_;
+      if (g16 == 0 && strip_ok && mrow[rb] < g.Npad) rowmax_out[(long)b * g.Npad + mrow[rb]] = r_;
     } else {
       r_ += __shfl_xor(r_, 16);
       r_ += __shfl_xor(r_, 32);
@@ -602,7 +609,7 @@ extern "C" int atdn_attn_stamps(unsigned* out) {
 #endif
 
 void launch_qk_rowmax(const float* qk, const AttnGeom& g, float* rowmax, hipStream_t st) {
-  const int nblk = g.B * ((g.RT + 3) / 4);
+  const int nblk = g.B * (((g.Npad + 63) / 64 + 3) / 4);   // 64-query strips, four per block
   hipLaunchKernelGGL((qk_softmax_kernel<true, false>), dim3(nblk), dim3(256), 0, st, qk, g, nullptr, rowmax, nullptr, nullptr);
   ATDN_HIP(hipGetLastError());
 }
