@@ -438,6 +438,33 @@ def test_gma_flow_predictions_match_reference_golden(golden_dir, gsd, flow_net):
     assert torch.equal(up_b, up)
 
 
+def test_gma_flow_predictions_fast_mode_and_errors(gsd):
+    """The per-iteration predictions in the opt-in f16 mode (its own tolerance: hundredths of a pixel from the default mode), and
+    the call's behaviour at the edges: batch invariance beyond max_batch, CPU tensors and iters = 0 raise."""
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=3)).to(DEV)
+    ref = RAFTGMA(max_batch=1)
+    ref.load_state_dict(gsd)
+    ref = ref.to(DEV).eval()
+    fast = RAFTGMA(max_batch=1, precision="f16")
+    fast.load_state_dict(gsd)
+    fast = fast.to(DEV).eval()
+    pr = ref(fr[0:1], fr[1:2], iters=4)
+    pf = fast(fr[0:1], fr[1:2], iters=4)
+    assert len(pf) == 4 and all(bool(torch.isfinite(p).all()) for p in pf)
+    _, up_fast = fast(fr[0:1], fr[1:2], iters=4, test_mode=True)
+    assert torch.equal(pf[-1], up_fast)
+    for a, b in zip(pr, pf):
+        assert _maxerr(a.cpu(), b.cpu()) < 0.25   # f16 operands: a fraction of a pixel on flows of tens of pixels
+    assert float(pr[-1].abs().max()) > 1.0
+    # a batch beyond max_batch grows the handle (the module's contract), and every pair's predictions are those of the pair alone
+    p2 = ref(torch.cat([fr[0:1], fr[1:2]]), torch.cat([fr[1:2], fr[0:1]]), iters=4)
+    assert all(torch.equal(a[0:1], b) for a, b in zip(p2, pr))
+    with pytest.raises(RuntimeError):
+        ref(fr[0:1].cpu(), fr[1:2].cpu(), iters=2)                                        # no CPU fallback
+    with pytest.raises(RuntimeError):
+        ref(fr[0:1], fr[1:2], iters=0)
+
+
 def test_gma_c2_kitti_size_matches_golden_and_is_batch_invariant(golden_dir, gsd, flow_net):
     g = np.load(os.path.join(golden_dir, "gma_c2.npz"))
     fr = torch.from_numpy(syn.make_frames(2, 376, 1232, seed=int(g["seed_frames"]))).to(DEV)
