@@ -270,5 +270,9 @@ bool& sf_fast_mode();
 // Definitions are explicitly instantiated in conv_sf_inst_*.hip
 template <class Epi>
 TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_t st);
+// two independent convolutions with the same epilogue class as one launch where the halo-patch path serves both with the same
+// kernel (conv_sf6.h: conv_sf6_pair_kernel), as two launches otherwise; instantiated for SfBias<ACT_RELU>
+template <class Epi>
+void conv_sf_dispatch_pair(const ConvShape& s0, float wscale0, Epi ep0, const ConvShape& s1, float wscale1, Epi ep1, hipStream_t st);
 
 }  // namespace atdn

@@ -98,8 +98,11 @@ template <class E> struct conv_stamp_kind : std::integral_constant<int, -1> {};
 // weight loads in the loop, bit 1 no patch refresh (and no chunk-boundary barrier), bit 2 no LDS fragment reads in the loop,
 // bit 3 no epilogue, bit 4 every block stores its tile to the SAME 192 pixels of image 0 (the epilogue's instructions all run,
 // the stores stay in L2: what the HBM write side of the epilogue costs)
+// (the body: one block of one convolution. `bidx` is the block's index within ITS convolution — blockIdx.x in conv_sf6_kernel, or
+// the index behind the first convolution's blocks in conv_sf6_pair_kernel, which runs two independent convolutions of the same
+// shape class as ONE launch)
 template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST = false, bool NORM = false, int ABL = 0>
-__global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
+__device__ __forceinline__ void conv_sf6_body(const Conv2Geom& g, const Epi& ep, const int bidx) {
   static_assert(ABL == 0 || !NORM, "ablation builds exist for the plain patch loader");
   static_assert(TW == 16, "the 16x16x32 loop is built for 16-pixel tile rows");
   constexpr int NIMG = 2;   // two patch images: a chunk boundary costs one barrier
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
   const int tid = threadIdx.x;
   const int tiles_img = g.tiles_x * g.tiles_y;
   const int nblk = g.nimg * tiles_img * g.ntile_n;
-  const int id = xcd_remap(blockIdx.x, nblk);
+  const int id = xcd_remap(bidx, nblk);
   const int tile_n = id % g.ntile_n;
   const int tmg = id / g.ntile_n;
   const int img = tmg / tiles_img;
@@ -378,8 +381,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the epilogue's stores have left the wave
       const unsigned long long t3 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
       const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-      if (wave == 0 && lane == 0 && blockIdx.x < ATDN_CONV_STAMP_SLOTS) {
-        unsigned long long* o = atdn_conv_stamps_dev[kStamp * 2 + (KH == 5 ? 1 : 0)][blockIdx.x];
+      if (wave == 0 && lane == 0 && bidx < ATDN_CONV_STAMP_SLOTS) {
+        unsigned long long* o = atdn_conv_stamps_dev[kStamp * 2 + (KH == 5 ? 1 : 0)][bidx];
         o[0] = st_r0; o[1] = r1; o[2] = st_t1 - st_t0; o[3] = st_t2 - st_t1; o[4] = st_bar; o[5] = t3 - st_t2;
         o[6] = ((unsigned long long)xcc << 32) | hw; o[7] = t3 - st_t0;
         o[8] = st_e_slab; o[9] = st_e_wait; o[10] = st_e_apply; o[11] = 0;
@@ -745,8 +748,43 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Ge
   }
 }
 
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST = false, bool NORM = false, int ABL = 0>
+__global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_kernel(const Conv2Geom g, const Epi ep) {
+  conv_sf6_body<TH, TW, BN, WM, WN, KH, KW, Epi, FAST, NORM, ABL>(g, ep, (int)blockIdx.x);
+}
+
+// Two INDEPENDENT convolutions of the same instantiation as one launch (round 5: convc2 and convf2 of the motion encoder — the
+// correlation branch and the flow branch of update.py:76-92 do not depend on each other). Blocks [0, nblk0) are the first
+// convolution's, the rest the second's; the second starts at a multiple of 8 so that both keep their XCD mapping (blocks of the
+// gap exit at once). A block computes exactly what it computes in a launch of its own: the results are the same bits; what changes
+// is that the second convolution's blocks fill the first one's tail instead of waiting for it.
+__device__ __forceinline__ Conv2Geom conv2_geom_pick(const Conv2Geom& a, const Conv2Geom& b, bool s) {
+  // field by field (uniform selects: the geometry stays in scalar registers; an indexed array of kernel arguments is spilled to LDS)
+  Conv2Geom g;
+  g.src0 = s ? b.src0 : a.src0; g.src1 = s ? b.src1 : a.src1; g.sb0 = s ? b.sb0 : a.sb0; g.sb1 = s ? b.sb1 : a.sb1;
+  g.ld0 = s ? b.ld0 : a.ld0; g.ld1 = s ? b.ld1 : a.ld1; g.C0 = s ? b.C0 : a.C0; g.C1 = s ? b.C1 : a.C1;
+  g.H = s ? b.H : a.H; g.W = s ? b.W : a.W; g.Ho = s ? b.Ho : a.Ho; g.Wo = s ? b.Wo : a.Wo;
+  g.KH = s ? b.KH : a.KH; g.KW = s ? b.KW : a.KW; g.padH = s ? b.padH : a.padH; g.padW = s ? b.padW : a.padW;
+  g.PH = s ? b.PH : a.PH; g.PW = s ? b.PW : a.PW; g.tiles_x = s ? b.tiles_x : a.tiles_x; g.tiles_y = s ? b.tiles_y : a.tiles_y;
+  g.nimg = s ? b.nimg : a.nimg; g.ntile_n = s ? b.ntile_n : a.ntile_n;
+  g.w = s ? b.w : a.w; g.ldw = s ? b.ldw : a.ldw; g.N = s ? b.N : a.N; g.wscale = s ? b.wscale : a.wscale;
+  g.in_mean = nullptr; g.in_rstd = nullptr;
+  return g;
+}
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST = false>
+__global__ __launch_bounds__(WM * WN * 64, 1) void conv_sf6_pair_kernel(const Conv2Geom g0, const Conv2Geom g1, const Epi ep0,
+                                                                        const Epi ep1, const int nblk0, const int start1) {
+  const int b = (int)blockIdx.x;
+  if (b >= nblk0 && b < start1) return;
+  const bool second = b >= start1;
+  const Conv2Geom g = conv2_geom_pick(g0, g1, second);
+  const Epi ep = Epi::pick(ep0, ep1, second);
+  // (one call: the body's LDS image exists once)
+  conv_sf6_body<TH, TW, BN, WM, WN, KH, KW, Epi, FAST, false, 0>(g, ep, second ? b - start1 : b);
+}
+
 template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST = false, bool NORM = false, int ABL = 0>
-inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
+inline Conv2Geom conv_sf6_geom(const ConvShape& s, float wscale) {
   constexpr int TW = 16;
   ATDN_CHECK(s.KH == KH && s.KW == KW && s.stride == 1, "kernel shape does not match the instantiation");
   Conv2Geom g{};
@@ -766,9 +804,31 @@ inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_
   ATDN_CHECK(NORM == (s.in_mean != nullptr) && (!NORM || (s.in_rstd && s.C1 == 0 && s.ld0 == s.C0)),
              "normalise-on-load: one dense fp32 source with its mean / rstd");
   ATDN_CHECK(g.w != nullptr, "missing weight copy for this kernel");
+  return g;
+}
+
+template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST = false, bool NORM = false, int ABL = 0>
+inline void launch_conv_sf6(const ConvShape& s, float wscale, Epi ep, hipStream_t st) {
+  constexpr int TW = 16;
+  const Conv2Geom g = conv_sf6_geom<TH, BN, WM, WN, KH, KW, Epi, FAST, NORM, ABL>(s, wscale);
   set_groups(ep, g.tiles_x * g.tiles_y * (TH * TW / 32));
   const int nblk = g.nimg * g.tiles_x * g.tiles_y * g.ntile_n;
   hipLaunchKernelGGL((conv_sf6_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, FAST, NORM, ABL>), dim3(nblk), dim3(WM * WN * 64), 0, st, g, ep);
+  ATDN_HIP(hipGetLastError());
+}
+
+template <int TH, int BN, int WM, int WN, int KH, int KW, class Epi, bool FAST>
+inline void launch_conv_sf6_pair(const ConvShape& s0, float wscale0, Epi ep0, const ConvShape& s1, float wscale1, Epi ep1,
+                                 hipStream_t st) {
+  constexpr int TW = 16;
+  static_assert(!Epi::kStats, "the pair launch serves plain-store epilogues");
+  const Conv2Geom g0 = conv_sf6_geom<TH, BN, WM, WN, KH, KW, Epi, FAST, false, 0>(s0, wscale0);
+  const Conv2Geom g1 = conv_sf6_geom<TH, BN, WM, WN, KH, KW, Epi, FAST, false, 0>(s1, wscale1);
+  const int nblk0 = g0.nimg * g0.tiles_x * g0.tiles_y * g0.ntile_n;
+  const int start1 = (nblk0 + 7) / 8 * 8;
+  const int nblk1 = g1.nimg * g1.tiles_x * g1.tiles_y * g1.ntile_n;
+  hipLaunchKernelGGL((conv_sf6_pair_kernel<TH, TW, BN, WM, WN, KH, KW, Epi, FAST>), dim3(start1 + nblk1), dim3(WM * WN * 64), 0, st,
+                     g0, g1, ep0, ep1, nblk0, start1);
   ATDN_HIP(hipGetLastError());
 }
 
@@ -864,6 +924,30 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
     if (bn == 96) { launch_conv_sf6_m<8, 96, 2, 3, KH, KW, Epi, FAST, false>(s, wscale, ep, st); return true; }
   }
   return false;
+}
+
+// Both convolutions as ONE launch when each of them, alone, would run the 12 x 16-pixel x 64-channel 3x3 kernel with a plain
+// store (the same selection rules as conv_sf6_try_shape<3, 3>: the pair changes the schedule, never the kernel a convolution gets).
+template <class Epi>
+inline bool conv_sf6_try_pair(const ConvShape& s0, float wscale0, const Epi& ep0, const ConvShape& s1, float wscale1, const Epi& ep1,
+                              hipStream_t st, bool fast) {
+  if constexpr ((epi_gen6<Epi>::value & 1) == 0 || Epi::kStats || epi_flowhead<Epi>::value) {
+    return false;
+  } else {
+    auto picks_tall64 = [&](const ConvShape& s) {
+      if (!conv_halo_eligible(s) || s.KH != 3 || s.KW != 3 || !s.wfrag16 || s.in_mean) return false;
+      if (epi_vec4<Epi>::value && (s.N % 4) != 0) return false;
+      if (s.C0 % 32 != 0 || s.C1 % 32 != 0 || s.C0 <= 0 || s.ld0 % 4 != 0) return false;
+      if (conv_sf6_block_width_3x3(s) != 64) return false;
+      const int Ho = conv_out(s.H, 3, 1, s.padH), Wo = conv_out(s.W, 3, 1, s.padW);
+      const long tiles12 = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
+      return cdiv(Ho, 12) * 12 * 100 <= cdiv(Ho, 8) * 8 * 103 && tiles12 * cdiv(s.N, 64) >= 512;
+    };
+    if (!picks_tall64(s0) || !picks_tall64(s1)) return false;
+    if (fast) launch_conv_sf6_pair<12, 64, 2, 2, 3, 3, Epi, true>(s0, wscale0, ep0, s1, wscale1, ep1, st);
+    else launch_conv_sf6_pair<12, 64, 2, 2, 3, 3, Epi, false>(s0, wscale0, ep0, s1, wscale1, ep1, st);
+    return true;
+  }
 }
 
 template <class Epi>

@@ -37,7 +37,18 @@ TileChoice conv_sf_dispatch(const ConvShape& s, float wscale, Epi ep, hipStream_
   return t;
 }
 
+// Two independent convolutions with the same epilogue class: one launch when the halo-patch path would give both the same kernel
+// (conv_sf6_try_pair), two launches otherwise. Same results either way.
+template <class Epi>
+void conv_sf_dispatch_pair(const ConvShape& s0, float wscale0, Epi ep0, const ConvShape& s1, float wscale1, Epi ep1, hipStream_t st) {
+  if (conv_sf6_try_pair(s0, wscale0, ep0, s1, wscale1, ep1, st, sf_fast_mode())) return;
+  conv_sf_dispatch(s0, wscale0, ep0, st);
+  conv_sf_dispatch(s1, wscale1, ep1, st);
+}
+
 #define ATDN_INSTANTIATE_CONV_SF(EPI) \
   template TileChoice conv_sf_dispatch<EPI>(const ConvShape&, float, EPI, hipStream_t);
+#define ATDN_INSTANTIATE_CONV_SF_PAIR(EPI) \
+  template void conv_sf_dispatch_pair<EPI>(const ConvShape&, float, EPI, const ConvShape&, float, EPI, hipStream_t);
 
 }  // namespace atdn

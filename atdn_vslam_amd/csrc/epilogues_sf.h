@@ -14,6 +14,11 @@ struct SfBias {
   static constexpr bool kPrefetch = false;
   const float* bias;  // may be null
   float* dst; long ob; int ld;
+  // field-wise choice between two epilogues of a pair launch (conv_sf6_pair_kernel): uniform selects, everything stays scalar —
+  // indexing an array of kernel arguments instead makes the compiler spill the array to LDS, 90 bytes per thread
+  static __device__ __forceinline__ SfBias pick(const SfBias& a, const SfBias& b, bool second) {
+    return SfBias{second ? b.bias : a.bias, second ? b.dst : a.dst, second ? b.ob : a.ob, second ? b.ld : a.ld};
+  }
   __device__ __forceinline__ void operator()(int img, int m, int n, float a) const { store_c(img, m, n, a, col(n)); }
   // element form with the per-column constants passed in: kernels fetch col(n) once per output column instead of
   // once per element (a load between the stores of consecutive rows makes each row wait for the previous row's stores)

@@ -31,6 +31,8 @@ ATDN_EXTERN_SF(SfBias<ACT_NONE>) ATDN_EXTERN_SF(SfBias<ACT_RELU>) ATDN_EXTERN_SF
 ATDN_EXTERN_SF(EpiBiasStats) ATDN_EXTERN_SF(SfBiasReluAddRelu) ATDN_EXTERN_SF(SfContextSplit)
 ATDN_EXTERN_SF(SfQK) ATDN_EXTERN_SF(SfVT)
 ATDN_EXTERN_SF(SfGruZR) ATDN_EXTERN_SF(SfGruQ)
+extern template void conv_sf_dispatch_pair<SfBias<ACT_RELU>>(const ConvShape&, float, SfBias<ACT_RELU>, const ConvShape&, float,
+                                                             SfBias<ACT_RELU>, hipStream_t);
 
 namespace {
 
@@ -578,14 +580,19 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   launch_lookup_conv(brick_pyramid(), coords1_.p, n8, coords_used_.p, convc1_.wf16, convc1_.wscale, convc1_.b, cor1_.p,
                      sf_fast_mode(), st);
   mark(ST_LOOKUP, st);
-  s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
-  conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
   // (Round 3 captured the flow branch — convf1, convf2: independent of the correlation branch — as a parallel branch of the
   // graph on a second stream: +0.3 % on bench.py's two-stream loop, but -3 % in the sequence driver, whose lane streams then
-  // share hardware queues with the branch streams of the two graphs. Removed: one stream per clip, one queue per stream.)
+  // share hardware queues with the branch streams of the two graphs. Removed: one stream per clip, one queue per stream.
+  // Round 5: the two 3x3 convolutions of the two branches, convc2 and convf2, run the same kernel on different operands — they go
+  // out as ONE launch (conv_sf6_pair_kernel): convf2's 640 blocks fill the tail of convc2's 1,920 (512 resident: 3.75 rounds +
+  // 1.25 rounds become 5) — motion encoder 5.80 -> 5.57 ms per forward on ONE stream; under bench.py's two streams the other
+  // clip's launches were already filling those tails and the rate does not move (410.3 / 410.3 / 408.9 against 410.5 / 410.3 /
+  // 409.1 pairs/s, profiles/r05_ab_pair_launch.txt). Kept for callers with one stream.)
   launch_flow_conv7_sf(flow4_.p, B, H8, W8, arena_.dev(convf1_sf_off_), convf1_wscale_, convf1_.b, flo1_.p, sf_fast_mode(), st);
-  s = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
-  conv_sf_dispatch(s, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
+  s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
+  const ConvShape sf2 = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
+  conv_sf_dispatch_pair(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256},
+                        sf2, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
   s = conv_shape(convm_, corflo_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   float* mf = x_.p + 128;
   conv_sf_dispatch(s, convm_.wscale, SfBias<ACT_RELU>{convm_.b, mf, (long)N * XLD, XLD}, st);
