@@ -145,7 +145,10 @@ def pmc_traffic(kernel_fragment, batch, largest=False):
     """HBM-side bytes per launch of a kernel from the newest committed rocprofv3 PMC passes (profiles/*_pmc.json:
     2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs). Returns (bytes, file) or (None, None): NOT measured in this run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    import re
+    # newest by name, the numbers in a name compared as numbers (r05_v10 is newer than r05_v9)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")),
+                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))])
     if not files:
         return None, None
     data = json.load(open(files[-1]))
