@@ -43,7 +43,7 @@ audit conv_sf_inst_d "conv_sf6_kernelILi8ELi16ELi128ELi1ELi4ELi1ELi5ENS_7SfGruZR
 audit conv_sf_inst_d "conv_sf6_kernelILi8ELi16ELi128ELi1ELi4ELi5ELi1ENS_7SfGruZRELb0" "z|r ConvGRU gate, 5x1"
 audit conv_sf_inst_d "conv_sf6_kernelILi8ELi16ELi128ELi1ELi4ELi1ELi5ENS_6SfGruQELb0" "q ConvGRU gate, 1x5"
 audit conv_sf_inst_d "conv_sf6_kernelILi8ELi16ELi128ELi1ELi4ELi5ELi1ENS_6SfGruQELb0" "q ConvGRU gate, 5x1"
-audit conv_sf_inst_e "conv_sf6_kernelILi8ELi16ELi256ELi1ELi8ELi3ELi3ENS_17SfFlowHeadPartialELb0" "flow head conv1 + conv2 partial sums, 3x3, 256-wide block (8 waves): one loop iteration = 1 chunk x 9 taps"
+audit conv_sf_inst_e "conv_sf6_kernelILi8ELi16ELi128ELi1ELi4ELi3ELi3ENS_17SfFlowHeadPartialELb0" "flow head conv1 + conv2 partial sums, 3x3, 128-wide block (4 waves, two blocks per pixel tile since round 5): one loop iteration = 1 chunk x 9 taps"
 audit conv_sf_inst_a "conv_sf6_kernelILi12ELi16ELi64ELi2ELi2ELi3ELi3ENS_6SfBiasILi1EEELb0ELb0" "thin 3x3, 64-wide block, 12x16 tile, plain sf store (cnet layer1, convc2, convf2)"
 audit conv_sf_inst_a "conv_sf6_kernelILi8ELi16ELi128ELi1ELi4ELi3ELi3ENS_6SfBiasILi1EEELb0ELb0" "3x3, 128-wide block (motion encoder 256 -> 126)"
 audit conv_sf_inst_b "conv_sf6_kernelILi12ELi16ELi64ELi2ELi2ELi3ELi3ENS_12EpiBiasStatsELb0ELb0" "fnet statistics conv, 64 channels, plain loader"
