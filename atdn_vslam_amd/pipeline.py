@@ -6,7 +6,6 @@
 head, transform, float32 pose accumulation.
 """
 import torch
-import torch.nn.functional as F
 
 from . import transforms
 from .modules import ATDNVO, RAFTGMA

@@ -1,6 +1,6 @@
 """Headline benchmark: frame-pairs/s of KITTI-shaped odometry inference on N MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps 20 --warmup 3          (N > 1: starts its own N ranks, see atdn_vslam_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -23,10 +23,24 @@ import os
 import sys
 import time
 
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks (python -m torch.distributed.run, one per
+# GPU) from THIS process before torch is imported or any GPU call is made, relay their output and exit with their code
+# (atdn_vslam_amd/launch.py; the parent never touches the GPU and never re-execs). Under an external launcher WORLD_SIZE is
+# set and this is a no-op.
+if __name__ == "__main__":
+    from atdn_vslam_amd.launch import spawn_ranks_if_needed
+    _rc = spawn_ranks_if_needed(__file__)
+    if _rc is not None:
+        sys.exit(_rc)
+
 # N > 1: the ranks of one node share its host cores. Cap every rank's CPU thread pools BEFORE torch (OpenMP / MKL) starts
 # them — 8 ranks x torch's default of one thread per core would oversubscribe a 16-core box 8-fold around every host-side
-# step of the timed loop (torch.distributed.run sets OMP_NUM_THREADS=1 itself when it is unset; this makes it explicit and
-# gives each rank its fair share instead).
+# step of the timed loop. The variable is overridden only when nobody chose it: unset, or the 1 that an external
+# torch.distributed.run exports by default when it is unset (TORCHELASTIC_RUN_ID marks that launcher; this file's own launcher
+# sets the share itself and flags a user's explicit figure with ATDN_OMP_FROM_USER).
 _WORLD = int(os.environ.get("WORLD_SIZE", "1"))
 if _WORLD > 1:
     try:
@@ -34,16 +48,14 @@ if _WORLD > 1:
     except AttributeError:
         _cores = os.cpu_count() or 1
     _share = str(max(1, _cores // _WORLD))
-    if os.environ.get("OMP_NUM_THREADS", "1") == "1":      # unset, or the launcher's default of 1
+    _omp = os.environ.get("OMP_NUM_THREADS")
+    if _omp is None or (_omp == "1" and "TORCHELASTIC_RUN_ID" in os.environ and "ATDN_OMP_FROM_USER" not in os.environ):
         os.environ["OMP_NUM_THREADS"] = _share
     os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
 
 import numpy as np
 import torch
 import torch.distributed as dist
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
 
 from atdn_vslam_amd import synthetic as syn  # noqa: E402
 from atdn_vslam_amd import transforms  # noqa: E402
@@ -217,6 +229,34 @@ DTYPE_LABEL = {"split_f16": "f32 via 3xf16 split MFMA (fp32 accumulate)",
                "f32": "f32 (exact fp32 MFMA)"}
 
 
+def launch_check(args, world, rank, local):
+    """`--launch-check`: what a harness can run on any box (no GPU needed) to see that `python bench.py --gpus N` reaches N
+    ranks that can talk to each other: gloo group over the launcher's rendezvous, one all-gather of (rank, local rank, CPU
+    threads), one JSON line on rank 0. ATDN_LAUNCH_CHECK_FAIL_RANK=r makes rank r fail BEFORE the collective, the way a rank
+    fails in the bench (through sharding.rendezvous: every rank raises, the job ends non-zero)."""
+    assert world == args.gpus, "launched with %d rank(s) for --gpus %d" % (world, args.gpus)
+    err = None
+    if world > 1:
+        dist.init_process_group("gloo")
+    if os.environ.get("ATDN_LAUNCH_CHECK_FAIL_RANK") == str(rank):
+        err = RuntimeError("launch check: rank %d told to fail" % rank)
+    rendezvous(err)
+    mine = torch.tensor([rank, local, torch.get_num_threads()], dtype=torch.int64)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(rows, mine)
+    else:
+        rows = [mine]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": [int(r[0]) for r in rows],
+                          "local_ranks": [int(r[1]) for r in rows], "cpu_threads_per_rank": [int(r[2]) for r in rows],
+                          "launched_by": "bench.py itself" if "ATDN_SELF_LAUNCHED" in os.environ else "external launcher"
+                          if "TORCHELASTIC_RUN_ID" in os.environ else "none (single process)"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +271,10 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip the sharded-sequence leg (BASELINE configs[2])")
     ap.add_argument("--config3-frames", type=int, default=4541, help="frames of the synthetic sequence of the config3 leg")
     ap.add_argument("--no-f16-leg", action="store_true", help="skip the secondary timed pass in the f16 fast mode")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the secondary timed pass in the exact-fp32 mode")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="dry run of the launch plumbing only: every rank joins a gloo group, the ranks all-gather their "
+                         "(rank, local rank, threads), rank 0 prints one JSON line; no GPU call is made")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,6 +283,8 @@ def main():
     # ATDN_BENCH_REHEARSAL=1: the N > 1 code path on a ONE-GPU box — every rank on cuda:0, gloo instead of RCCL (which
     # refuses two ranks on one device). Checks the sharding / gather / scan plumbing only; its numbers mean nothing.
     rehearsal = os.environ.get("ATDN_BENCH_REHEARSAL") == "1"
+    if args.launch_check:
+        return launch_check(args, world, rank, local)
     if rehearsal:
         local = 0
     # ATDN_BENCH_FORCE_DIST=1: a ONE-rank launch still initialises the process group and runs every collective of the N > 1
@@ -252,7 +298,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    assert world == args.gpus, ("%d rank(s) for --gpus %d: start `python bench.py --gpus N` without a launcher (it starts its "
+                                "own ranks) or with --nproc-per-node == --gpus" % (world, args.gpus))
     if world > 1:
         torch.set_num_threads(max(1, usable_cores() // world))
     dev = torch.device("cuda", local)
@@ -305,7 +352,7 @@ def main():
 
     feats = torch.empty((max(K, Wm, 2 * S) * B, 512), device=dev)
 
-    def timed(host):
+    def timed(host, K=K):
         """W warm-up steps (at least two on EVERY pipeline: the graphs of a first and of a continued clip), then exactly
         K timed steps + the sequence tail, bracketed by barrier + synchronize. Returns (seconds, step_ms, tail_ms)."""
         nonlocal calls
@@ -417,6 +464,23 @@ def main():
         active[0] = pipes
         del fast
 
+    # ---- exact-fp32 mode as a secondary leg: what `RAFTGMA(saturation_fallback=True)` (modules.py) drops to when a checkpoint's
+    # activations leave the split-f16 range — every GEMM on v_mfma_f32_32x32x2_f32, the reference's data flow (row-major
+    # pyramid, separate lookup, logits + softmax). Same clip and frames, a quarter of the steps (never the headline).
+    f32 = None
+    if not args.no_f32_leg and args.precision == "split_f16":
+        exact = [OdometryPipeline(gsd, hsd, device=dev, max_batch=B, iters=ITERS, precision="f32") for _ in range(S)]
+        frames0 = resize_frames(seq_dev[:B + 1])
+        _, up_ref = pipe.features_clip(frames0)
+        _, up_exact = exact[0].features_clip(frames0)
+        d = (up_exact - up_ref).abs()
+        f32_err = (float(d.max()), float(d.mean()), float(up_ref.abs().max()))
+        K32 = max(2, K // 4)
+        active[0] = exact
+        f32 = timed(host=False, K=K32) + (f32_err, K32)
+        active[0] = pipes
+        del exact
+
     if rank == 0:
         total_pairs = world * K * B
         # per-stage device time of the same forward in this run, eager with HIP events on the launch stream
@@ -495,6 +559,13 @@ def main():
                                "dtype": DTYPE_LABEL["f16"],
                                "flow_up_abs_diff_vs_split_f16_px": {"max": f16[3][0], "mean": f16[3][1], "max_abs_flow": f16[3][2],
                                                                      "sample": "%d pairs of the bench clip, 12 iterations" % B}}
+        if f32 is not None:
+            n32 = world * f32[4] * B
+            out["f32_exact"] = {"value": n32 / f32[0], "unit": "frame-pairs/s", "ms_per_step": f32[0] * 1e3 / f32[4], "steps": f32[4],
+                                "ratio_to_value": (n32 / f32[0]) / (total_pairs / dt), "dtype": DTYPE_LABEL["f32"],
+                                "role": "the mode RAFTGMA(saturation_fallback=True) switches to when the split-f16 range guard trips",
+                                "flow_up_abs_diff_vs_split_f16_px": {"max": f32[3][0], "mean": f32[3][1], "max_abs_flow": f32[3][2],
+                                                                     "sample": "%d pairs of the bench clip, 12 iterations" % B}}
         if h2d is not None:
             # second timed pass of the same K steps with the uint8 frames in pinned HOST memory: H2D (copy stream,
             # double-buffered) + convert + resize inside the timed region. Never the headline `value`.
@@ -503,6 +574,11 @@ def main():
                                     "host_bytes_per_step": (B + 1) * 3 * H_KITTI * W_KITTI}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"], out["cpu_baseline_1thread"] = cpu_baseline(gsd, hsd, resize_frames(seq_dev[:6]))
+        else:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_reason"] = ("--no-cpu-baseline" if world == 1 else "the CPU leg is timed at N = 1 only (rank 0 "
+                                          "would hold the other %d ranks in the closing barrier and share its cores with them); "
+                                          "the N = 1 line of the same build carries it" % (world - 1))
         print(json.dumps(out))
     if dist_on:
         dist.barrier()

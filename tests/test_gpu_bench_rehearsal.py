@@ -18,7 +18,7 @@ def test_two_rank_bench_rehearsal_prints_one_valid_line():
     env = dict(os.environ, ATDN_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--config3-frames", "44"]
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--config3-frames", "44"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -45,7 +45,7 @@ def test_bench_config3_with_a_shard_shorter_than_one_clip():
     env = dict(os.environ, ATDN_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--config3-frames", "10"]
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--config3-frames", "10"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -62,7 +62,7 @@ def test_bench_collectives_on_real_rccl_at_world_size_one():
     env = dict(os.environ, ATDN_BENCH_FORCE_DIST="1", ATDN_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29621", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
-           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--config3-frames", "40"]
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--config3-frames", "40"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -70,3 +70,20 @@ def test_bench_collectives_on_real_rccl_at_world_size_one():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config3"]["pairs"] == 39 and d["config3"]["value"] > 0
     assert "REHEARSAL" not in d["data"]
+
+
+def test_bench_starts_its_own_ranks():
+    """The line a harness types: `python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE. bench.py's parent starts
+    the two ranks before any GPU call (atdn_vslam_amd/launch.py), relays rank 0's one JSON line and the exit code. On this
+    one-GPU box both ranks share cuda:0 over gloo (ATDN_BENCH_REHEARSAL); the N > 1 line carries `cpu_baseline: null` + why."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ATDN_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--no-h2d-leg",
+           "--no-f16-leg", "--no-f32-leg", "--config3-frames", "40"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line reaches the parent's stdout"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config3"]["pairs"] == 39
+    assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_reason"]

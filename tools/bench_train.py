@@ -1,7 +1,9 @@
 """Throughput of the CLVO training iteration (BASELINE config 4 shape: batch 24, sequence length 6, 376x1232 flows)
 on one GPU, or data-parallel under torch.distributed.run (one process per GPU, RCCL all-reduce of the flat gradient).
 
-    python tools/bench_train.py [--batch 24] [--seq 6] [--steps 10] [--warmup 2]
+    python tools/bench_train.py [--gpus N] [--batch 24] [--seq 6] [--steps 10] [--warmup 2]
+
+`--gpus N` with N > 1 and no launcher around it starts its own N ranks (atdn_vslam_amd/launch.py), exactly as bench.py does.
 """
 import argparse
 import json
@@ -10,6 +12,13 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+if __name__ == "__main__":   # before torch is imported / any GPU call: the parent only starts the ranks and relays their exit code
+    from atdn_vslam_amd.launch import spawn_ranks_if_needed
+    _rc = spawn_ranks_if_needed(__file__)
+    if _rc is not None:
+        sys.exit(_rc)
+
 import numpy as np
 import torch
 
@@ -23,10 +32,23 @@ def main():
     ap.add_argument("--seq", type=int, default=6)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks of the data-parallel job (default: WORLD_SIZE, else 1)")
+    ap.add_argument("--launch-check", action="store_true", help="launch plumbing only (gloo all-gather of the ranks, no GPU call)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert a.gpus is None or a.gpus == world, "%d rank(s) for --gpus %s" % (world, a.gpus)
+    if a.launch_check:
+        import torch.distributed as dist
+        rows = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.all_gather(rows, torch.tensor([rank], dtype=torch.int64))
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": [int(r[0]) for r in rows]}))
+        return
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if world > 1:
