@@ -201,8 +201,10 @@ __device__ __forceinline__ void conv_sf6_body(const Conv2Geom& g, const Epi& ep,
     const float hi = (pmeta[k] >> 12) != 0 ? 65504.f : 0.f;
     float4 v = pr[k];
     v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y; v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
-    // (a NaN of the raw tensor is dropped by the maximum below and by v_med3, as fmaxf(., 0) dropped it before: it shows as 0
-    // here and as a NaN in the statistics of the producer, which has already flagged it)
+    // (a NaN of the raw tensor is dropped by the maximum below and by v_med3 and shows as 0 here. It cannot pass unseen: one NaN
+    // or infinity in a channel makes that channel's mean / rstd non-finite, and in_finalize_merge_kernel (kernels.hip) raises the
+    // saturation alarm for non-finite statistics — the producers store raw fp32 and raise none of their own. Two unordered tests
+    // per patch row here would be 16 more vector instructions per 324 MFMAs of the hottest loop of the feature network.)
     const float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
     norm_sat |= !(m <= 65504.f);
     v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, hi); v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, hi);
@@ -797,6 +799,10 @@ inline Conv2Geom conv_sf6_geom(const ConvShape& s, float wscale) {
   ATDN_CHECK(s.ldw % 4 == 0 && s.ldw >= s.KH * s.KW * (s.C0 + s.C1), "weight rows too short");
   ATDN_CHECK(!epi_vec4<Epi>::value || !Epi::kPrefetch || s.N % 4 == 0, "channel-vector epilogue with operand loads needs N % 4 == 0");
   ATDN_CHECK((long)s.H * s.W < (1L << 20) - 1, "image too large for the packed patch descriptor");
+  // the epilogues address an image's slice as a scalar base + an unsigned 32-bit BYTE offset (sf.h: sf_store4_flag_u / sf_load4u,
+  // the statistics epilogue's mo[e]): pixels x row width x 4 B must stay under 4 GB. Rows of this library are <= 1024 floats.
+  ATDN_CHECK((long)g.Ho * g.Wo * 1024L * 4L <= (1L << 32) && s.ld0 <= 1024 && s.ld1 <= 1024 && s.N <= 1024,
+             "per-image slice of 4 GB or more: the 32-bit epilogue offsets would wrap");
   g.tiles_x = cdiv(g.Wo, TW); g.tiles_y = cdiv(g.Ho, TH);
   g.nimg = s.nimg; g.ntile_n = cdiv(s.N, BN);
   g.w = s.wfrag16; g.ldw = s.ldw; g.N = s.N; g.wscale = wscale;

@@ -1,5 +1,6 @@
 // Non-GEMM kernels of the odometry path, gfx950. Wave = 64 lanes throughout.
 #include "kernels.h"
+#include "sf.h"
 
 namespace atdn {
 
@@ -112,8 +113,12 @@ __global__ void in_finalize_merge_kernel(const double* __restrict__ part, int ni
   }
   const double mu = n > 0.0 ? s1 / n : 0.0;
   const double between = n > 0.0 ? fmax(sq - s1 * s1 / n, 0.0) : 0.0;
-  mean[i] = (float)mu;
-  rstd[i] = (float)(1.0 / sqrt((m2 + between) / (double)HW + (double)eps));
+  const float mu_f = (float)mu, rs_f = (float)(1.0 / sqrt((m2 + between) / (double)HW + (double)eps));
+  mean[i] = mu_f;
+  rstd[i] = rs_f;
+  // a NaN / infinity anywhere in the raw (fp32, un-clamped) channel shows here: the consumers' normalise-on-load loaders and
+  // in_apply_sf_kernel would turn it into zeros without an alarm of their own
+  sf_report(!(fabsf(mu_f) <= 3.0e38f) | !(rs_f <= 3.0e38f));
 }
 void launch_in_finalize_cnt(const float* part_sum, const float* part_m2, const float* part_cnt, int nimg,
                             int groups_per_img, int HW, int C, float eps, float* mean, float* rstd, double* scratch,

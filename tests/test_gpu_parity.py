@@ -117,7 +117,7 @@ HALO_CASES = [
 
 STRIDE2_CASES = [
     # (Cin, Cout, H, W, nimg): the encoders' stride-2 3x3 convolutions (layer2.0 / layer3.0 conv1), split-f16 store.
-    # (Round 5 built a stride-2 form of the halo-patch kernel for them — tools/ab/r05_stride2.patch — which these cases
+    # (Round 5 built a stride-2 form of the halo-patch kernel for them — tools/ab/historical/r05_stride2.patch — which these cases
     # verified; it lost to the GEMM-shaped kernel they run on and is not in the tree)
     (64, 96, 188, 616, 2),     # fnet / cnet layer2.0.conv1 at KITTI size
     (96, 128, 94, 308, 3),     # layer3.0.conv1
@@ -127,7 +127,7 @@ STRIDE2_CASES = [
 
 
 @pytest.mark.parametrize("case", STRIDE2_CASES)
-def test_split_f16_stride2_halo_kernel_matches_fp64(case):
+def test_split_f16_stride2_3x3_convs_match_fp64(case):
     cin, cout, H, W, nimg = case
     r = np.random.RandomState(hash(case) & 0xFFFF)
     x = torch.from_numpy(r.normal(0, 1, (nimg, cin, H, W)).astype(np.float32))

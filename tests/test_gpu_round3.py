@@ -396,3 +396,22 @@ def test_two_lane_sequence_driver_is_bit_identical_to_one_lane():
     assert tuple(two.shape) == (45, 4, 4) and torch.equal(two, one)
     assert torch.equal(pipe.run_sequence(frames, batch=8, lanes=[pipe2]), one)
     assert float(one[-1][:3, 3].norm()) > 0.1
+
+
+def test_a_nan_pixel_raises_the_alarm_through_the_feature_network():
+    """the feature network's stem and statistics convolutions store RAW fp32 (no clamp, no alarm of their own) and the
+    consumers' normalise-on-load loaders turn a NaN into zero (v_med3 drops it). One NaN in a frame makes its channel statistics
+    non-finite, and in_finalize_merge_kernel raises the saturation alarm for those: the product path refuses the frame instead
+    of computing from silently zeroed channels. (The reference propagates the NaN into its flow.)"""
+    gsd = syn.to_torch(syn.make_gma_state(seed=1))
+    net = RAFTGMA()
+    net.load_state_dict(gsd)
+    net = net.to(DEV).eval()
+    net.saturation_check_every = 1
+    fr = torch.from_numpy(syn.make_frames(2, 160, 512, seed=3)).to(DEV)
+    low, up = net(fr[0:1], fr[1:2], iters=2, test_mode=True)
+    assert bool(torch.isfinite(up).all())
+    bad = fr.clone()
+    bad[1, 1, 80, 256] = float("nan")          # frame 2 only: the context network (frame 1) never sees it
+    with pytest.raises(SplitF16RangeError):
+        net(bad[0:1], bad[1:2], iters=2, test_mode=True)

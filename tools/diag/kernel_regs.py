@@ -44,6 +44,8 @@ def kernels_of(lib):
 def demangle(names):
     import shutil
     tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
+    if not tool and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-cxxfilt"):
+        tool = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
     if not tool:
         return list(names)
     r = subprocess.run([tool], input="\n".join(names), stdout=subprocess.PIPE, text=True)
