@@ -55,6 +55,14 @@ class ClvoNet {
   hipStream_t cap_stream_ = nullptr;
   bool scan_graph_ = true;        // ATDN_NO_GRAPH=1: eager launches
   void launch_scan_steps(int T, int Bs, hipStream_t st);
+  // persistent scan (lstm_scan.hip): sequences of one batch row and at least kPersistentMinSteps steps run as ONE
+  // launch. ATDN_SCAN_PERSISTENT=0 keeps the per-step kernel. A launch that gave up on a bounded spin (its outputs are NaN)
+  // leaves a non-zero word in scan_abort_host_ (pinned; copied behind every launch): the next call sees it, says so on stderr
+  // and stays on the per-step kernel.
+  static constexpr int kPersistentMinSteps = 16;
+  bool scan_persistent_ = true;
+  DeviceBuf scan_xch_;
+  unsigned int* scan_abort_host_ = nullptr;
 };
 
 }  // namespace atdn

@@ -27,7 +27,8 @@ ClvoNet::~ClvoNet() {
   (void)hipDeviceSynchronize();   // a scan graph of this handle may still be running on the caller's stream
   for (auto& kv : scan_graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &pre_, &hseq_, &x2seq_, &hseq2_, &cstate_}) b->release();
+  if (scan_abort_host_) (void)hipHostFree(scan_abort_host_);
+  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &pre_, &hseq_, &x2seq_, &hseq2_, &cstate_, &scan_xch_}) b->release();
   arena_.release();
 }
 
@@ -102,6 +103,10 @@ void ClvoNet::finalize() {
     r.skip_w = arena_.dev(r.skip_w_off); r.skip_b = arena_.dev(r.skip_b_off);
   }
   scan_graph_ = !(getenv("ATDN_NO_GRAPH") && getenv("ATDN_NO_GRAPH")[0] == '1');
+  scan_persistent_ = !(getenv("ATDN_SCAN_PERSISTENT") && getenv("ATDN_SCAN_PERSISTENT")[0] == '0');
+  scan_xch_.alloc((lstm_scan_exchange_bytes() + 3) / 4);
+  ATDN_HIP(hipHostMalloc(reinterpret_cast<void**>(&scan_abort_host_), 64, hipHostMallocDefault));
+  *scan_abort_host_ = 0u;
   ATDN_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
   for (Lin* l : {&fc_, &lstm1_ih_, &lstm1_hh_, &lstm_lin_, &lstm2_ih_, &lstm2_hh_, &rot_[0], &rot_[1], &rot_[2],
                  &tr_[0], &tr_[1], &tr_[2]}) {
@@ -198,6 +203,21 @@ void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, f
   gemm(feat, lstm1_ih_, pre_.p, 2048);
   const MlpHead R{rot_[0].w, rot_[0].b, rot_[1].w, rot_[1].b, rot_[2].w};
   const MlpHead Tt{tr_[0].w, tr_[0].b, tr_[1].w, tr_[1].b, tr_[2].w};
+  if (scan_persistent_ && *scan_abort_host_ != 0u) {
+    fprintf(stderr, "atdn: a persistent LSTM scan of this handle gave up on a bounded spin (its poses were NaN); "
+                    "staying on the per-step kernel\n");
+    scan_persistent_ = false;
+  }
+  if (scan_persistent_ && Bs == 1 && T >= kPersistentMinSteps) {
+    // ONE launch for the whole sequence (lstm_scan.hip): reads and writes the caller's state in place, h2 of every step into
+    // hseq2_ rows 1..T (where the per-step pipeline leaves them), then both regressors batched over the sequence
+    launch_lstm_scan(pre_.p, lstm1_hh_.w, lstm1_hh_.b, lstm_lin_.w, lstm_lin_.b, lstm2_ih_.w, lstm2_ih_.b, lstm2_hh_.w,
+                     lstm2_hh_.b, state, hseq2_.p + sb, scan_xch_.p, T, st);
+    ATDN_HIP(hipMemcpyAsync(scan_abort_host_, reinterpret_cast<const char*>(scan_xch_.p) + (lstm_scan_exchange_bytes() - 64),
+                            sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    launch_mlp_heads(hseq2_.p + sb, (int)rows, R, Tt, rot, tr, st);
+    return;
+  }
   {
     // lstm1 (step s), lstm_linear (step s - 1) and lstm2 with its input projection (step s - 2) share ONE launch per
     // step: T + 2 dependent launches instead of 2T + 2, replayed as one hipGraph per (T, Bs)

@@ -73,6 +73,14 @@ struct LstmPipeArgs {
   const float *Wih2, *bih2, *Whh2, *bhh2, *x2_in, *h2_in; float *c2, *h2_out;
 };
 void launch_lstm_pipe(const LstmPipeArgs& a, hipStream_t st);
+// The same recurrence for ONE batch row as one persistent launch per sequence (lstm_scan.hip): weights resident in registers,
+// the three pipeline stages exchange their 512-value results through tagged 8-byte granules. `state` [4][512] = h1, c1, h2, c2
+// (read at the start, written at the end), `h2seq` [T][512] = lstm2's hidden state after every step, `exchange` = a device
+// buffer of lstm_scan_exchange_bytes() that this call zeroes on the stream before the launch.
+long lstm_scan_exchange_bytes();
+void launch_lstm_scan(const float* pre1, const float* Whh1, const float* bhh1, const float* Wlin, const float* blin,
+                      const float* Wih2, const float* bih2, const float* Whh2, const float* bhh2, float* state, float* h2seq,
+                      void* exchange, int T, hipStream_t st);
 // both regressors (512 -> 128 -> 64 -> 3, Mish, last layer no bias): out rot [B][3], tr [B][3]
 struct MlpHead { const float *w0, *b0, *w1, *b1, *w2; };
 void launch_mlp_heads(const float* h2, int B, MlpHead rot, MlpHead tr, float* rot_out, float* tr_out, hipStream_t st);
