@@ -38,7 +38,7 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
 constexpr int HD = 512;            // hidden size of both cells
-constexpr unsigned SPIN_LIMIT = 40000;   // passes of ~0.5-1 us each: tens of milliseconds, then give up
+constexpr unsigned long long SPIN_LIMIT_TICKS = 50000000ull;   // 0.5 s of the 100 MHz real-time clock (s_memrealtime), then give up
 
 // sum over the 64 lanes on the vector ALU (DPP row shifts + row broadcasts; no LDS crossbar), returned as a wave-uniform value
 __device__ __forceinline__ float wave_sum_dpp(float v) {
@@ -192,6 +192,7 @@ __global__ __launch_bounds__((NWV + 1) * 64) void lstm_scan_kernel(const ScanArg
       // clocks 2.02, then +0.05 us per further 128 clocks (profiles/r06_scan_poll_delay.txt). The delay follows the box: one unit
       // (128 clocks) more after a tick whose first pass failed, one less after 32 ticks in a row whose first pass succeeded.
       for (int z = 0; z < dly; ++z) __builtin_amdgcn_s_sleep(2);
+      unsigned long long t_start = 0;
       for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
@@ -206,7 +207,12 @@ __global__ __launch_bounds__((NWV + 1) * 64) void lstm_scan_kernel(const ScanArg
           break;
         }
         const unsigned ab = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ab != 0u || spins > SPIN_LIMIT) {   // uniform: every lane read the same word and counts the same passes
+        // bounded by WALL time, not by a pass count: a workgroup that waits for a CU behind another stream's kernels is late, not
+        // lost (the clock is read on the first failed pass and then every 64th)
+        bool late = false;
+        if (spins == 0) t_start = __builtin_amdgcn_s_memrealtime();
+        else if ((spins & 63u) == 0u) late = __builtin_amdgcn_s_memrealtime() - t_start > SPIN_LIMIT_TICKS;
+        if (ab != 0u || late) {   // uniform: every lane read the same word, the clock is a scalar
           if (lane == 0) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *dead = 1; }
           break;
         }

@@ -55,8 +55,7 @@ def test_persistent_scan_matches_the_per_step_kernel(T):
     # deterministic: a second run gives the same bits (fixed summation order, no atomics on the data path)
     r2, t2, s2 = one.scan(f, state=st0)
     assert torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(s1, s2)
-    # chunks with the state carried = one call (every chunk length >= 16 takes the persistent kernel, the 5-step tail the per-step one
-    # only when T is not a multiple: checked against the single call within the gate functions' difference)
+    # chunks of 50 steps with the state carried (each one a persistent launch of its own) = the single call, bit for bit
     if T >= 100:
         st, rr = st0, []
         for c in range(0, T, 50):
@@ -97,3 +96,35 @@ def test_persistent_scan_of_a_kitti00_length_sequence_is_faster_and_finite():
     assert float((out["persistent"][1] - out["per_step"][1]).abs().max()) < 1e-5
     assert float((out["persistent"][2] - out["per_step"][2]).abs().max()) < 1e-5
     assert out["persistent"][0] < out["per_step"][0]
+
+
+def test_persistent_scans_share_the_gpu_with_each_other_and_with_a_flow_forward():
+    """Residency is not a given: two persistent scans on two streams at once (256 workgroups), and a scan that starts while another
+    stream's flow network holds the chip, must give the bits of a scan that ran alone — a workgroup that waits for a CU is late,
+    not lost (the spins are bounded by wall time, 0.5 s)."""
+    from atdn_vslam_amd.modules import RAFTGMA
+    a, b = _head(True), _head(True)
+    fa, fb = _feats(600, 21), _feats(700, 22)
+    ra = a.scan(fa)
+    rb = b.scan(fb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        ra2 = a.scan(fa)
+    with torch.cuda.stream(s2):
+        rb2 = b.scan(fb)
+    torch.cuda.synchronize()
+    assert torch.equal(ra[0], ra2[0]) and torch.equal(rb[0], rb2[0]) and torch.equal(ra[2], ra2[2])
+    net = RAFTGMA(max_batch=4)
+    net.load_state_dict(syn.to_torch(syn.make_gma_state(seed=1)))
+    net = net.to(DEV).eval()
+    fr = torch.from_numpy(syn.make_frames(5, 376, 1232, seed=3)).to(DEV)
+    net.forward_sequence(fr, iters=4)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        for _ in range(3):
+            net.forward_sequence(fr, iters=4)
+    with torch.cuda.stream(s2):
+        ra3 = a.scan(fa)
+    torch.cuda.synchronize()
+    assert torch.equal(ra[0], ra3[0]) and torch.equal(ra[1], ra3[1]) and torch.equal(ra[2], ra3[2])
