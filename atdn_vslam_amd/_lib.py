@@ -16,6 +16,7 @@ SIGNATURES = {
     "atdn_version": (C.c_int, []),
     "atdn_last_error": (C.c_char_p, []),
     "atdn_gma_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "atdn_gma_set_low_latency": (C.c_int, [_vp, C.c_int]),
     "atdn_gma_load": (C.c_int, [_vp, C.c_char_p, _vp, _i64p, C.c_int]),
     "atdn_gma_finalize": (C.c_int, [_vp]),
     "atdn_gma_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

@@ -44,8 +44,12 @@ void launch_qk_softmax(const float* qk, const AttnGeom& g, const float* rowmax, 
 // out[b][m][c] = mf[b][m][c] + gamma * rinv[b][m] * sum_k P[b][m][k] * V[b][k][c]          (gma.py:111-115)
 //   vT sf [B][128][ldN] (V transposed, k contiguous, the 32 keys of every chunk in the operand order above: SfVT);
 //   mf / out sf rows with pixel stride ld (floats), per-pair stride sb
+// `part` != nullptr (the low-latency form, round 6): when the launch would leave most CUs idle (B <= 4 at KITTI size) the key axis
+// is cut into attn_v_splits(g) ranges, one block each, with fp32 partial slabs in `part` ([8][B][Npad][128] floats) and a reduce
+// pass; another summation order than the one-block-per-tile form, so only callers that asked for it get it.
+int attn_v_splits(const AttnGeom& g);
 void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const float* vT, const float* gamma,
-                   const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st);
+                   const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st, float* part = nullptr);
 // debug / tests: normalised probabilities as fp32 rows [B][N][ldN]
 void launch_attn_decode(const float* P, const float* rinv, const AttnGeom& g, float* rows, hipStream_t st);
 

@@ -336,11 +336,17 @@ __device__ unsigned atdn_attn_stamps_dev[1024][2][8];
 #else
 #define STAMP(k) do {} while (0)
 #endif
-template <bool FAST>
+// SPLIT (round 6: the low-latency form for the per-frame callers, B <= 4): the key axis of a (pair, 8 strips) tile is cut into
+// `nsplit` ranges of `qsplit` chunks, one block each — ONE pair is 29 tiles on 256 CUs otherwise (attention x V was 2.4 of the
+// 7.1 ms of a single-pair forward) — and a block stores its raw fp32 sums into its slab of `part` [nsplit][B][Npad][128];
+// attn_reduce_kernel adds the slabs in order and applies the residual. Same kernel body, another summation order: the
+// default path (SPLIT = false) keeps one order for every batch size, which is what makes clip mode bit-identical to pair mode.
+template <bool FAST, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict__ P, const float* __restrict__ rinv,
                                                         const AttnGeom g, const float* __restrict__ vT,
                                                         const float* __restrict__ gamma, const float* __restrict__ mf,
-                                                        float* __restrict__ out, const long sb, const int ld) {
+                                                        float* __restrict__ out, const long sb, const int ld,
+                                                        const int qsplit = 0, float* __restrict__ part = nullptr) {
   // Round 3: the multiply runs on v_mfma_f32_16x16x32_f16 (K = 32 = one whole chunk of keys per instruction; same FLOP per
   // cycle, but the chip holds a higher clock under this shape on random operands: §3.10 of DESIGN.md). A = V^T (16 channels
   // per block), B = the attention fragment (16 query rows per block): lane (n = lane & 15, g = lane >> 4) holds row / column
@@ -356,16 +362,20 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool setA = wave < 4;
   const int tiles = (g.RT + 7) >> 3;
-  const int id = xcd_remap(blockIdx.x, g.B * tiles);
+  const int nsplit = SPLIT ? (g.Q + qsplit - 1) / qsplit : 1;
+  const int id0 = xcd_remap(blockIdx.x, g.B * tiles * nsplit);
+  const int ks = SPLIT ? id0 % nsplit : 0;
+  const int id = SPLIT ? id0 / nsplit : id0;
   const int b = id / tiles, tile = id - b * tiles;
   const int strip = tile * 8 + wave;
   const bool strip_ok = strip < g.RT;
   const int n16 = lane & 15, g16 = lane >> 4;
-  const int Q = g.Q;
+  const int qlo = SPLIT ? ks * qsplit : 0;             // first chunk of this block's key range
+  const int Q = SPLIT ? min(qsplit, g.Q - qlo) : g.Q;  // ... and its length: every chunk index below is relative to qlo
 
   // (address arithmetic of the two streams on the scalar unit — wave index through readfirstlane, uniform bases + 32-bit lane
   // offsets — was measured in round 4: 1-3 % SLOWER on the stage, not kept)
-  const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * Q) * BLK;
+  const char* pblk = reinterpret_cast<const char*>(P) + ((long)(b * g.RT + min(strip, g.RT - 1)) * g.Q + qlo) * BLK;
   typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
   f16x8 ring[D][2];      // [slot][row block]
   u32x4s ringb[D];       // residual bytes of both row blocks: one load
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   // per row, eight lanes = one contiguous 128-byte row, no bank conflicts (the 8-byte piece moves this replaced had
   // SQ_LDS_BANK_CONFLICT at 17 % of the kernel's LDS cycles).
   const int lr = (tid & 255) >> 3, ls = tid & 7;
-  const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls;
+  const float* vrow = vT + ((long)b * 128 + lr) * g.ldN + 4 * ls + qlo * 32;
   constexpr int NSTG = 4;
   v4f breg[2][NSTG];
   auto fetchB = [&](int q, int set) __attribute__((always_inline)) {
@@ -555,6 +565,20 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
   }
 #endif
   // lane (n, g) holds, for query rows 32 strip + 16 rb + n, channels 16 cb + 4 g + 0..3
+  if constexpr (SPLIT) {
+    float* pp = part + ((long)ks * g.B + b) * g.Npad * 128;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = strip * 32 + 16 * rb + n16;
+      if (strip_ok && m < g.N) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+          *reinterpret_cast<float4*>(pp + (long)m * 128 + 16 * cb + 4 * g16) =
+              make_float4(acc[cb][rb][0], acc[cb][rb][1], acc[cb][rb][2], acc[cb][rb][3]);
+      }
+    }
+    return;
+  }
   const float gam = gamma[0];
   const float* mfb = mf + (long)b * sb;
   float* ob = out + (long)b * sb;
@@ -573,6 +597,33 @@ __global__ __launch_bounds__(512, 2) void attn_v3_kernel(const float* __restrict
         sf_store4_flag(ob, (long)m * ld, c, o, clamped);
       }
     }
+  }
+  sf_report(clamped);
+}
+
+// the split form's second half: out[b][m][c] = mf + gamma * rinv[m] * (slab 0 + slab 1 + ... in order), stored as sf
+__global__ __launch_bounds__(256) void attn_reduce_kernel(const float* __restrict__ part, const int nsplit, const AttnGeom g,
+                                                          const float* __restrict__ rinv, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mf, float* __restrict__ out, const long sb,
+                                                          const int ld) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // one thread = 4 channels of one query row
+  const long rows = (long)g.B * g.N;
+  bool clamped = false;
+  if (i < rows * 32) {
+    const long row = i >> 5;
+    const int c = (int)(i & 31) * 4;
+    const int b = (int)(row / g.N), m = (int)(row - (long)b * g.N);
+    const long slab = (long)g.B * g.Npad * 128;
+    const float* p = part + ((long)b * g.Npad + m) * 128 + c;
+    float4 s = *reinterpret_cast<const float4*>(p);
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 t = *reinterpret_cast<const float4*>(p + k * slab);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const float rv = rinv[(long)b * g.Npad + m] * gamma[0];
+    const float4 x = sf_load4(mf + (long)b * sb, (long)m * ld, c);
+    sf_store4_flag(out + (long)b * sb, (long)m * ld, c, make_float4(x.x + rv * s.x, x.y + rv * s.y, x.z + rv * s.z, x.w + rv * s.w),
+                   clamped);
   }
   sf_report(clamped);
 }
@@ -623,9 +674,29 @@ void launch_qk_softmax(const float* qk, const AttnGeom& g, const float* rowmax, 
   ATDN_HIP(hipGetLastError());
 }
 
+int attn_v_splits(const AttnGeom& g) {
+  // enough key ranges to put a block on (nearly) every CU, at most 8: one pair = 29 tiles -> 8 x 29 chunks
+  const int tiles = g.B * ((g.RT + 7) / 8);
+  int n = std::min(8, std::max(1, 256 / std::max(tiles, 1)));
+  while (n > 1 && (g.Q + n - 1) / n < 8) --n;   // a range of fewer than 8 chunks is all prologue
+  return n;
+}
+
 void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const float* vT, const float* gamma,
-                   const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st) {
+                   const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st, float* part) {
   ATDN_CHECK(g.ldN % 32 == 0 && g.Q * 32 == g.ldN && ld % 32 == 0, "attention geometry");
+  const int want = part ? attn_v_splits(g) : 1;
+  if (want > 1) {
+    const int qsplit = (g.Q + want - 1) / want, nsplit = (g.Q + qsplit - 1) / qsplit;
+    const dim3 gr(g.B * ((g.RT + 7) / 8) * nsplit), bl(512);
+    if (fast) hipLaunchKernelGGL((attn_v3_kernel<true, true>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld, qsplit, part);
+    else hipLaunchKernelGGL((attn_v3_kernel<false, true>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld, qsplit, part);
+    ATDN_HIP(hipGetLastError());
+    const long n4 = (long)g.B * g.N * 32;
+    hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, nsplit, g, rinv, gamma, mf, out, sb, ld);
+    ATDN_HIP(hipGetLastError());
+    return;
+  }
   const dim3 gr(g.B * ((g.RT + 7) / 8)), bl(512);
   if (fast) hipLaunchKernelGGL((attn_v3_kernel<true>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld);
   else hipLaunchKernelGGL((attn_v3_kernel<false>), gr, bl, 0, st, P, rinv, g, vT, gamma, mf, out, sb, ld);

@@ -81,6 +81,12 @@ int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch, int precision) 
   *out = new atdn_gma(H, W, max_batch, precision);
   ATDN_API_END
 }
+int atdn_gma_set_low_latency(atdn_gma* h, int on) {
+  ATDN_API_BEGIN
+  ATDN_CHECK(h, "null handle");
+  h->net.set_low_latency(on != 0);
+  ATDN_API_END
+}
 int atdn_gma_load(atdn_gma* h, const char* key, const float* data, const int64_t* shape, int rank) {
   ATDN_API_BEGIN
   ATDN_CHECK(h && key && data && rank >= 0 && rank <= 4, "bad state-dict entry");

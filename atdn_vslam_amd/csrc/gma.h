@@ -65,6 +65,13 @@ class GmaNet {
   // modes use the bricked pyramid (every level a GEMM against pooled features in brick order, 4 x 8 cells = one 128-byte
   // line), the lookup fused with convc1 (lookup_fused.hip) and the fused attention kernels (attention.hip).
   bool classic_ = false;
+  // Low-latency form for the per-frame callers (neural_slam.py:202 calls the flow network with ONE pair per frame): launches
+  // that would leave most of the chip idle at small B are cut finer — today attention x V, along its key axis (attention.h).
+  // Another summation order than the default path, so it is opt-in (set before finalize()); the default path keeps clip mode,
+  // continued clips and pair mode bit-identical.
+  bool low_latency_ = false;
+  void set_low_latency(bool on);
+  DeviceBuf attn_part_;   // [8][maxB][Npad][128] fp32 partial sums of the split attention x V
   DeviceBuf fbrick_[4], fplain_[3], coords_used_;   // features in brick order (levels 0-3), plain pooled features (1-3)
   int brickBW_[4], brickBH_[4], brickNB_[4];
   BrickPyramid brick_pyramid() const;

@@ -147,6 +147,11 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   (void)hipGetDevice(&dev_);   // (no throw: argument errors must be reportable without a device; finalize() needs one anyway)
 }
 
+void GmaNet::set_low_latency(bool on) {
+  ATDN_CHECK(!ready_, "set_low_latency: call it before finalize() (the workspace and the captured graphs depend on it)");
+  low_latency_ = on;
+}
+
 GmaNet::~GmaNet() {
   DeviceGuard dg(dev_);   // the handle's device, not whichever is current
   // a graph replay or kernel of this handle may still be running on the caller's stream
@@ -157,7 +162,8 @@ GmaNet::~GmaNet() {
                       &rstd_[1], &rstd_[2], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
                       &pre_zr_[1], &pre_q_[0], &pre_q_[1], &rowmax_, &rinv_,
-                      &fbrick_[0], &fbrick_[1], &fbrick_[2], &fbrick_[3], &fplain_[0], &fplain_[1], &fplain_[2], &coords_used_, &fhG_};
+                      &fbrick_[0], &fbrick_[1], &fbrick_[2], &fbrick_[3], &fplain_[0], &fplain_[1], &fplain_[2], &coords_used_, &fhG_,
+                      &attn_part_};
   for (auto* b : all) b->release();
   arena_.release();
 }
@@ -276,6 +282,8 @@ void GmaNet::finalize() {
   const AttnGeom ag = attn_geom(B, N, ldN);
   qk_.alloc(n8 * 256); attn_.alloc(std::max(n8 * ldN, attn_floats(ag))); vT_.alloc((long)B * 128 * ldN);
   if (sf) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
+  // (only where the split can engage: attn_v_splits() is 1 from 8 pairs per launch on at KITTI size)
+  if (sf && low_latency_ && attn_v_splits(attn_geom(1, N, ldN)) > 1) attn_part_.alloc(8L * B * ag.Npad * 128);
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
   z_.alloc(n8 * 128); rh_.alloc(n8 * 128); fh_.alloc(n8 * 256); mask_.alloc(n8 * 576);
   if (sf) fhG_.alloc(2 * n8 * 18);   // (two copies: one per 128-channel block of the fused flow head)
@@ -606,7 +614,7 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   conv_sf_dispatch(v, to_v_.wscale, SfVT{vT_.p, (long)128 * ldN, ldN}, st);   // keys of a chunk in operand order
   mark(ST_AGG_VT, st);
   launch_attn_v(attn_.p, rinv_.p, attn_geom(B, N, ldN), vT_.p, gamma_, mf, x_.p + 256, (long)N * XLD, XLD,
-                sf_fast_mode(), st);
+                sf_fast_mode(), st, attn_part_.p);   // (attn_part_ is null unless the handle was built low-latency)
   mark(ST_AGG, st);
 
   for (int p = 0; p < 2; ++p) {

@@ -131,8 +131,13 @@ class RAFTGMA(_NativeModule):
 
     PRECISIONS = {"f32": 0, "split_f16": 1, "f16": 2}
 
-    def __init__(self, args=None, max_batch=1, precision=None, saturation_check_every=512, saturation_fallback=False):
-        """`saturation_check_every`: in the split-f16 modes the module reads the library's saturation counter after the
+    def __init__(self, args=None, max_batch=1, precision=None, saturation_check_every=512, saturation_fallback=False,
+                 low_latency=False):
+        """`low_latency=True`: the form for the reference's per-frame call pattern (neural_slam.py:202: ONE pair per call) — launches
+        that would leave most of the chip idle at one to four pairs are cut finer (attention x V along its key axis: a single-pair
+        forward 7.1 -> 5.2 ms). Same flow within rounding (~1e-6 px), NOT bit-identical to the default path, whose clip,
+        continued-clip and pair modes are bit-identical to each other; pipeline.VisualOdometry and slam.NeuralSLAM ask for it.
+        `saturation_check_every`: in the split-f16 modes the module reads the library's saturation counter after the
         FIRST forward of a freshly loaded checkpoint (and whenever the weights changed), then every that many forwards
         (0: never again), and `check_saturation()` can be called at any time (OdometryPipeline.run_sequence does, at the end
         of a sequence). A non-zero count raises SplitF16RangeError — or, with `saturation_fallback=True`, switches THIS
@@ -143,6 +148,7 @@ class RAFTGMA(_NativeModule):
         super().__init__()
         self.args = args
         self.saturation_fallback = bool(saturation_fallback)
+        self.low_latency = bool(low_latency)
         self.fell_back = False
         self.saturation_check_every = int(saturation_check_every)
         self.saturation_checks = 0      # how many times the counter has been read (tests)
@@ -243,6 +249,8 @@ class RAFTGMA(_NativeModule):
             h = C.c_void_p()
             mb = max(B, self.max_batch)
             _lib.check(L.atdn_gma_create(C.byref(h), H, W, mb, self.PRECISIONS[self.precision]))
+            if self.low_latency:
+                _lib.check(L.atdn_gma_set_low_latency(h, 1))
             _lib.load_state(L.atdn_gma_load, h, self.state_dict())
             _lib.check(L.atdn_gma_finalize(h))
             ent = (h, fp, L.atdn_gma_destroy, mb)

@@ -86,11 +86,12 @@ class OdometryPipeline:
     """Holds the two networks on one device and runs batches of frame pairs."""
 
     def __init__(self, gma_state, clvo_state, device="cuda:0", max_batch=4, iters=12, size=SLAM_SIZE, precision=None,
-                 saturation_fallback=False):
+                 saturation_fallback=False, low_latency=False):
         self.device = torch.device(device)
         self.iters = iters
         self.size = size
-        self.flow_net = RAFTGMA(max_batch=max_batch, precision=precision, saturation_fallback=saturation_fallback)
+        self.flow_net = RAFTGMA(max_batch=max_batch, precision=precision, saturation_fallback=saturation_fallback,
+                                low_latency=low_latency)
         self.flow_net.load_state_dict(gma_state)
         self.flow_net = self.flow_net.to(self.device).eval()
         self.head = ATDNVO()
@@ -211,7 +212,8 @@ class VisualOdometry:
     """Frame-at-a-time odometry with the reference's call pattern: `pose = vo(frame)`."""
 
     def __init__(self, gma_state, clvo_state, device="cuda:0", iters=12):
-        self.pipe = OdometryPipeline(gma_state, clvo_state, device=device, max_batch=1, iters=iters)
+        # one pair per call: the low-latency form of the flow network (modules.RAFTGMA)
+        self.pipe = OdometryPipeline(gma_state, clvo_state, device=device, max_batch=1, iters=iters, low_latency=True)
         # frame-by-frame caller: every call ends in a device synchronisation anyway (the pose goes to the host), so the
         # split-f16 range guard is read on EVERY forward — no pose computed from clamped activations is ever handed out
         self.pipe.flow_net.saturation_check_every = 1

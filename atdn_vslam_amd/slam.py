@@ -83,7 +83,7 @@ class NeuralSLAM:
         self._device = torch.device(args.device if getattr(args, "device", None) not in (None, "cpu") else "cuda:0")
         # frame-by-frame caller that returns a host pose per call (one device synchronisation each): the split-f16 range guard
         # is read after EVERY forward, so no pose computed from clamped activations is ever returned
-        self._flow_net = RAFTGMA(max_batch=1, precision=precision, saturation_check_every=1)
+        self._flow_net = RAFTGMA(max_batch=1, precision=precision, saturation_check_every=1, low_latency=True)
         self._flow_net.load_state_dict(_load_weights(flow_weights if flow_weights is not None else self.FLOW_CHECKPOINT))
         self._flow_net = self._flow_net.to(self._device).eval()
         self._padder = transforms.InputPadder((3,) + SLAM_SIZE)

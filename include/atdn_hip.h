@@ -45,6 +45,13 @@ const char* atdn_last_error(void);
 #define ATDN_PRECISION_F16 2
 int atdn_gma_create(atdn_gma** out, int H, int W, int max_batch, int precision);
 
+/* Low-latency form for the reference's per-frame call pattern — NeuralSLAM.__call__ runs the flow network on ONE pair per
+ * frame (neural_slam.py:202; evaluate_odometry.py:63-66 likewise): launches that would leave most of the chip idle at one to
+ * four pairs are cut finer (attention x V along its key axis, with fp32 partial sums). Same results within rounding (another
+ * summation order: ~1e-6 px), NOT bit-identical to the default path, whose clip / continued / pair modes are bit-identical to
+ * each other. Call between atdn_gma_create and atdn_gma_finalize; `on` = 0 / 1. */
+int atdn_gma_set_low_latency(atdn_gma* h, int on);
+
 /* One state-dict entry (load_state_dict, neural_slam.py:52). `key` as in the checkpoint, with or without the
  * DataParallel "module." prefix; `data` is a HOST fp32 buffer of the given shape. Non-float buffers
  * (num_batches_tracked, rel_ind) need not be passed. */
