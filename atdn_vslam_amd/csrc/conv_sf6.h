@@ -907,6 +907,19 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
       return false;
     }
   }
+  // Small grids (round 6: one or two pairs per launch — the reference's per-frame call pattern; 47 x 154 pixels are 60 tiles of
+  // 8 x 16): when even 64-wide blocks leave most of the chip's 512 block slots empty, 4 x 16-pixel tiles double the blocks. A
+  // block then carries half the MFMAs behind a relatively larger halo, which costs efficiency nobody is short of at this size.
+  // Same K order as every other tile shape, so the same bits (tests/test_gpu_parity.py: a pair comes out of an 8-pair launch
+  // exactly as out of a single-pair call). Not for the statistics epilogues (their tile height follows from the layer's geometry
+  // alone) nor the fused flow head (one block holds all channels of its pixels).
+  if constexpr (!Epi::kStats && !epi_flowhead<Epi>::value) {
+    if (bn == 64 && tiles * cdiv(s.N, 64) < 300) {
+      *bn_out = 64; *th_out = 4;
+      launch_conv_sf6_m<4, 64, 2, 2, KH, KW, Epi, FAST, false>(s, wscale, ep, st);
+      return true;
+    }
+  }
   if constexpr (KH == 3) {
     if (bn == 32) { *bn_out = 32; launch_conv_sf6_m<8, 32, 4, 1, KH, KW, Epi, FAST, false>(s, wscale, ep, st); return true; }
     const long tiles12 = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
