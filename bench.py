@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--config3-frames", type=int, default=4541, help="frames of the synthetic sequence of the config3 leg")
     ap.add_argument("--no-f16-leg", action="store_true", help="skip the secondary timed pass in the f16 fast mode")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the secondary timed pass in the exact-fp32 mode")
+    ap.add_argument("--no-per-frame-leg", action="store_true", help="skip the one-pair-per-call leg (the reference's per-frame call pattern)")
     ap.add_argument("--launch-check", action="store_true",
                     help="dry run of the launch plumbing only: every rank joins a gloo group, the ranks all-gather their "
                          "(rank, local rank, threads), rank 0 prints one JSON line; no GPU call is made")
@@ -481,6 +482,25 @@ def main():
         active[0] = pipes
         del exact
 
+    # ---- the reference's own call pattern as a secondary leg: ONE frame per call (NeuralSLAM.__call__ in odometry mode,
+    # neural_slam.py:192-227 = pipeline.VisualOdometry): host uint8 frame -> H2D -> resize -> flow (one pair, the low-latency form) ->
+    # head (one LSTM step) -> pose on the host, synchronous; rank 0 only, never the headline
+    per_frame = None
+    if not args.no_per_frame_leg and rank == 0 and args.precision == "split_f16":
+        from atdn_vslam_amd.pipeline import VisualOdometry
+        vo = VisualOdometry(gsd, hsd, device=dev, iters=ITERS)
+        nf = 24
+        for k in range(4):
+            vo(seq_host[k])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(4, 4 + nf):
+            pose = vo(seq_host[k])
+        torch.cuda.synchronize()
+        per_frame = ((time.perf_counter() - t0) / nf, nf)
+        assert bool(torch.isfinite(pose).all())
+        del vo
+
     if rank == 0:
         total_pairs = world * K * B
         # per-stage device time of the same forward in this run, eager with HIP events on the launch stream
@@ -566,6 +586,12 @@ def main():
                                 "role": "the mode RAFTGMA(saturation_fallback=True) switches to when the split-f16 range guard trips",
                                 "flow_up_abs_diff_vs_split_f16_px": {"max": f32[3][0], "mean": f32[3][1], "max_abs_flow": f32[3][2],
                                                                      "sample": "%d pairs of the bench clip, 12 iterations" % B}}
+        if per_frame is not None:
+            out["per_frame"] = {"value": 1.0 / per_frame[0], "unit": "frame-pairs/s", "ms_per_frame": per_frame[0] * 1e3, "frames": per_frame[1],
+                                "workload": "pipeline.VisualOdometry: one host uint8 frame per call -> pose on the host, synchronous "
+                                            "(NeuralSLAM.__call__'s odometry branch, neural_slam.py:192-227); flow network in its "
+                                            "low-latency form (one pair per launch)",
+                                "ratio_to_value": (1.0 / per_frame[0]) / (total_pairs / dt)}
         if h2d is not None:
             # second timed pass of the same K steps with the uint8 frames in pinned HOST memory: H2D (copy stream,
             # double-buffered) + convert + resize inside the timed region. Never the headline `value`.

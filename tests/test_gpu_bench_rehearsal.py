@@ -18,7 +18,7 @@ def test_two_rank_bench_rehearsal_prints_one_valid_line():
     env = dict(os.environ, ATDN_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--config3-frames", "44"]
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--no-per-frame-leg", "--config3-frames", "44"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -45,7 +45,7 @@ def test_bench_config3_with_a_shard_shorter_than_one_clip():
     env = dict(os.environ, ATDN_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--config3-frames", "10"]
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--no-per-frame-leg", "--config3-frames", "10"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -62,7 +62,7 @@ def test_bench_collectives_on_real_rccl_at_world_size_one():
     env = dict(os.environ, ATDN_BENCH_FORCE_DIST="1", ATDN_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29621", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
-           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--config3-frames", "40"]
+           "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg", "--no-f16-leg", "--no-f32-leg", "--no-per-frame-leg", "--config3-frames", "40"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -79,7 +79,7 @@ def test_bench_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(ATDN_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--no-h2d-leg",
-           "--no-f16-leg", "--no-f32-leg", "--config3-frames", "40"]
+           "--no-f16-leg", "--no-f32-leg", "--no-per-frame-leg", "--config3-frames", "40"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
