@@ -149,6 +149,7 @@ class RAFTGMA(_NativeModule):
         self.args = args
         self.saturation_fallback = bool(saturation_fallback)
         self.low_latency = bool(low_latency)
+        self._stream_tail = None        # forward_consecutive: (last frame tensor, its version, handle) of the chain in progress
         self.fell_back = False
         self.saturation_check_every = int(saturation_check_every)
         self.saturation_checks = 0      # how many times the counter has been read (tests)
@@ -174,6 +175,7 @@ class RAFTGMA(_NativeModule):
 
     def _drop_handles(self):
         super()._drop_handles()
+        self._stream_tail = None
         self._sat_pending = True        # new weights (load_state_dict / .to()): the next forward is checked again
 
     def check_saturation(self, raise_on_clamp=True):
@@ -266,6 +268,7 @@ class RAFTGMA(_NativeModule):
         `flow_predictions` (network.py:106-129) — a list of `iters` tensors [B,2,H,W], the upsampled flow after every iteration;
         values only (this module is inference-only: the list carries no autograd graph)."""
         self._require_input(image1, "RAFTGMA.forward")
+        self._stream_tail = None   # pair mode overwrites the handle's feature maps: a forward_consecutive chain ends here
         if image1.shape != image2.shape or image1.dim() != 4 or image1.shape[1] != 3:
             raise RuntimeError("expected two [B,3,H,W] frames, got %s and %s" % (tuple(image1.shape), tuple(image2.shape)))
         B, _, H, W = image1.shape
@@ -304,6 +307,7 @@ class RAFTGMA(_NativeModule):
         Same bits as the non-continued call and as pair mode (round 3: the kernels' statistics grouping no longer depends on
         how many images share a launch; tests/test_gpu_round3.py)."""
         self._require_input(frames, "RAFTGMA.forward_sequence")
+        self._stream_tail = None
         if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[0] < 2:
             raise RuntimeError("expected frames [B+1,3,H,W] with B >= 1, got %s" % (tuple(frames.shape),))
         if self.precision not in ("split_f16", "f16"):
@@ -325,6 +329,30 @@ class RAFTGMA(_NativeModule):
         if retry:   # (the f32 mode has no sequence form: pair mode on the same frames)
             return self.forward(frames[:-1], frames[1:], iters=iters, flow_init=flow_init, test_mode=True)
         return flow_low, flow_up
+
+    @torch.no_grad()
+    def forward_consecutive(self, prev, cur, iters=12):
+        """`flow_net(prev[None], cur[None], iters, test_mode=True)` for a caller that walks a sequence one frame per call
+        (NeuralSLAM.__call__, neural_slam.py:192-227: frame t is image2 of one pair and image1 of the next): when `prev` IS the
+        tensor that was `cur` of the previous call of this method — same object, not modified since, same handle, nothing else
+        run on the module in between — its features are still in the handle and only `cur` goes through the feature network
+        (atdn_gma_forward_sequence_continued with one pair). The continued form gives the bits of pair mode
+        (tests/test_gpu_round3.py), so this is pair mode minus one feature-network pass; anything that breaks the chain (another
+        forward, new weights, .to(), another frame size) just makes the next call encode both frames again."""
+        self._require_input(cur, "RAFTGMA.forward_consecutive")
+        if prev.shape != cur.shape or cur.dim() != 3 or cur.shape[0] != 3:
+            raise RuntimeError("expected two [3,H,W] frames, got %s and %s" % (tuple(prev.shape), tuple(cur.shape)))
+        if self.precision not in ("split_f16", "f16"):
+            return self.forward(prev[None], cur[None], iters=iters, test_mode=True)
+        key = self._key(cur.shape[1], cur.shape[2])
+        ent, tail = self._handles.get(key), self._stream_tail
+        cont = (tail is not None and ent is not None and tail[0] is prev and tail[1] == prev._version and tail[2] == ent[0].value
+                and ent[1] == self._fingerprint())
+        low, up = self.forward_sequence(torch.stack([prev, cur]), iters=iters, continued=cont)
+        ent = self._handles.get(key)
+        if ent is not None and not self.fell_back:
+            self._stream_tail = (cur, cur._version, ent[0].value)   # (holds `cur`: its storage cannot be handed to another tensor)
+        return low, up
 
     def debug_read(self, name, shape, H, W):
         """Copy an internal activation of the (H, W) handle to a CPU tensor (parity tests)."""

@@ -230,7 +230,8 @@ class VisualOdometry:
         im = resize_frames(im.to(self.device).float())
         im = self.pipe.padder.pad(im)[0]
         if self._prev is not None:
-            _, flow = self.pipe.flow_net(self._prev[None], im[None], iters=self.pipe.iters, test_mode=True)
+            # (pair mode's bits; the previous frame's features are reused when the chain of calls is unbroken)
+            _, flow = self.pipe.flow_net.forward_consecutive(self._prev, im, iters=self.pipe.iters)
             rot, tr = self.pipe.head(flow)
             self.current_pose = transforms.accumulate(self.current_pose, rot.squeeze().cpu(), tr.squeeze().cpu())
         self._prev = im

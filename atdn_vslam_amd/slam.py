@@ -161,7 +161,8 @@ class NeuralSLAM:
             im = resize_frames(im.to(self._device).float(), SLAM_SIZE)
             if self._image_buffer is not None:
                 im2 = self._padder.pad(im)[0]
-                _, flow = self._flow_net(self._image_buffer[None], im2[None], iters=12, test_mode=True)
+                # (pair mode's bits, one feature-network pass per frame while the chain of odometry calls is unbroken)
+                _, flow = self._flow_net.forward_consecutive(self._image_buffer, im2, iters=12)
                 pred_rot, pred_tr = self._odometry_net(flow)
                 rot, tr = pred_rot.squeeze().cpu(), pred_tr.squeeze().cpu()
                 pred_mat = transforms.transform(rot, tr)

@@ -67,3 +67,32 @@ def test_low_latency_is_faster_for_one_pair_per_call():
         out[name] = (time.perf_counter() - t0) / 10 * 1e3
     print("single-pair forward, 376x1232, 12 iterations: default %.2f ms, low-latency %.2f ms" % (out["default"], out["low_latency"]))
     assert out["low_latency"] < out["default"]
+
+
+@pytest.mark.parametrize("low_latency", [False, True])
+def test_forward_consecutive_is_pair_mode_minus_one_feature_pass(low_latency):
+    """RAFTGMA.forward_consecutive(prev, cur): what the per-frame callers use. While the chain of calls is unbroken only `cur`
+    passes the feature network (the continued form of the sequence call, one pair); the flows are pair mode's, bit for bit.
+    A pair-mode call in between, a frame modified in place, or a `prev` that is not the previous `cur` end the chain — the next
+    call encodes both frames again and still gives pair mode's bits."""
+    net = _net(low_latency)
+    ref = _net(low_latency)
+    fr = [f.clone() for f in torch.from_numpy(syn.make_frames(7, 160, 512, seed=31)).to(DEV)]
+
+    def pair(a, b):
+        return ref(a[None], b[None], iters=6, test_mode=True)[1]
+
+    for k in range(1, 4):                                   # unbroken chain: calls 2 and 3 are continued
+        up = net.forward_consecutive(fr[k - 1], fr[k], iters=6)[1]
+        assert torch.equal(up, pair(fr[k - 1], fr[k])), k
+    assert net._stream_tail is not None and net._stream_tail[0] is fr[3]
+    net(fr[0][None], fr[1][None], iters=6, test_mode=True)  # something else runs on the module: the chain ends
+    assert net._stream_tail is None
+    up = net.forward_consecutive(fr[3], fr[4], iters=6)[1]
+    assert torch.equal(up, pair(fr[3], fr[4]))
+    fr[4].mul_(0.5)                                         # the previous frame is modified in place: its features are stale
+    up = net.forward_consecutive(fr[4], fr[5], iters=6)[1]
+    assert torch.equal(up, pair(fr[4], fr[5]))
+    other = fr[5].clone()                                   # equal content, another tensor: not trusted, encoded again
+    up = net.forward_consecutive(other, fr[6], iters=6)[1]
+    assert torch.equal(up, pair(other, fr[6]))
