@@ -13,6 +13,7 @@
 //       — every wave interleaving its own memory work with its own MFMAs — and the 4-byte SF4 element format were
 //       deleted in round 3 after their A/B tests; measurements in DESIGN.md 3.6.)
 #include "attention.h"
+#include <cstdlib>
 
 #include <type_traits>
 
@@ -685,7 +686,9 @@ int attn_v_splits(const AttnGeom& g) {
 void launch_attn_v(const float* P, const float* rinv, const AttnGeom& g, const float* vT, const float* gamma,
                    const float* mf, float* out, long sb, int ld, bool fast, hipStream_t st, float* part) {
   ATDN_CHECK(g.ldN % 32 == 0 && g.Q * 32 == g.ldN && ld % 32 == 0, "attention geometry");
-  const int want = part ? attn_v_splits(g) : 1;
+  // (ATDN_ATTN_FORCE_SPLIT=n: the experiment of DESIGN.md section 10.4 — the split form at ANY batch size, n key ranges)
+  static const int force = getenv("ATDN_ATTN_FORCE_SPLIT") ? atoi(getenv("ATDN_ATTN_FORCE_SPLIT")) : 0;
+  const int want = !part ? 1 : force > 0 ? std::min(force, 8) : attn_v_splits(g);
   if (want > 1) {
     const int qsplit = (g.Q + want - 1) / want, nsplit = (g.Q + qsplit - 1) / qsplit;
     const dim3 gr(g.B * ((g.RT + 7) / 8) * nsplit), bl(512);

@@ -148,7 +148,7 @@ class RAFTGMA(_NativeModule):
         super().__init__()
         self.args = args
         self.saturation_fallback = bool(saturation_fallback)
-        self.low_latency = bool(low_latency)
+        self.low_latency = bool(low_latency) or os.environ.get("ATDN_LOW_LATENCY") == "1"   # (the variable: experiments only)
         self._stream_tail = None        # forward_consecutive: (last frame tensor, its version, handle) of the chain in progress
         self.fell_back = False
         self.saturation_check_every = int(saturation_check_every)
