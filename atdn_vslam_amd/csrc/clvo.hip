@@ -103,7 +103,7 @@ void ClvoNet::finalize() {
     r.skip_w = arena_.dev(r.skip_w_off); r.skip_b = arena_.dev(r.skip_b_off);
   }
   scan_graph_ = !(getenv("ATDN_NO_GRAPH") && getenv("ATDN_NO_GRAPH")[0] == '1');
-  scan_persistent_ = !(getenv("ATDN_SCAN_PERSISTENT") && getenv("ATDN_SCAN_PERSISTENT")[0] == '0');
+  scan_persistent_ = !(getenv("ATDN_SCAN_PERSISTENT") && getenv("ATDN_SCAN_PERSISTENT")[0] == '0') && lstm_scan_fits_device();
   scan_xch_.alloc((lstm_scan_exchange_bytes() + 3) / 4);
   ATDN_HIP(hipHostMalloc(reinterpret_cast<void**>(&scan_abort_host_), 64, hipHostMallocDefault));
   *scan_abort_host_ = 0u;

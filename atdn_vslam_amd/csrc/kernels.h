@@ -78,6 +78,7 @@ void launch_lstm_pipe(const LstmPipeArgs& a, hipStream_t st);
 // (read at the start, written at the end), `h2seq` [T][512] = lstm2's hidden state after every step, `exchange` = a device
 // buffer of lstm_scan_exchange_bytes() that this call zeroes on the stream before the launch.
 long lstm_scan_exchange_bytes();
+bool lstm_scan_fits_device();   // all 128 workgroups resident at once on the current device?
 void launch_lstm_scan(const float* pre1, const float* Whh1, const float* bhh1, const float* Wlin, const float* blin,
                       const float* Wih2, const float* bih2, const float* Whh2, const float* bhh2, float* state, float* h2seq,
                       void* exchange, int T, hipStream_t st);

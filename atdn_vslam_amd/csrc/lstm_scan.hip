@@ -298,6 +298,19 @@ __global__ __launch_bounds__((NWV + 1) * 64) void lstm_scan_kernel(const ScanArg
 
 }  // namespace
 
+// Can every workgroup of the persistent kernel be resident at once on this device? (A partitioned or smaller part — fewer CUs than
+// the 128 workgroups need at one 5-wave workgroup per CU — would park the surplus workgroups behind the resident ones, which
+// wait for them: the bounded spins would end the launch after 0.5 s with NaN poses. Such a device keeps the per-step kernel.)
+bool lstm_scan_fits_device() {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_scan_kernel<4>, 5 * 64, 0) != hipSuccess) return false;
+  // the occupancy query can over-report by one workgroup per CU (MI355X_MICROARCH.md, residency): count one fewer where it says > 1
+  const int safe = per_cu > 1 ? per_cu - 1 : per_cu;
+  return (long)safe * cus >= HD / 4;
+}
+
 long lstm_scan_exchange_bytes() { return (long)(2 * NGRAN) * 8 + 64; }
 
 void launch_lstm_scan(const float* pre1, const float* Whh1, const float* bhh1, const float* Wlin, const float* blin,
