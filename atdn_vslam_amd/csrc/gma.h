@@ -1,5 +1,6 @@
 // GMA optical-flow forward (RAFTGMA.forward, test_mode=True) as one hipGraph of hand-written kernels.
 #pragma once
+#include <vector>
 #include <map>
 #include <memory>
 
@@ -72,6 +73,17 @@ class GmaNet {
   bool low_latency_ = false;
   void set_low_latency(bool on);
   DeviceBuf attn_part_;   // [8][maxB][Npad][128] fp32 partial sums of the split attention x V
+  // ... and, in the captured graph of one or two pairs, independent chains run as parallel branches on a second capture
+  // stream: feature network + correlation pyramid beside context network + attention + GRU context terms, and inside an
+  // iteration the flow branch of the motion encoder beside the correlation branch. Same kernels, same operands (the context
+  // network gets scratch maps of its own), so the same bits; at 16 pairs every launch fills the chip and branches only
+  // share hardware queues with the other clip's stream (round 3 measured that: -3 % in the sequence driver).
+  DeviceBuf enc2_[4];
+  hipStream_t par_stream_ = nullptr;
+  std::vector<hipEvent_t> par_events_;
+  size_t par_next_ = 0;
+  bool par_ = false;       // true only inside capture() of a low-latency handle
+  void fork(hipStream_t from, hipStream_t to);   // `to` continues from where `from` stands
   DeviceBuf fbrick_[4], fplain_[3], coords_used_;   // features in brick order (levels 0-3), plain pooled features (1-3)
   int brickBW_[4], brickBH_[4], brickNB_[4];
   BrickPyramid brick_pyramid() const;
@@ -84,7 +96,8 @@ class GmaNet {
   void iteration(int B, hipStream_t st);
   void run_body_sf(int B, int iters, hipStream_t st);
   // first_img: index of the first image of img4_ to encode (continued sequences skip frame 0 in the feature network)
-  void run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int first_img = 0);
+  void run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int first_img = 0,
+                      DeviceBuf* bufs = nullptr);   // bufs: four scratch maps (default enc_)
   void iteration_sf(int B, hipStream_t st);
   void capture(int B, int iters);
   void launch_body(int B, int iters, hipStream_t st);

@@ -147,6 +147,13 @@ GmaNet::GmaNet(int H_, int W_, int max_batch, int precision_) : H(H_), W(W_), ma
   (void)hipGetDevice(&dev_);   // (no throw: argument errors must be reportable without a device; finalize() needs one anyway)
 }
 
+void GmaNet::fork(hipStream_t from, hipStream_t to) {
+  ATDN_CHECK(par_next_ < par_events_.size(), "out of branch events");
+  hipEvent_t e = par_events_[par_next_++];
+  ATDN_HIP(hipEventRecord(e, from));
+  ATDN_HIP(hipStreamWaitEvent(to, e, 0));
+}
+
 void GmaNet::set_low_latency(bool on) {
   ATDN_CHECK(!ready_, "set_low_latency: call it before finalize() (the workspace and the captured graphs depend on it)");
   low_latency_ = on;
@@ -158,12 +165,14 @@ GmaNet::~GmaNet() {
   (void)hipDeviceSynchronize();
   for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
+  if (par_stream_) (void)hipStreamDestroy(par_stream_);
+  for (auto& e : par_events_) (void)hipEventDestroy(e);
   DeviceBuf* all[] = {&img4_, &enc_[0], &enc_[1], &enc_[2], &enc_[3], &scratch_, &pcnt_, &fin_, &fmap_, &psum_, &pm2_, &mean_[0], &mean_[1], &mean_[2], &rstd_[0],
                       &rstd_[1], &rstd_[2], &pyr_[0], &pyr_[1], &pyr_[2], &pyr_[3], &h_[0], &h_[1], &x_, &qk_, &attn_, &vT_,
                       &corrfeat_, &cor1_, &corflo_, &flo1_, &z_, &rh_, &fh_, &mask_, &coords1_, &flow4_, &pre_zr_[0],
                       &pre_zr_[1], &pre_q_[0], &pre_q_[1], &rowmax_, &rinv_,
                       &fbrick_[0], &fbrick_[1], &fbrick_[2], &fbrick_[3], &fplain_[0], &fplain_[1], &fplain_[2], &coords_used_, &fhG_,
-                      &attn_part_};
+                      &attn_part_, &enc2_[0], &enc2_[1], &enc2_[2], &enc2_[3]};
   for (auto* b : all) b->release();
   arena_.release();
 }
@@ -284,6 +293,12 @@ void GmaNet::finalize() {
   if (sf) { rowmax_.alloc((long)B * ag.Npad); rinv_.alloc((long)B * ag.Npad); }
   // (only where the split can engage: attn_v_splits() is 1 from 8 pairs per launch on at KITTI size)
   if (sf && low_latency_ && attn_v_splits(attn_geom(1, N, ldN)) > 1) attn_part_.alloc(8L * B * ag.Npad * 128);
+  if (sf && low_latency_) {
+    for (int i = 0; i < 4; ++i) enc2_[i].alloc((long)B * H2 * W2 * 64);
+    ATDN_HIP(hipStreamCreateWithFlags(&par_stream_, hipStreamNonBlocking));
+    par_events_.resize(2 * (1 + 64));
+    for (auto& e : par_events_) ATDN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   corrfeat_.alloc(n8 * CORR_LD); cor1_.alloc(n8 * 256); corflo_.alloc(n8 * 256); flo1_.alloc(n8 * 128);
   z_.alloc(n8 * 128); rh_.alloc(n8 * 128); fh_.alloc(n8 * 256); mask_.alloc(n8 * 576);
   if (sf) fhG_.alloc(2 * n8 * 18);   // (two copies: one per 128-channel block of the fused flow head)
@@ -484,10 +499,12 @@ void GmaNet::mask_head(int B, hipStream_t st) {
 // =============================================================== split-f16 pipeline (precision == 1)
 // Same op sequence; every TAP-mode GEMM runs on conv_sf_kernel and every tensor that feeds one is stored in the
 // sf format (sf.h). ROW-mode layers (7x7 stems, convf1) stay on the exact-fp32 engine and write sf directly.
-void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int first_img) {
+void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hipStream_t st, float** out_buf, int first_img,
+                            DeviceBuf* bufs) {
   const float* images = img4_.p + (long)first_img * H * W * 4;
   int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
-  float* X = enc_[0].p; float* R = enc_[1].p; float* Y = enc_[2].p; float* O = enc_[3].p;
+  DeviceBuf* eb = bufs ? bufs : enc_;
+  float* X = eb[0].p; float* R = eb[1].p; float* Y = eb[2].p; float* O = eb[3].p;
   // in_slot >= 0: `src` is the RAW output of the previous statistics conv and mean_/rstd_[in_slot] are its statistics
   // (normalise-on-load: the conv's patch loader applies InstanceNorm + ReLU itself)
   auto stats_sf = [&](const PackedConv& L, const float* src, int ld, int ih, int iw, int stride, int pad, float* dst,
@@ -584,6 +601,7 @@ void GmaNet::run_encoder_sf(const EncoderWeights& E, bool instance, int nimg, hi
 void GmaNet::iteration_sf(int B, hipStream_t st) {
   const long n8 = (long)B * N;
   ConvShape s;
+  if (par_) fork(st, par_stream_);   // the flow branch starts where the previous iteration (or the set-up) ended
   // cor1 = relu(convc1(lookup(coords1))) in one kernel: the 324 samples of a pixel never leave the CU
   launch_lookup_conv(brick_pyramid(), coords1_.p, n8, coords_used_.p, convc1_.wf16, convc1_.wscale, convc1_.b, cor1_.p,
                      sf_fast_mode(), st);
@@ -596,11 +614,20 @@ void GmaNet::iteration_sf(int B, hipStream_t st) {
   // 1.25 rounds become 5) — motion encoder 5.80 -> 5.57 ms per forward on ONE stream; under bench.py's two streams the other
   // clip's launches were already filling those tails and the rate does not move (410.3 / 410.3 / 408.9 against 410.5 / 410.3 /
   // 409.1 pairs/s, profiles/r05_ab_pair_launch.txt). Kept for callers with one stream.)
-  launch_flow_conv7_sf(flow4_.p, B, H8, W8, arena_.dev(convf1_sf_off_), convf1_wscale_, convf1_.b, flo1_.p, sf_fast_mode(), st);
   s = conv_shape(convc2_, cor1_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   const ConvShape sf2 = conv_shape(convf2_, flo1_.p, 128, (long)N * 128, B, H8, W8, 1, 1, 1);
-  conv_sf_dispatch_pair(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256},
-                        sf2, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
+  if (par_) {
+    // low-latency capture: the flow branch (convf1 -> convf2) runs beside the correlation branch (lookup + convc1 -> convc2);
+    // it was forked at the top of the iteration (the lookup above is already on `st`)
+    launch_flow_conv7_sf(flow4_.p, B, H8, W8, arena_.dev(convf1_sf_off_), convf1_wscale_, convf1_.b, flo1_.p, sf_fast_mode(), par_stream_);
+    conv_sf_dispatch(sf2, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, par_stream_);
+    conv_sf_dispatch(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256}, st);
+    fork(par_stream_, st);   // join
+  } else {
+    launch_flow_conv7_sf(flow4_.p, B, H8, W8, arena_.dev(convf1_sf_off_), convf1_wscale_, convf1_.b, flo1_.p, sf_fast_mode(), st);
+    conv_sf_dispatch_pair(s, convc2_.wscale, SfBias<ACT_RELU>{convc2_.b, corflo_.p, (long)N * 256, 256},
+                          sf2, convf2_.wscale, SfBias<ACT_RELU>{convf2_.b, corflo_.p + 192, (long)N * 256, 256}, st);
+  }
   s = conv_shape(convm_, corflo_.p, 256, (long)N * 256, B, H8, W8, 1, 1, 1);
   float* mf = x_.p + 128;
   conv_sf_dispatch(s, convm_.wscale, SfBias<ACT_RELU>{convm_.b, mf, (long)N * XLD, XLD}, st);
@@ -646,6 +673,10 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   // were already moved into fmap_ slot 0 by forward_sequence and only frames 1..B are encoded (img4_ still holds all
   // B+1 frames: the context network needs frame 0)
   const int nfeat = seq_ == 0 ? 2 * B : seq_ == 1 ? B + 1 : B;
+  // low-latency capture (par_): the context chain (context network -> attention -> GRU context terms) is a branch of its own
+  // beside the feature chain (feature network -> correlation pyramid); they share no tensor (enc2_: the context network's maps)
+  hipStream_t sB = par_ ? par_stream_ : st;
+  if (par_) fork(st, sB);
   // (Round 4 measured the encoders depth-first in sub-batches of <= 2-8 frames, so that a conv's output and its consumer's
   // input fit the 256 MiB Infinity Cache together: every extra launch cost 10-12 us and nothing came back from the cache,
   // profiles/r04_ab_encoder_subbatch.txt. All frames of a launch go through a layer together.)
@@ -677,21 +708,21 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   }
   mark(ST_POOL, st);
 
-  run_encoder_sf(cnet_, false, B, st, &f);
+  run_encoder_sf(cnet_, false, B, sB, &f, 0, par_ ? enc2_ : nullptr);
   s = conv_shape(cnet_.head, f, 128, (long)N * 128, B, H8, W8, 1, 0, 0);
   conv_sf_dispatch(s, cnet_.head.wscale,
-                   SfContextSplit{cnet_.head.b, h_[0].p, (long)N * 128, x_.p, (long)N * XLD, XLD}, st);
+                   SfContextSplit{cnet_.head.b, h_[0].p, (long)N * 128, x_.p, (long)N * XLD, XLD}, sB);
   mark(ST_CNET, st);
 
   s = conv_shape(to_qk_, x_.p, XLD, (long)N * XLD, B, H8, W8, 1, 0, 0);
-  conv_sf_dispatch(s, to_qk_.wscale, SfQK{1.0f / sqrtf(128.0f), 128, qk_.p, (long)N * 256, 256}, st);
+  conv_sf_dispatch(s, to_qk_.wscale, SfQK{1.0f / sqrtf(128.0f), 128, qk_.p, (long)N * 256, 256}, sB);
   {
     // Q K^T with the row softmax fused in (attention.hip): a cheap first sweep (f16 x f16 logits) for the row maxima,
     // then the full-precision sweep that writes exp(s - max) in MFMA-operand order and the row sums
     const AttnGeom ag = attn_geom(B, N, ldN);
-    launch_qk_rowmax(qk_.p, ag, rowmax_.p, st);
+    launch_qk_rowmax(qk_.p, ag, rowmax_.p, sB);
     mark(ST_ATTN_LOGITS, st);
-    launch_qk_softmax(qk_.p, ag, rowmax_.p, attn_.p, rinv_.p, sf_fast_mode(), st);
+    launch_qk_softmax(qk_.p, ag, rowmax_.p, attn_.p, rinv_.p, sf_fast_mode(), sB);
   }
   mark(ST_ATTN, st);
 
@@ -699,11 +730,12 @@ void GmaNet::run_body_sf(int B, int iters, hipStream_t st) {
   for (int p = 0; p < 2; ++p) {
     const int ph = p ? 2 : 0, pw = p ? 0 : 2;
     ConvShape g = conv_shape(gru_zr_ctx_[p], x_.p, XLD, (long)N * XLD, B, H8, W8, 1, ph, pw);
-    conv_sf_dispatch(g, gru_zr_ctx_[p].wscale, EpiBias<ACT_NONE>{nullptr, pre_zr_[p].p, (long)N * 256, 256, 1.f}, st);
+    conv_sf_dispatch(g, gru_zr_ctx_[p].wscale, EpiBias<ACT_NONE>{nullptr, pre_zr_[p].p, (long)N * 256, 256, 1.f}, sB);
     g = conv_shape(gru_q_ctx_[p], x_.p, XLD, (long)N * XLD, B, H8, W8, 1, ph, pw);
-    conv_sf_dispatch(g, gru_q_ctx_[p].wscale, EpiBias<ACT_NONE>{nullptr, pre_q_[p].p, (long)N * 128, 128, 1.f}, st);
+    conv_sf_dispatch(g, gru_q_ctx_[p].wscale, EpiBias<ACT_NONE>{nullptr, pre_q_[p].p, (long)N * 128, 128, 1.f}, sB);
   }
   mark(ST_GRU_CTX, st);
+  if (par_) fork(sB, st);   // join: the iterations need both chains
 
   for (int it = 0; it < iters; ++it) {
     iteration_sf(B, st);
@@ -726,13 +758,18 @@ void GmaNet::mask_head_sf(int B, hipStream_t st) {
 void GmaNet::capture(int B, int iters) {
   hipGraph_t graph = nullptr;
   ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
+  // parallel branches: low-latency handles, one or two pairs per launch (gma.h)
+  par_ = low_latency_ && precision >= 1 && B <= 2 && par_stream_ != nullptr && !preds_out_;
+  par_next_ = 0;
   try {
     if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, cap_stream_); } else run_body(B, iters, cap_stream_);
   } catch (...) {
+    par_ = false;
     (void)hipStreamEndCapture(cap_stream_, &graph);
     if (graph) (void)hipGraphDestroy(graph);
     throw;
   }
+  par_ = false;
   ATDN_HIP(hipStreamEndCapture(cap_stream_, &graph));
   hipGraphExec_t exec = nullptr;
   ATDN_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));

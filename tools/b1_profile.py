@@ -31,3 +31,30 @@ for k in range(4, 12):
     vo(fr[k])
 torch.cuda.synchronize()
 print("VisualOdometry per frame (host uint8->pose, synchronous): %.2f ms" % ((time.perf_counter() - t0) / 8 * 1e3))
+
+# ---- where a VisualOdometry call goes: the flow network alone (forward_consecutive chain, device frames), the head alone, the call
+from atdn_vslam_amd.modules import ATDNVO, RAFTGMA
+from atdn_vslam_amd.pipeline import resize_frames
+net = RAFTGMA(max_batch=1, low_latency=True)
+net.load_state_dict(gsd)
+net = net.to(dev).eval()
+frd = [resize_frames(f.to(dev).float()) for f in fr]
+for k in range(1, 4):
+    net.forward_consecutive(frd[k - 1], frd[k], iters=12)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for k in range(4, 12):
+    low, up = net.forward_consecutive(frd[k - 1], frd[k], iters=12)
+torch.cuda.synchronize()
+print("flow network, forward_consecutive (low-latency, device frames): %.2f ms per call" % ((time.perf_counter() - t0) / 8 * 1e3))
+head = ATDNVO()
+head.load_state_dict(hsd)
+head = head.to(dev).eval()
+for _ in range(3):
+    head(up)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(8):
+    rot, tr = head(up)
+torch.cuda.synchronize()
+print("pose head (encode + one LSTM step + regressors): %.2f ms per call" % ((time.perf_counter() - t0) / 8 * 1e3))
