@@ -56,12 +56,13 @@ class ClvoNet {
   bool scan_graph_ = true;        // ATDN_NO_GRAPH=1: eager launches
   void launch_scan_steps(int T, int Bs, hipStream_t st);
   // persistent scan (lstm_scan.hip): sequences of one batch row and at least kPersistentMinSteps steps run as ONE
-  // launch. ATDN_SCAN_PERSISTENT=0 keeps the per-step kernel. A launch that gave up on a bounded spin (its outputs are NaN)
-  // leaves a non-zero word in scan_abort_host_ (pinned; copied behind every launch): the next call sees it, says so on stderr
-  // and stays on the per-step kernel.
+  // launch. ATDN_SCAN_PERSISTENT=0 keeps the per-step kernel. A launch that gave up on a bounded spin leaves a non-zero word in
+  // scan_abort_host_ (pinned; copied behind the launch): step() synchronises, sees it, restores the state it saved in
+  // scan_state0_, repeats the sequence on the per-step kernel and stays there (clvo.hip). ATDN_SCAN_TEST_ABORT=1 makes the next
+  // persistent launch of a handle give up at once (the test of that path).
   static constexpr int kPersistentMinSteps = 16;
   bool scan_persistent_ = true;
-  DeviceBuf scan_xch_;
+  DeviceBuf scan_xch_, scan_state0_;
   unsigned int* scan_abort_host_ = nullptr;
 };
 

@@ -28,7 +28,7 @@ ClvoNet::~ClvoNet() {
   for (auto& kv : scan_graphs_) (void)hipGraphExecDestroy(kv.second);
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
   if (scan_abort_host_) (void)hipHostFree(scan_abort_host_);
-  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &pre_, &hseq_, &x2seq_, &hseq2_, &cstate_, &scan_xch_}) b->release();
+  for (DeviceBuf* b : {&in4_, &bufA_, &bufB_, &bufS_, &flat_, &pre_, &hseq_, &x2seq_, &hseq2_, &cstate_, &scan_xch_, &scan_state0_}) b->release();
   arena_.release();
 }
 
@@ -105,6 +105,7 @@ void ClvoNet::finalize() {
   scan_graph_ = !(getenv("ATDN_NO_GRAPH") && getenv("ATDN_NO_GRAPH")[0] == '1');
   scan_persistent_ = !(getenv("ATDN_SCAN_PERSISTENT") && getenv("ATDN_SCAN_PERSISTENT")[0] == '0') && lstm_scan_fits_device();
   scan_xch_.alloc((lstm_scan_exchange_bytes() + 3) / 4);
+  scan_state0_.alloc(4 * 512);
   ATDN_HIP(hipHostMalloc(reinterpret_cast<void**>(&scan_abort_host_), 64, hipHostMallocDefault));
   *scan_abort_host_ = 0u;
   ATDN_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
@@ -203,20 +204,30 @@ void ClvoNet::step(const float* feat, int T, int Bs, float* state, float* rot, f
   gemm(feat, lstm1_ih_, pre_.p, 2048);
   const MlpHead R{rot_[0].w, rot_[0].b, rot_[1].w, rot_[1].b, rot_[2].w};
   const MlpHead Tt{tr_[0].w, tr_[0].b, tr_[1].w, tr_[1].b, tr_[2].w};
-  if (scan_persistent_ && *scan_abort_host_ != 0u) {
-    fprintf(stderr, "atdn: a persistent LSTM scan of this handle gave up on a bounded spin (its poses were NaN); "
-                    "staying on the per-step kernel\n");
-    scan_persistent_ = false;
-  }
-  if (scan_persistent_ && Bs == 1 && T >= kPersistentMinSteps) {
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &capturing);
+  if (scan_persistent_ && Bs == 1 && T >= kPersistentMinSteps && capturing == hipStreamCaptureStatusNone) {
     // ONE launch for the whole sequence (lstm_scan.hip): reads and writes the caller's state in place, h2 of every step into
-    // hseq2_ rows 1..T (where the per-step pipeline leaves them), then both regressors batched over the sequence
+    // hseq2_ rows 1..T (where the per-step pipeline leaves them), then both regressors batched over the sequence.
+    // The launch is VERIFIED before its results are used: the stream is synchronised (a sequence scan is the end of a
+    // sequence: its caller fetches the poses next) and the abort word read; a launch that gave up on a bounded spin —
+    // workgroups that never became resident together — is repeated on the per-step kernel from the saved state, and the handle
+    // stays there. Nobody ever sees the NaN poses the kernel leaves behind on that path.
+    ATDN_HIP(hipMemcpyAsync(scan_state0_.p, state, 4 * 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
     launch_lstm_scan(pre_.p, lstm1_hh_.w, lstm1_hh_.b, lstm_lin_.w, lstm_lin_.b, lstm2_ih_.w, lstm2_ih_.b, lstm2_hh_.w,
                      lstm2_hh_.b, state, hseq2_.p + sb, scan_xch_.p, T, st);
     ATDN_HIP(hipMemcpyAsync(scan_abort_host_, reinterpret_cast<const char*>(scan_xch_.p) + (lstm_scan_exchange_bytes() - 64),
                             sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-    launch_mlp_heads(hseq2_.p + sb, (int)rows, R, Tt, rot, tr, st);
-    return;
+    ATDN_HIP(hipStreamSynchronize(st));
+    if (*scan_abort_host_ == 0u) {
+      launch_mlp_heads(hseq2_.p + sb, (int)rows, R, Tt, rot, tr, st);
+      return;
+    }
+    fprintf(stderr, "atdn: the persistent LSTM scan gave up on a bounded spin (its workgroups were not resident together); "
+                    "repeating the sequence on the per-step kernel and staying there\n");
+    scan_persistent_ = false;
+    *scan_abort_host_ = 0u;
+    ATDN_HIP(hipMemcpyAsync(state, scan_state0_.p, 4 * 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   {
     // lstm1 (step s), lstm_linear (step s - 1) and lstm2 with its input projection (step s - 2) share ONE launch per

@@ -124,6 +124,7 @@ __global__ __launch_bounds__((NWV + 1) * 64) void lstm_scan_kernel(const ScanArg
 #pragma unroll
     for (int t = 0; t < PD; ++t) fetch_p1(t);
     barrier_lds();
+    if (a.mode & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }   // test hook: the launch gives up at once
     const unsigned dead_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) int*)dead;
     for (int s = 0; s < T + 2; ++s) {
       fetch_p1(s + PD);
@@ -176,9 +177,10 @@ __global__ __launch_bounds__((NWV + 1) * 64) void lstm_scan_kernel(const ScanArg
   constexpr int XB = (256 / NWV) * GPW;   // the same units + 256
   barrier_lds();
 
-  bool failed = false;
+  bool failed = (a.mode & 128) != 0;   // ATDN_SCAN_TEST_ABORT: behave like a launch whose spins ran out
+  if (failed && threadIdx.x == 0) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int dly = (a.mode & 15) ? (a.mode & 15) : 8, streak = 0;   // sweepers: delay of the first poll in units of 128 clocks (adaptive)
-  for (int s = 0; s < T + 2; ++s) {
+  for (int s = 0; s < T + 2 && !failed; ++s) {
     const int par = s & 1;
     float* img = lds + par * NGRAN;
     const bool doA = s < T, doC = s >= 2;   // (lstm_linear is live in ticks 1 .. T; nothing of it is carried)
@@ -322,7 +324,7 @@ void launch_lstm_scan(const float* pre1, const float* Whh1, const float* bhh1, c
   ScanArgs a{pre1, Whh1, bhh1, Wlin, blin, Wih2, bih2, Whh2, bhh2, state, h2seq,
              reinterpret_cast<unsigned long long*>(exchange),
              reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(exchange) + (long)(2 * NGRAN) * 8), T,
-             getenv("ATDN_SCAN_MODE") ? atoi(getenv("ATDN_SCAN_MODE")) : 0};
+             (getenv("ATDN_SCAN_MODE") ? atoi(getenv("ATDN_SCAN_MODE")) : 0) | (getenv("ATDN_SCAN_TEST_ABORT") ? 128 : 0)};
   // 128 workgroups of 4 units: one arithmetic wave per SIMD (64 of 8 units: two waves share a SIMD's vector ALU; 2.44 against
   // 2.02 us per tick at each form's best poll delay). ATDN_SCAN_MODE bit 6 selects the 64-workgroup form for comparison.
   if (a.mode & 64) hipLaunchKernelGGL(lstm_scan_kernel<8>, dim3(HD / 8), dim3(9 * 64), 0, st, a);

@@ -128,3 +128,25 @@ def test_persistent_scans_share_the_gpu_with_each_other_and_with_a_flow_forward(
         ra3 = a.scan(fa)
     torch.cuda.synchronize()
     assert torch.equal(ra[0], ra3[0]) and torch.equal(ra[1], ra3[1]) and torch.equal(ra[2], ra3[2])
+
+
+def test_a_persistent_launch_that_gives_up_is_repeated_on_the_per_step_kernel(capfd):
+    """The persistent launch is verified before its results are used (ClvoNet::step synchronises and reads the abort word): a
+    launch that gave up — here forced by ATDN_SCAN_TEST_ABORT — leaves NaN behind, and the caller must never see it: the sequence is
+    repeated on the per-step kernel from the saved state (same bits as a handle that never had the persistent kernel), a line goes
+    to stderr, and the handle stays on the per-step kernel afterwards."""
+    per, one = _head(False), _head(True)
+    f = _feats(200, 33)
+    st0 = torch.from_numpy(np.random.RandomState(4).normal(0, 0.2, (4, 1, 512)).astype(np.float32)).to(DEV)
+    want = per.scan(f, state=st0)
+    os.environ["ATDN_SCAN_TEST_ABORT"] = "1"
+    try:
+        got = one.scan(f, state=st0)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("ATDN_SCAN_TEST_ABORT")
+    assert bool(torch.isfinite(got[0]).all())
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    assert "repeating the sequence on the per-step kernel" in capfd.readouterr().err
+    again = one.scan(f, state=st0)                      # the hook is gone, the handle stays where it is
+    assert torch.equal(again[0], want[0])
