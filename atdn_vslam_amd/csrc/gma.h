@@ -83,6 +83,7 @@ class GmaNet {
   std::vector<hipEvent_t> par_events_;
   size_t par_next_ = 0;
   bool par_ = false;       // true only inside capture() of a low-latency handle
+  bool par_ok_ = true;     // cleared when a capture with branches failed once: later captures are single chains
   void fork(hipStream_t from, hipStream_t to);   // `to` continues from where `from` stands
   DeviceBuf fbrick_[4], fplain_[3], coords_used_;   // features in brick order (levels 0-3), plain pooled features (1-3)
   int brickBW_[4], brickBH_[4], brickNB_[4];

@@ -756,25 +756,39 @@ void GmaNet::mask_head_sf(int B, hipStream_t st) {
 }
 
 void GmaNet::capture(int B, int iters) {
-  hipGraph_t graph = nullptr;
-  ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
-  // parallel branches: low-latency handles, one or two pairs per launch (gma.h)
-  par_ = low_latency_ && precision >= 1 && B <= 2 && par_stream_ != nullptr && !preds_out_;
-  par_next_ = 0;
-  try {
-    if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, cap_stream_); } else run_body(B, iters, cap_stream_);
-  } catch (...) {
-    par_ = false;
-    (void)hipStreamEndCapture(cap_stream_, &graph);
-    if (graph) (void)hipGraphDestroy(graph);
-    throw;
+  // parallel branches: low-latency handles, one or two pairs per launch (gma.h). If a capture with branches cannot be built (a
+  // runtime that refuses the cross-stream dependency), the same body is captured again as one chain: same kernels either way.
+  const bool want_par = low_latency_ && precision >= 1 && B <= 2 && par_stream_ != nullptr && !preds_out_ && par_ok_;
+  for (int attempt = want_par ? 0 : 1; attempt < 2; ++attempt) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ATDN_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
+    par_ = attempt == 0;
+    par_next_ = 0;
+    try {
+      if (precision >= 1) { FastGuard fg(precision == 2); run_body_sf(B, iters, cap_stream_); } else run_body(B, iters, cap_stream_);
+      par_ = false;
+      ATDN_HIP(hipStreamEndCapture(cap_stream_, &graph));
+      ATDN_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    } catch (...) {
+      const bool was_par = par_ || attempt == 0;
+      par_ = false;
+      hipGraph_t g2 = nullptr;
+      (void)hipStreamEndCapture(cap_stream_, &g2);
+      if (g2) (void)hipGraphDestroy(g2);
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      if (attempt == 0 && was_par) {
+        fprintf(stderr, "atdn: the flow graph could not be captured with parallel branches; capturing it as one chain\n");
+        par_ok_ = false;
+        continue;
+      }
+      throw;
+    }
+    (void)hipGraphDestroy(graph);
+    graphs_[{B, iters * 4 + seq_}] = exec;
+    return;
   }
-  par_ = false;
-  ATDN_HIP(hipStreamEndCapture(cap_stream_, &graph));
-  hipGraphExec_t exec = nullptr;
-  ATDN_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-  (void)hipGraphDestroy(graph);
-  graphs_[{B, iters * 4 + seq_}] = exec;
 }
 
 void GmaNet::forward_sequence(const float* frames, int B, int iters, const float* flow_init, float* flow_low,
