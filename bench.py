@@ -372,6 +372,12 @@ def main():
             torch.cuda.synchronize()
         except Exception as e:   # noqa: BLE001 — one rank failing in warm-up must not leave the others in the barrier
             err = e
+        # ... and the collective of the tail at the size the timed region uses (the first all-gather of a size sets up RCCL's
+        # buffers and protocol for it: that belongs in the warm-up). Every rank takes part, failed or not (sharding.gather_features
+        # carries a failure to every rank), so it doubles as the barrier that agrees on failure.
+        if dist_on:
+            gather_features(None if err is not None else feats[:K * B], world * K * B, error=err, device=dev)
+            err = None
         # barrier that agrees on failure (sharding.rendezvous: one small all-gather of status rows; every rank raises if
         # any rank did), then the contract's plain barrier
         rendezvous(err, device=dev)
