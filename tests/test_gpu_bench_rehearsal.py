@@ -87,3 +87,27 @@ def test_bench_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config3"]["pairs"] == 39
     assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_reason"]
+
+
+def test_bench_line_carries_the_secondary_legs():
+    """One GPU, no launcher: the line the driver records. Beside `value` it carries `roofline`, the legs round 6 added — `f32_exact`
+    (what the saturation fallback costs) and `per_frame` (the reference's one-frame-per-call pattern) — and `f16_fast`; none of
+    them is `value`."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-h2d-leg",
+           "--no-config3"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["vs_baseline"] is None and d["scaling"] == "weak"
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    f32 = d["f32_exact"]
+    assert 0 < f32["value"] < d["value"] and abs(f32["ratio_to_value"] - f32["value"] / d["value"]) < 1e-9
+    assert f32["flow_up_abs_diff_vs_split_f16_px"]["max"] < 1e-3        # the two fp32-grade modes agree inside the stated tolerance
+    pf = d["per_frame"]
+    assert 0 < pf["value"] < d["value"] and abs(pf["value"] * pf["ms_per_frame"] - 1e3) < 1e-6 * 1e3
+    assert d["f16_fast"]["value"] > d["value"]
+    assert d["cpu_baseline"] is None and d["cpu_baseline_reason"] == "--no-cpu-baseline"
