@@ -227,12 +227,16 @@ class VisualOdometry:
 
     @torch.no_grad()
     def __call__(self, im):
-        im = resize_frames(im.to(self.device).float())
+        im = im.to(self.device)
+        im = resize_frames(im if im.dtype == torch.uint8 else im.float())   # (uint8 frames are converted inside the resize kernel)
+        if im.dtype != torch.float32:
+            im = im.float()
         im = self.pipe.padder.pad(im)[0]
         if self._prev is not None:
             # (pair mode's bits; the previous frame's features are reused when the chain of calls is unbroken)
             _, flow = self.pipe.flow_net.forward_consecutive(self._prev, im, iters=self.pipe.iters)
             rot, tr = self.pipe.head(flow)
-            self.current_pose = transforms.accumulate(self.current_pose, rot.squeeze().cpu(), tr.squeeze().cpu())
+            rt = torch.cat([rot.reshape(-1), tr.reshape(-1)]).cpu()   # one trip to the host for both vectors
+            self.current_pose = transforms.accumulate(self.current_pose, rt[:3], rt[3:])
         self._prev = im
         return self.current_pose

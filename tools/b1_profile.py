@@ -22,7 +22,7 @@ for B in (1, 2, 4, 16):
     del pipe
 print(json.dumps(out))
 vo = VisualOdometry(gsd, hsd, device=dev, iters=12)
-fr = torch.from_numpy(syn.make_frames(12, 376, 1241, seed=21))
+fr = torch.from_numpy(syn.make_frames(12, 376, 1241, seed=21)).round().clamp(0, 255).to(torch.uint8)   # what a camera delivers
 for k in range(4):
     vo(fr[k])
 torch.cuda.synchronize()
@@ -30,7 +30,7 @@ t0 = time.perf_counter()
 for k in range(4, 12):
     vo(fr[k])
 torch.cuda.synchronize()
-print("VisualOdometry per frame (host uint8->pose, synchronous): %.2f ms" % ((time.perf_counter() - t0) / 8 * 1e3))
+print("VisualOdometry per frame (host uint8 frame -> pose on the host, synchronous): %.2f ms" % ((time.perf_counter() - t0) / 8 * 1e3))
 
 # ---- where a VisualOdometry call goes: the flow network alone (forward_consecutive chain, device frames), the head alone, the call
 from atdn_vslam_amd.modules import ATDNVO, RAFTGMA
