@@ -158,7 +158,10 @@ class NeuralSLAM:
     @torch.no_grad()
     def __call__(self, im):
         if self._mode == "odometry":
-            im = resize_frames(im.to(self._device).float(), SLAM_SIZE)
+            im = im.to(self._device)
+            im = resize_frames(im if im.dtype == torch.uint8 else im.float(), SLAM_SIZE)   # (uint8: converted inside the resize kernel)
+            if im.dtype != torch.float32:
+                im = im.float()
             if self._image_buffer is not None:
                 im2 = self._padder.pad(im)[0]
                 # (pair mode's bits, one feature-network pass per frame while the chain of odometry calls is unbroken)
