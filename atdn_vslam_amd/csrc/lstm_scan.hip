@@ -86,7 +86,7 @@ struct ScanArgs {
   const float *Whh1, *bhh1, *Wlin, *blin, *Wih2, *bih2, *Whh2, *bhh2;
   float* state;                      // [4][512]: h1, c1, h2, c2 — read at the start, written at the end
   float* h2seq;                      // [T][512]: lstm2's hidden state after every step (input of the regressors)
-  unsigned long long* xch;           // [2 slots][64 workgroups][24 granules: h1 | lin | h2 of the workgroup's 8 units]
+  unsigned long long* xch;           // [2 slots][workgroup][h1 | lin | h2][unit of the workgroup]: 3 x 512 granules per slot
   unsigned int* abort_word;          // behind the granules
   int T;
   int mode;                          // diagnostics (ATDN_SCAN_MODE): bits 0-3 initial poll delay, 16 no arithmetic, 32 no sweep (both: timing only), 64 the 64-workgroup form
@@ -102,10 +102,10 @@ template <int NWV>
 __global__ __launch_bounds__((NWV + 1) * 64) void lstm_scan_kernel(const ScanArgs a) {
   constexpr int GPW = 3 * NWV;
   static_assert(NWV == 4 || NWV == 8, "operand runs of four units must stay inside one workgroup's block");
-  // ONE LDS object. Image of a tick's inputs in the order they were published: [workgroup 64][h1 | lin | h2][unit 8]
+  // ONE LDS object. Image of a tick's inputs in the order they were published: [workgroup][h1 | lin | h2][unit of the workgroup]
   __shared__ __attribute__((aligned(16))) float lds[2 * NGRAN + 8 * 32 + 32 + 4];
-  float* p1s = lds + 2 * NGRAN;                                         // [8 ring slots][gate 4][unit 8]
-  float* pub = p1s + 8 * 32;                                                // [h1 | lin | h2][unit 8] of this tick
+  float* p1s = lds + 2 * NGRAN;                                             // [8 ring slots][gate 4][unit NWV] (32 floats apart)
+  float* pub = p1s + 8 * 32;                                                // [h1 | lin | h2][unit NWV] of this tick
   int* dead = reinterpret_cast<int*>(pub + 32);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = a.T;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__((NWV + 1) * 64) void lstm_scan_kernel(const ScanArg
   unsigned h2mask = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) h2mask |= ((((wave % 3) * 8 + i) * 64 + lane) % GPW >= 2 * NWV ? 1u : 0u) << i;
-  // operand addresses in the image: units 4 l .. 4 l + 3 (workgroup l / 2, half l & 1) and 256 + the same
+  // operand addresses in the image: units 4 l .. 4 l + 3 (workgroup 4 l / NWV, offset 4 l % NWV) and 256 + the same
   const int xo = ((4 * lane) / NWV) * GPW + (4 * lane) % NWV;
   constexpr int XB = (256 / NWV) * GPW;   // the same units + 256
   barrier_lds();
