@@ -146,8 +146,9 @@ class RAFTGMA(_NativeModule):
     def __init__(self, args=None, max_batch=1, precision=None, saturation_check_every=512, saturation_fallback=False,
                  low_latency=False):
         """`low_latency=True`: the form for the reference's per-frame call pattern (neural_slam.py:202: ONE pair per call) — launches
-        that would leave most of the chip idle at one to four pairs are cut finer (attention x V along its key axis: a single-pair
-        forward 7.1 -> 5.2 ms). Same flow within rounding (~1e-6 px), NOT bit-identical to the default path, whose clip,
+        that would leave most of the chip idle at one to four pairs are cut finer (attention x V along its key axis) and independent
+        chains of the captured graph run as parallel branches: a single-pair forward 6.9 -> 4.9 ms. Same flow within rounding
+        (8e-5 px at KITTI size after 12 iterations), NOT bit-identical to the default path, whose clip,
         continued-clip and pair modes are bit-identical to each other; pipeline.VisualOdometry and slam.NeuralSLAM ask for it.
         `saturation_check_every`: in the split-f16 modes the module reads the library's saturation counter after the
         FIRST forward of a freshly loaded checkpoint (and whenever the weights changed), then every that many forwards
