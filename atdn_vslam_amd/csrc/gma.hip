@@ -758,7 +758,9 @@ void GmaNet::mask_head_sf(int B, hipStream_t st) {
 void GmaNet::capture(int B, int iters) {
   // parallel branches: low-latency handles, one or two pairs per launch (gma.h). If a capture with branches cannot be built (a
   // runtime that refuses the cross-stream dependency), the same body is captured again as one chain: same kernels either way.
-  const bool want_par = low_latency_ && precision >= 1 && B <= 2 && par_stream_ != nullptr && !preds_out_ && par_ok_;
+  // (ATDN_PAR_FORCE=1: branches at any batch size — the A/B of DESIGN.md section 10.8, nothing else)
+  static const bool par_force = getenv("ATDN_PAR_FORCE") && getenv("ATDN_PAR_FORCE")[0] == '1';
+  const bool want_par = low_latency_ && precision >= 1 && (B <= 2 || par_force) && par_stream_ != nullptr && !preds_out_ && par_ok_;
   for (int attempt = want_par ? 0 : 1; attempt < 2; ++attempt) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
