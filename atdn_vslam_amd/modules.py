@@ -116,6 +116,7 @@ class _NativeModule(nn.Module):
     def _apply(self, fn, *args, **kw):
         # .to() / .cuda() / .float(): parameters move, handles built from the old ones are stale
         out = super()._apply(fn, *args, **kw)
+        self._fp_slots = None   # (collected again on the next forward: cheap, and indifferent to how _apply replaced the leaves)
         self._drop_handles()
         return out
 
