@@ -18,6 +18,7 @@
 // VMEM instructions. Epilogues without it (InstanceNorm statistics need the pixel-major registers) keep the
 // classic orientation.
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 #include "conv_sf.h"
 
@@ -914,7 +915,9 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
   // exactly as out of a single-pair call). Not for the statistics epilogues (their tile height follows from the layer's geometry
   // alone) nor the fused flow head (one block holds all channels of its pixels).
   if constexpr (!Epi::kStats && !epi_flowhead<Epi>::value) {
-    if (bn == 64 && tiles * cdiv(s.N, 64) < 300) {
+    // (ATDN_CONV_SMALL_TILES=1: the 4 x 16 x 64 form for every 1x5 / 5x1 convolution at ANY grid size — the A/B of DESIGN.md 10.8)
+    static const bool force_small = getenv("ATDN_CONV_SMALL_TILES") && getenv("ATDN_CONV_SMALL_TILES")[0] == '1';
+    if ((bn == 64 && tiles * cdiv(s.N, 64) < 300) || (force_small && KH != 3)) {
       *bn_out = 64; *th_out = 4;
       launch_conv_sf6_m<4, 64, 2, 2, KH, KW, Epi, FAST, false>(s, wscale, ep, st);
       return true;
