@@ -923,6 +923,16 @@ inline bool conv_sf6_try_shape(const ConvShape& s, float wscale, const Epi& ep, 
       return true;
     }
   }
+  if constexpr (KH != 3 && !Epi::kStats && !epi_flowhead<Epi>::value) {
+    // (ATDN_CONV_SMALL_TILES=2: 4 x 16-pixel x 128-channel blocks for the 1x5 / 5x1 convolutions — half the row tiles per wave of the
+    // shipped 8 x 16 x 128 block, so fewer registers: the A/B of DESIGN.md 10.8)
+    static const bool half128 = getenv("ATDN_CONV_SMALL_TILES") && getenv("ATDN_CONV_SMALL_TILES")[0] == '2';
+    if (half128 && bn == 128) {
+      *bn_out = 128; *th_out = 4;
+      launch_conv_sf6_m<4, 128, 1, 4, KH, KW, Epi, FAST, false>(s, wscale, ep, st);
+      return true;
+    }
+  }
   if constexpr (KH == 3) {
     if (bn == 32) { *bn_out = 32; launch_conv_sf6_m<8, 32, 4, 1, KH, KW, Epi, FAST, false>(s, wscale, ep, st); return true; }
     const long tiles12 = (long)s.nimg * cdiv(Wo, 16) * cdiv(Ho, 12);
